@@ -1,0 +1,164 @@
+/*
+ * s2r.h — C ABI of libs2r: the MI355X (gfx950) voice-render path behind s2_lib's
+ * buffer-fill API.
+ *
+ * This is the drop-in boundary.  Each entry point names the reference interface it
+ * replaces (paths relative to /root/reference/components/s2_lib/src/try3/).  The
+ * reference's public surface is `synth::Synth::{new, note_on, note_off, sample}`
+ * (synth.rs:53-80,154-169) as used by s2_bin (components/s2_bin/src/main.rs:132-147,
+ * 198-205); rust/s2_lib_gpu/src/lib.rs wraps this header back into exactly those
+ * signatures, include/s2_synth.hpp does the same for C++.
+ *
+ * Conventions
+ *   - every function returns an s2r_status (0 = ok, < 0 = error); nothing unwinds or
+ *     aborts across the boundary (the reference panics instead: process.rs:36,71);
+ *   - a handle is NOT thread-safe: one caller thread at a time, like `&mut Synth`;
+ *   - s2r_fill OVERWRITES the caller's buffer (synth.rs:201-202) and returns when it is
+ *     complete; no allocation happens inside fill;
+ *   - note events take effect at the next fill boundary (s2_bin applies MIDI between
+ *     `sample` calls: main.rs:140-147);
+ *   - the library needs a gfx950 device: s2r_create fails with S2R_ERR_NO_DEVICE
+ *     otherwise.  There is no CPU fallback.
+ */
+#ifndef S2R_H
+#define S2R_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S2R_ABI_VERSION 1
+
+typedef enum {
+    S2R_OK = 0,
+    S2R_ERR_INVALID = -1,          /* bad argument / null handle */
+    S2R_ERR_NO_DEVICE = -2,        /* no usable gfx950 device */
+    S2R_ERR_HIP = -3,              /* a HIP runtime call failed; see s2r_last_error */
+    S2R_ERR_PATCH_SYNTAX = -4,     /* .synth2 text rejected */
+    S2R_ERR_PATCH_RANGE = -5,      /* value outside its unit's range (units.rs:55-65) */
+    S2R_ERR_TOO_MANY_FRAMES = -6,  /* frames > max_frames given at create */
+    S2R_ERR_OFFSET_OVERFLOW = -7,  /* a voice's frame offset would pass u32::MAX: the
+                                      reference panics here (process.rs:36 "overflow") */
+    S2R_ERR_OUT_OF_MEMORY = -8
+} s2r_status;
+
+/* static_config.rs:26-32 (declaration order) */
+typedef enum { S2R_OSC_SQUARE = 0, S2R_OSC_SAW = 1, S2R_OSC_TRIANGLE = 2, S2R_OSC_SINE = 3 } s2r_osc_kind;
+
+/* static_config.rs:38-44  sc::Adsr  (Ms, Ms, Unipolar<1>, Ms) */
+typedef struct { float attack_ms, decay_ms, sustain, release_ms; } s2r_adsr;
+
+/* static_config.rs:4-24  sc::Layer — the patch.  ONE patch is shared by all voices, as in
+ * the reference (synth.rs:10). */
+typedef struct {
+    int32_t osc_kind;              /* s2r_osc_kind          sc::Oscillator.kind */
+    float osc_gain;                /* Unipolar<1>           sc::Oscillator.gain */
+    float noise;                   /* Unipolar<1>           sc::Layer.noise */
+    float lpf_freq;                /* Hz                    sc::LowPassFilter.freq */
+    s2r_adsr amp_env;
+    s2r_adsr mod_env;
+    float mod_env_to_osc_freq;     /* Bipolar<10>           sc::Modulations */
+    float mod_env_to_lpf_freq;     /* Bipolar<10> */
+} s2r_patch;
+
+typedef struct {
+    uint32_t struct_size;          /* = sizeof(s2r_config) */
+    uint32_t total_voices;         /* size of the voice pool; the reference fixes it at
+                                      NUM_VOICES = 8 (synth.rs:7) */
+    uint32_t shard_begin;          /* first pool index rendered by THIS handle */
+    uint32_t shard_voices;         /* voices rendered by this handle; 0 => total_voices.
+                                      Voice allocation always runs over the whole pool, so
+                                      every shard's handle must see the same event stream */
+    uint32_t max_frames;           /* largest `frames` a fill will be asked for */
+    int32_t device;                /* HIP device ordinal; -1 => current device */
+    uint32_t block_voices;         /* voices per workgroup: 64..1024, multiple of 64;
+                                      0 => 256.  Part of the mix-tree spec */
+    uint32_t mix_groups;           /* >= 1: second-level grouping of the block partials so a
+                                      1-GPU run reproduces the G-GPU summation order; 0 => 1 */
+} s2r_config;
+
+/* One voice's complete state, for checkpoint/resume and tests.
+ * synth.rs:23-30 (Voice) + state.rs:10-21 (st::Layer). */
+typedef struct {
+    uint8_t note;                  /* Voice.note */
+    uint8_t started;               /* current_frame_offset.is_some() */
+    uint8_t released;              /* release_frame_offset.is_some() */
+    uint8_t _pad;
+    uint32_t current_frame_offset;
+    uint32_t release_frame_offset;
+    float pitch_hz;                /* note_to_pitch(note), synth.rs:208-212 */
+    float phase_accum;             /* OscillatorState (None == 0.0, oscillators.rs:483) */
+    float lpf_last;                /* LowPassFilterState.last */
+    uint32_t noise_seed;           /* NoiseState.seed (always 0 in the reference, synth.rs:68) */
+    float velocity;                /* stored, never used in rendering (synth.rs:18,26) */
+} s2r_voice_state;
+
+typedef struct s2r_synth s2r_synth;
+
+/* Synth::new (synth.rs:54-59): default_config() patch, all voices idle. */
+int s2r_create(const s2r_config *cfg, s2r_synth **out);
+void s2r_destroy(s2r_synth *s);
+
+/* The `.synth2` patch text (example.synth2:1-3 sketches `synth <ident> { }`; the reference
+ * ships no loader — grammar in DESIGN.md).  An empty body == Synth::default_config()
+ * (synth.rs:125-152). */
+int s2r_load_patch(s2r_synth *s, const char *text, size_t len);
+int s2r_set_patch(s2r_synth *s, const s2r_patch *patch);
+int s2r_get_patch(const s2r_synth *s, s2r_patch *out);
+void s2r_default_patch(s2r_patch *out);                      /* synth.rs:125-152 */
+
+/* Synth::note_on(Note, Velocity) (synth.rs:61-70) incl. next_voice (synth.rs:101-120).
+ * Optionally reports the chosen pool index. */
+int s2r_note_on(s2r_synth *s, uint8_t note, float velocity);
+int s2r_note_on_ex(s2r_synth *s, uint8_t note, float velocity, uint32_t *voice_index_out);
+/* Synth::note_off(Note) (synth.rs:72-96): last active voice holding `note`. */
+int s2r_note_off(s2r_synth *s, uint8_t note);
+
+/* Synth::sample(&mut [f32], SampleRateKhz) (synth.rs:154-169).  `sample_rate_hz` is what
+ * the reference calls SampleRateKhz but holds Hz (units.rs:14).  Full 16-frame chunks take
+ * the x16 code path, a tail of frames % 16 the scalar path, restarting per call
+ * (synth.rs:158, process.rs:25-48).  Output = the mix of this handle's shard, root-added to
+ * +0.0 (synth.rs:176). */
+int s2r_fill(s2r_synth *s, float *mono_out, size_t frames, uint32_t sample_rate_hz);
+/* The audio callback's mono -> every channel copy (s2_bin/src/audio_player.rs:224-228),
+ * done on device: interleaved L,R with L == R. */
+int s2r_fill_stereo(s2r_synth *s, float *interleaved_lr_out, size_t frames, uint32_t sample_rate_hz);
+
+/* Multi-GPU building block: renders this shard and leaves its PARTIAL mix (no root add) in
+ * `dev_partial_out` (device memory, `frames` floats) on `hip_stream` (a hipStream_t, may
+ * be NULL) without synchronising.  Partials of all shards are then combined in rank order
+ * by s2r_sum_partials_device. */
+int s2r_fill_device(s2r_synth *s, float *dev_partial_out, size_t frames, uint32_t sample_rate_hz, void *hip_stream);
+/* out[i] = ((+0.0 + rows[0][i]) + rows[1][i]) + ...   rows is [n_rows][frames] on device. */
+int s2r_sum_partials_device(const float *dev_rows, uint32_t n_rows, size_t frames, float *dev_out, void *hip_stream);
+
+/* Mix disabled: every shard voice's frames, host array [shard_voices][frames] (rows of idle
+ * voices are +0.0).  Advances state exactly like s2r_fill.  process::process_layer_buf_simd
+ * per voice (process.rs:14-49). */
+int s2r_render_voices(s2r_synth *s, float *per_voice_out, size_t frames, uint32_t sample_rate_hz);
+
+/* Checkpoint / resume and test access; `voices` has shard_voices entries. */
+int s2r_export_state(s2r_synth *s, s2r_voice_state *voices);
+int s2r_import_state(s2r_synth *s, const s2r_voice_state *voices);
+/* NoiseState.seed of one pool voice ("todo don't default this", state.rs:19). */
+int s2r_set_noise_seed(s2r_synth *s, uint32_t voice_index, uint32_t seed);
+
+/* Introspection */
+uint32_t s2r_abi_version(void);
+uint32_t s2r_shard_voices(const s2r_synth *s);
+uint32_t s2r_block_voices(const s2r_synth *s);
+uint64_t s2r_double_release_count(const s2r_synth *s);      /* synth.rs:77 warn counter */
+/* device time of the most recent fill's render kernel in milliseconds (HIP events recorded
+ * on the library's stream around the launch); < 0 if timing is off.  Enable with
+ * s2r_set_timing(s, 1): adds two event records per fill. */
+int s2r_set_timing(s2r_synth *s, int enabled);
+float s2r_last_render_ms(s2r_synth *s);
+const char *s2r_last_error(const s2r_synth *s);             /* never NULL */
+const char *s2r_status_string(int status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S2R_H */

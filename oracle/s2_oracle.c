@@ -1,0 +1,621 @@
+/*
+ * s2_oracle.c — CPU ORACLE.  TEST INFRASTRUCTURE ONLY (see s2_oracle.h).
+ *
+ * Restates, function by function, the reference's voice-render path.  Citations are
+ * relative to /root/reference/components/s2_lib/src/.  The arithmetic follows the
+ * reference's default build: cargo feature "fma" ON (components/s2_lib/Cargo.toml:6-8),
+ * no contraction / fast-math otherwise.  Build with -ffp-contract=off.
+ *
+ * The x16 path (what runs for every buffer length that is a multiple of 16) and the
+ * scalar "sisd" tail path are both here and deliberately DISAGREE exactly where the
+ * reference does (process.rs:342-345,353-356 add the gains; process.rs:287,292 multiply).
+ */
+#include "s2_oracle.h"
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ units.rs */
+
+/* units.rs:44-53  Ms::as_samples: seconds = ms / 1000.0; samples = sample_rate * seconds */
+float s2o_ms_as_samples(float ms, uint32_t sample_rate) {
+    float sr = (float)sample_rate;
+    float seconds = ms / 1000.0f;
+    return sr * seconds;
+}
+
+/* units.rs:19-26 / 32-42  Hz::as_samples: sample_rate / hz */
+static float hz_as_samples(float hz, uint32_t sample_rate) {
+    return (float)sample_rate / hz;
+}
+
+/* ------------------------------------------------------------------ math.rs */
+
+/* math.rs:11-19 (scalar) and :27-40 (x16), feature fma: slope = rise/run; fma(slope,x,y0) */
+static float line_fma(float y_rise, float x_run, float x_value, float y_offset) {
+    float slope = y_rise / x_run;
+    return fmaf(slope, x_value, y_offset);
+}
+
+/* old/simdtest.rs:247-261: the x16 ADSR's own helper — divide, multiply, add (no fma) */
+static float line_nofma(float y_rise, float x_run, float x_value, float y_offset) {
+    float slope = y_rise / x_run;
+    float y_value = slope * x_value;
+    return y_value + y_offset;
+}
+
+/* Rust `as u32` / Simd::cast::<u32>() on f32: saturating, NaN -> 0 */
+static uint32_t f32_as_u32(float f) {
+    if (!(f > 0.0f)) return 0;            /* negative, -0, NaN */
+    if (f >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)f;
+}
+
+/* ------------------------------------------------------------------ envelopes */
+
+/* old/simdtest.rs:270-331  AdsrX16::sample, one lane at a time */
+void s2o_adsr_x16(float attack, float decay, float sustain, float release,
+                  const uint32_t offset_u[16], int has_release, uint32_t release_offset_u,
+                  float out[16]) {
+    for (int i = 0; i < 16; i++) {
+        float offset = (float)offset_u[i];                                  /* :277-279 */
+        float decay_offset = attack;                                        /* :281 */
+        float sustain_offset = attack + decay;                              /* :282 */
+        float release_offset = (float)(has_release ? release_offset_u : 0xffffffffu); /* :283 */
+        release_offset = fmaxf(release_offset, sustain_offset);             /* :285 simd_max */
+        float end_offset = release_offset + release;                        /* :286 */
+
+        int in_attack = offset < decay_offset;                              /* :288-292 */
+        int in_decay = !in_attack && offset < sustain_offset;
+        int in_sustain = !in_attack && !in_decay && offset < release_offset;
+        int in_release = !in_attack && !in_decay && !in_sustain && offset < end_offset;
+        int in_end = !in_attack && !in_decay && !in_sustain && !in_release;
+
+        float attack_sample = line_nofma(1.0f, attack, offset, 0.0f);                         /* :294-300 */
+        float decay_sample = line_nofma(sustain - 1.0f, decay, offset - decay_offset, 1.0f);  /* :302-308 */
+        float sustain_sample = sustain;                                                       /* :310 */
+        float release_sample = line_nofma(-sustain, release, offset - release_offset, sustain); /* :312-318 */
+        float end_sample = 0.0f;
+
+        float sample = 0.0f;                                                /* :322-327 */
+        if (in_attack) sample = attack_sample;
+        if (in_decay) sample = decay_sample;
+        if (in_sustain) sample = sustain_sample;
+        if (in_release) sample = release_sample;
+        if (in_end) sample = end_sample;
+        out[i] = sample;
+    }
+}
+
+/* envelopes.rs:21-150  Adsr::sample (scalar path; release starts from the CURRENT level) */
+float s2o_adsr_scalar(float attack, float decay, float sustain, float release,
+                      uint32_t offset_u, int has_release, uint32_t release_offset_u) {
+    float offset = (float)offset_u;                                          /* :32 */
+    float decay_offset = attack;
+    float sustain_offset = attack + decay;
+    float release_offset = (float)(has_release ? release_offset_u : 0xffffffffu); /* :35 */
+    float end_offset = release_offset + release;
+
+    int in_release = offset >= release_offset && offset < end_offset;       /* :39-43 */
+    int in_end = offset >= end_offset;
+    int in_attack = !in_release && !in_end && offset < decay_offset;
+    int in_decay = !in_release && !in_end && !in_attack && offset < sustain_offset;
+    int in_sustain = !in_release && !in_end && !in_attack && !in_decay && offset < release_offset;
+
+    /* :57-63 release_start_stage, :68-93 release_start_sample */
+    float release_start_sample;
+    if (release_offset < decay_offset)
+        release_start_sample = line_fma(1.0f, attack, release_offset, 0.0f);
+    else if (release_offset < sustain_offset)
+        release_start_sample = line_fma(sustain - 1.0f, decay, release_offset - decay_offset, 1.0f);
+    else
+        release_start_sample = sustain;
+
+    if (in_attack) return line_fma(1.0f, attack, offset, 0.0f);                            /* :96-107 */
+    if (in_decay) return line_fma(sustain - 1.0f, decay, offset - decay_offset, 1.0f);     /* :108-119 */
+    if (in_sustain) return sustain;                                                        /* :120-127 */
+    if (in_release)                                                                        /* :128-139 */
+        return line_fma(-release_start_sample, release, offset - release_offset, release_start_sample);
+    return 0.0f;                                                                           /* :140-147 */
+}
+
+/* ------------------------------------------------------------------ hashnoise.rs */
+
+#define SEED32 0x9e3779b9u                                                  /* :7 */
+
+uint32_t s2o_hash_word(uint32_t start, uint32_t word) {                      /* :53-55 */
+    uint32_t rot = (start << 5) | (start >> 27);
+    return (rot ^ word) * SEED32;
+}
+
+void s2o_hash_word_x16(const uint32_t start[16], const uint32_t word[16], uint32_t out[16]) { /* :57-68 */
+    for (int i = 0; i < 16; i++) {
+        uint32_t leftshift = start[i] << 5;
+        uint32_t rightshift = start[i] >> (32 - 5);
+        uint32_t rotated = leftshift | rightshift;
+        out[i] = (rotated ^ word[i]) * SEED32;
+    }
+}
+
+float s2o_hash_noise(uint32_t seed, float offset) {                          /* :14-27 */
+    uint32_t off = f32_as_u32(offset);
+    uint32_t hash = s2o_hash_word(seed, off);
+    uint16_t value16 = (uint16_t)hash;
+    float value = (float)value16;
+    float u16_max = 65535.0f;
+    return value / u16_max * 2.0f - 1.0f;
+}
+
+void s2o_hash_noise_x16(uint32_t seed, const float offset[16], float out[16]) { /* :33-51 */
+    uint32_t off[16], start[16], hash[16];
+    for (int i = 0; i < 16; i++) { off[i] = f32_as_u32(offset[i]); start[i] = seed; }
+    s2o_hash_word_x16(start, off, hash);
+    for (int i = 0; i < 16; i++) {
+        uint16_t v16 = (uint16_t)hash[i];        /* cast::<u16>() truncates */
+        float value = (float)v16;
+        out[i] = value / 65535.0f * 2.0f - 1.0f;
+    }
+}
+
+/* ------------------------------------------------------------------ tables.rs / lookup.rs */
+
+static float g_sin_table[1024];
+static pthread_once_t g_sin_once = PTHREAD_ONCE_INIT;
+
+/* components/s2_bin/src/tables.rs:6-10: i = i as f32 / 1024.0; i = i * PI * 2.0; sin(i).
+ * The literals the reference ships (s2_lib try3/tables.rs:2-1025) equal the correctly
+ * rounded f32 sine of that f32 argument everywhere except four entries that the author's
+ * libm rounded one ULP further from zero; tests/test_sin_table.py diffs this against the
+ * reference file whenever /root/reference is present and pins CRC32 0x55293b66. */
+static void sin_table_init(void) {
+    for (int k = 0; k < 1024; k++) {
+        float i = (float)k / 1024.0f;
+        i = i * 3.14159274101257324f * 2.0f;
+        g_sin_table[k] = (float)sin((double)i);
+    }
+    static const int plus_one_ulp_in_magnitude[4] = { 395, 399, 610, 627 };
+    for (int j = 0; j < 4; j++) {
+        uint32_t u; memcpy(&u, &g_sin_table[plus_one_ulp_in_magnitude[j]], 4);
+        u += 1;
+        memcpy(&g_sin_table[plus_one_ulp_in_magnitude[j]], &u, 4);
+    }
+}
+const float *s2o_sin_table(void) { pthread_once(&g_sin_once, sin_table_init); return g_sin_table; }
+
+/* lookup.rs:10-44  table_lookup_exclusive */
+float s2o_table_lookup_exclusive(const float *table, uint32_t len, float value, float range, int *panicked) {
+    float table_length = (float)len;
+    float table_value = value * table_length / range;                       /* :22 */
+    uint32_t low = f32_as_u32(table_value);                                  /* :23 */
+    uint32_t idx1 = low;
+    uint32_t idx2 = (idx1 + 1u) % len;                                       /* :26 (u32 +1: debug-overflow aside) */
+    float low_f = (float)low;
+    if (idx1 >= len) { if (panicked) *panicked = 1; return 0.0f; }           /* :31 index panic */
+    float sample1 = table[idx1], sample2 = table[idx2];
+    return line_fma(sample2 - sample1, 1.0f, table_value - low_f, sample1);  /* :34-42 */
+}
+
+/* lookup.rs:92-130  table_lookup_inclusive */
+float s2o_table_lookup_inclusive(const float *table, uint32_t len, float value, float range, int *panicked) {
+    float table_length = (float)(len ? len - 1u : 0u);                       /* :106-108 */
+    float table_value = value * table_length / range;
+    uint32_t low = f32_as_u32(table_value);
+    uint32_t idx1 = low;
+    uint32_t idx2 = (idx1 + 1u) % len;
+    float low_f = (float)low;
+    if (idx1 >= len) { if (panicked) *panicked = 1; return 0.0f; }
+    float sample1 = table[idx1], sample2 = table[idx2];
+    return line_fma(sample2 - sample1, 1.0f, table_value - low_f, sample1);
+}
+
+static void lookup_x16(const float *table, uint32_t len, float table_length,
+                       const float value[16], const float range[16], float out[16]) {
+    for (int i = 0; i < 16; i++) {
+        float table_value = value[i] * table_length / range[i];              /* :63 / :150 */
+        uint32_t low = f32_as_u32(table_value);                              /* :64 cast::<u32>() */
+        uint32_t idx1 = low;
+        uint32_t idx2 = (idx1 + 1u) % len;                                   /* :67 wrapping simd add */
+        float low_f = (float)low;
+        float sample1 = idx1 < len ? table[idx1] : 0.0f;                     /* :72 gather_or_default */
+        float sample2 = idx2 < len ? table[idx2] : 0.0f;
+        out[i] = line_fma(sample2 - sample1, 1.0f, table_value - low_f, sample1); /* :75-84 */
+    }
+}
+
+/* lookup.rs:46-85 */
+void s2o_table_lookup_exclusive_x16(const float *table, uint32_t len, const float value[16], const float range[16], float out[16]) {
+    lookup_x16(table, len, (float)len, value, range, out);
+}
+/* lookup.rs:132-172 */
+void s2o_table_lookup_inclusive_x16(const float *table, uint32_t len, const float value[16], const float range[16], float out[16]) {
+    lookup_x16(table, len, (float)(len ? len - 1u : 0u), value, range, out);
+}
+/* lookup.rs:187-199 */
+void s2o_table_lookup_periodic_x16(const float *table, uint32_t len, const float value[16], const float range[16], float out[16]) {
+    float v[16];
+    for (int i = 0; i < 16; i++) v[i] = fmodf(value[i], range[i]);
+    s2o_table_lookup_exclusive_x16(table, len, v, range, out);
+}
+
+/* ------------------------------------------------------------------ filters.rs */
+
+/* filters.rs:16-34  LowPassFilter::process (feature fma) */
+float s2o_lpf_process(float *last, uint32_t sample_rate_u, float freq, float input) {
+    float sample_rate = (float)sample_rate_u;
+    const float pi = 3.14159274101257324f;
+    float x = expf(-2.0f * pi * freq / sample_rate);        /* ((-2*pi)*freq)/sr ; Rust f32::exp = libm expf */
+    float a0 = 1.0f - x;
+    float b1 = -x;
+    float out = fmaf(a0, input, -b1 * *last);
+    *last = out;
+    return out;
+}
+
+/* ------------------------------------------------------------------ oscillators.rs */
+
+/* oscillators.rs:377-381  accum_phase */
+static float accum_phase(float phase, float period) {
+    float phase_delta = 1.0f / period;
+    return fmodf(phase + phase_delta, 1.0f);
+}
+
+/* oscillators.rs:391-400  accum_phase_x16 */
+static float accum_phase_x16(float phase0, const float period[16], float phase[16]) {
+    float acc = phase0;
+    for (int i = 0; i < 16; i++) phase[i] = phase0;
+    for (int i = 1; i < 16; i++) { acc = accum_phase(acc, period[i - 1]); phase[i] = acc; }
+    acc = accum_phase(acc, period[15]);
+    return acc;
+}
+
+/* oscillators.rs:207-215 / 217-239 (feature fma): period.mul_add(phase, offset) */
+static float phased_offset(float period, float phase, float offset) { return fmaf(period, phase, offset); }
+
+/* oscillators.rs:47-58 / 60-80 */
+static float basic_square(float period, float offset) {
+    offset = fmodf(offset, period);
+    float half_period = period / 2.0f;
+    return offset < half_period ? 1.0f : -1.0f;
+}
+/* oscillators.rs:82-97 / 99-119 */
+static float basic_saw(float period, float offset) {
+    offset = fmodf(offset, period);
+    return line_fma(-2.0f, period, offset, 1.0f);
+}
+/* oscillators.rs:121-146 / 148-183 (x16 computes both halves and selects: same value) */
+static float basic_triangle(float period, float offset) {
+    offset = fmodf(offset, period);
+    float half_period = period / 2.0f;
+    if (offset < half_period) return line_fma(-2.0f, half_period, offset, 1.0f);
+    return line_fma(2.0f, half_period, offset - half_period, -1.0f);
+}
+
+static float osc_sample(int kind, float period, float phase, int x16, int *panicked) {
+    float offset = phased_offset(period, phase, 0.0f);
+    switch (kind) {
+    case S2O_OSC_SQUARE: return basic_square(period, offset);
+    case S2O_OSC_SAW: return basic_saw(period, offset);
+    case S2O_OSC_TRIANGLE: return basic_triangle(period, offset);
+    default: {
+        const float *T = s2o_sin_table();
+        if (x16) {   /* oscillators.rs:191-199 -> lookup.rs:187-199; evaluated lane-wise */
+            float v[16], r[16], o[16];
+            for (int i = 0; i < 16; i++) { v[i] = offset; r[i] = period; }
+            s2o_table_lookup_periodic_x16(T, 1024, v, r, o);
+            return o[0];
+        }
+        /* oscillators.rs:185-189 -> lookup.rs:179-185 */
+        return s2o_table_lookup_exclusive(T, 1024, fmodf(offset, period), period, panicked);
+    }
+    }
+}
+
+/* ------------------------------------------------------------------ process.rs */
+
+/* process.rs:231-250 */
+void s2o_modulate_freq_unipolar_x16(float freq, const float mod[16], float amount, float out[16]) {
+    for (int i = 0; i < 16; i++) {
+        float modulation_amount_ = mod[i] * amount;
+        out[i] = s2o_sleef_powf(2.0f, modulation_amount_) * freq;
+    }
+}
+/* process.rs:221-229 */
+float s2o_modulate_freq_unipolar(float freq, float mod, float amount) {
+    float modulation_amount_ = mod * amount;
+    volatile float two = 2.0f;   /* keep the call a real libm powf, not a folded exp2f */
+    return powf(two, modulation_amount_) * freq;
+}
+
+typedef struct { float periods[16]; float lpf_freqs[16]; float gains[16]; } plan_x16;
+
+/* process.rs:137-174 prepare_frame_x16 (+ :191-219 sample_envelope_x16 / offsets_x16) */
+static void prepare_frame_x16(const s2o_layer_cfg *c, float pitch, uint32_t sr, uint32_t offset,
+                              int has_release, uint32_t release_offset, plan_x16 *p) {
+    uint32_t offsets[16];
+    for (int i = 0; i < 16; i++) offsets[i] = offset + (uint32_t)i;          /* wrapping simd add */
+    float mod_env[16], osc_freqs[16];
+    s2o_adsr_x16(s2o_ms_as_samples(c->amp_env.attack_ms, sr), s2o_ms_as_samples(c->amp_env.decay_ms, sr),
+                 c->amp_env.sustain, s2o_ms_as_samples(c->amp_env.release_ms, sr),
+                 offsets, has_release, release_offset, p->gains);
+    s2o_adsr_x16(s2o_ms_as_samples(c->mod_env.attack_ms, sr), s2o_ms_as_samples(c->mod_env.decay_ms, sr),
+                 c->mod_env.sustain, s2o_ms_as_samples(c->mod_env.release_ms, sr),
+                 offsets, has_release, release_offset, mod_env);
+    s2o_modulate_freq_unipolar_x16(pitch, mod_env, c->mod_env_to_osc_freq, osc_freqs);
+    s2o_modulate_freq_unipolar_x16(c->lpf_freq, mod_env, c->mod_env_to_lpf_freq, p->lpf_freqs);
+    for (int i = 0; i < 16; i++) p->periods[i] = hz_as_samples(osc_freqs[i], sr);
+}
+
+/* process.rs:306-379 sample_voice_x16 */
+static void sample_voice_x16(const s2o_layer_cfg *c, const plan_x16 *p, s2o_layer_state *st,
+                             uint32_t sr, uint32_t offset, float out[16], int *panicked) {
+    float init_phase = st->has_phase ? st->phase_accum : 0.0f;               /* oscillators.rs:483 */
+    float phase[16];
+    float next = accum_phase_x16(init_phase, p->periods, phase);
+    float samples[16];
+    for (int i = 0; i < 16; i++) {
+        float osc = osc_sample(c->osc_kind, p->periods[i], phase[i], 1, panicked);
+        float osc_plus = osc + c->osc_gain;                                  /* :342-345  ADD */
+        float off_f = (float)(offset + (uint32_t)i);                         /* :347-348 */
+        float noise = s2o_hash_noise(st->seed, off_f);
+        float noise_plus = noise + c->noise;                                 /* :353-356  ADD */
+        samples[i] = osc_plus + noise_plus;                                  /* :358 */
+    }
+    st->has_phase = 1; st->phase_accum = next;                               /* oscillators.rs:492 */
+    for (int i = 0; i < 16; i++)                                             /* :363-371 sequential */
+        samples[i] = s2o_lpf_process(&st->lpf_last, sr, p->lpf_freqs[i], samples[i]);
+    for (int i = 0; i < 16; i++) out[i] = samples[i] * p->gains[i];          /* :373-376 */
+}
+
+/* process.rs:101-135 + 252-304: scalar prepare_frame + sample_voice */
+static float process_layer(const s2o_layer_cfg *c, s2o_layer_state *st, float pitch, uint32_t sr,
+                           uint32_t offset, int has_release, uint32_t release_offset, int *panicked) {
+    float amp = s2o_adsr_scalar(s2o_ms_as_samples(c->amp_env.attack_ms, sr), s2o_ms_as_samples(c->amp_env.decay_ms, sr),
+                                c->amp_env.sustain, s2o_ms_as_samples(c->amp_env.release_ms, sr),
+                                offset, has_release, release_offset);
+    float mod = s2o_adsr_scalar(s2o_ms_as_samples(c->mod_env.attack_ms, sr), s2o_ms_as_samples(c->mod_env.decay_ms, sr),
+                                c->mod_env.sustain, s2o_ms_as_samples(c->mod_env.release_ms, sr),
+                                offset, has_release, release_offset);
+    float osc_freq = s2o_modulate_freq_unipolar(pitch, mod, c->mod_env_to_osc_freq);
+    float lpf_freq = s2o_modulate_freq_unipolar(c->lpf_freq, mod, c->mod_env_to_lpf_freq);
+    float period = hz_as_samples(osc_freq, sr);
+
+    float phase = st->has_phase ? st->phase_accum : 0.0f;                    /* oscillators.rs:461 */
+    float osc = osc_sample(c->osc_kind, period, phase, 0, panicked);
+    st->has_phase = 1; st->phase_accum = accum_phase(phase, period);         /* oscillators.rs:469 */
+    float osc_sample_ = osc * c->osc_gain;                                   /* :287  MULTIPLY */
+    float noise = s2o_hash_noise(st->seed, (float)offset);                   /* :289-291 */
+    float noise_sample = noise * c->noise;                                   /* :292  MULTIPLY */
+    float sample = osc_sample_ + noise_sample;
+    sample = s2o_lpf_process(&st->lpf_last, sr, lpf_freq, sample);
+    return sample * amp;                                                     /* :302 */
+}
+
+/* process.rs:14-49 process_layer_buf_simd, :51-74 process_layer_buf_sisd.  Returns 0, or
+ * -1 where the reference panics (`checked_add(..).expect("overflow")`, :36,:71). */
+int s2o_process_layer_buf_simd(const s2o_layer_cfg *cfg, s2o_layer_state *st, float pitch,
+                               uint32_t sr, uint32_t offset, int has_release,
+                               uint32_t release_offset, float *buf, size_t len) {
+    int panicked = 0;
+    size_t i = 0;
+    for (; i + 16 <= len; i += 16) {
+        plan_x16 p;
+        prepare_frame_x16(cfg, pitch, sr, offset, has_release, release_offset, &p);
+        sample_voice_x16(cfg, &p, st, sr, offset, buf + i, &panicked);
+        if (offset > 0xffffffffu - 16u) return -1;
+        offset += 16;
+    }
+    for (; i < len; i++) {
+        buf[i] = process_layer(cfg, st, pitch, sr, offset, has_release, release_offset, &panicked);
+        if (offset == 0xffffffffu) return -1;
+        offset += 1;
+    }
+    return panicked ? -1 : 0;
+}
+
+/* ------------------------------------------------------------------ synth.rs */
+
+/* synth.rs:208-212 */
+float s2o_note_to_pitch(uint8_t note_u) {
+    float note = (float)note_u;
+    volatile float two = 2.0f;
+    return 440.0f * powf(two, (note - 69.0f) / 12.0f);
+}
+
+/* synth.rs:125-152 */
+s2o_layer_cfg s2o_default_config(void) {
+    s2o_layer_cfg c;
+    c.osc_kind = S2O_OSC_SAW; c.osc_gain = 1.0f;
+    c.noise = 0.0f;
+    c.lpf_freq = 200.0f;
+    c.amp_env.attack_ms = 100.0f; c.amp_env.decay_ms = 100.0f; c.amp_env.sustain = 0.5f; c.amp_env.release_ms = 100.0f;
+    c.mod_env.attack_ms = 0.0f; c.mod_env.decay_ms = 200.0f; c.mod_env.sustain = 0.0f; c.mod_env.release_ms = 0.0f;
+    c.mod_env_to_osc_freq = 0.0f;
+    c.mod_env_to_lpf_freq = 10.0f;
+    return c;
+}
+
+s2o_synth *s2o_synth_new(uint32_t num_voices) {
+    s2o_synth *s = (s2o_synth *)calloc(1, sizeof *s);
+    s->config = s2o_default_config();
+    s->num_voices = num_voices;
+    s->voices = (s2o_voice *)calloc(num_voices ? num_voices : 1, sizeof(s2o_voice)); /* Voice::default(), :41-51 */
+    return s;
+}
+void s2o_synth_free(s2o_synth *s) { if (s) { free(s->voices); free(s); } }
+
+/* synth.rs:101-120: the voice with the greatest current_frame_offset (None = u32::MAX),
+ * first such index on ties (strict `>`). */
+uint32_t s2o_next_voice_index(const s2o_synth *s) {
+    uint32_t oldest_index = 0, oldest_off = 0;
+    for (uint32_t i = 0; i < s->num_voices; i++) {
+        uint32_t this_off = s->voices[i].has_current ? s->voices[i].current_frame_offset : 0xffffffffu;
+        if (i == 0) { oldest_off = this_off; oldest_index = 0; }
+        else if (this_off > oldest_off) { oldest_off = this_off; oldest_index = i; }
+    }
+    return oldest_index;
+}
+
+/* synth.rs:61-70 */
+void s2o_note_on(s2o_synth *s, uint8_t note, float velocity) {
+    s2o_voice *v = &s->voices[s2o_next_voice_index(s)];
+    memset(v, 0, sizeof *v);                      /* state: st::Layer::default() */
+    v->note = note; v->velocity = velocity;
+    v->has_current = 1; v->current_frame_offset = 0;
+    v->has_release = 0;
+}
+
+/* synth.rs:72-96: LAST index whose note matches and which is active */
+void s2o_note_off(s2o_synth *s, uint8_t note) {
+    int64_t found = -1;
+    for (uint32_t i = 0; i < s->num_voices; i++) {
+        const s2o_voice *v = &s->voices[i];
+        if (v->note == note && v->has_current && !v->has_release) found = i;
+    }
+    if (found < 0) return;
+    s2o_voice *v = &s->voices[found];
+    if (!v->has_release) { v->has_release = 1; v->release_frame_offset = v->current_frame_offset; }
+    else s->double_release++;                     /* unreachable, as in the reference (:74-78) */
+}
+
+/* One voice through Synth::sample's chunking (synth.rs:158-168, 171-198): 16-frame
+ * chunks, then one tail chunk; offset advances by saturating_add per chunk (:197). */
+static void render_one_voice(s2o_synth *s, s2o_voice *v, float *row, size_t frames, uint32_t sr) {
+    if (!v->has_current) { for (size_t i = 0; i < frames; i++) row[i] = 0.0f; return; }
+    float pitch = s2o_note_to_pitch(v->note);                                /* :179 */
+    size_t done = 0;
+    while (done < frames) {
+        size_t n = frames - done < 16 ? frames - done : 16;
+        float buf[16] = {0};
+        if (s2o_process_layer_buf_simd(&s->config, &v->state, pitch, sr, v->current_frame_offset,
+                                       v->has_release, v->release_frame_offset, buf, n) != 0)
+            s->panicked = 1;
+        memcpy(row + done, buf, n * sizeof(float));
+        uint32_t o = v->current_frame_offset;
+        v->current_frame_offset = (o > 0xffffffffu - (uint32_t)n) ? 0xffffffffu : o + (uint32_t)n; /* :197 */
+        done += n;
+    }
+}
+
+void s2o_render_voices(s2o_synth *s, float *per_voice, size_t frames, uint32_t sr) {
+    for (uint32_t v = 0; v < s->num_voices; v++)
+        render_one_voice(s, &s->voices[v], per_voice + (size_t)v * frames, frames, sr);
+}
+
+typedef struct { s2o_synth *s; float *pv; size_t frames; uint32_t sr; uint32_t v0, v1; float *acc; } mt_job;
+static void *mt_render(void *arg) {
+    mt_job *j = (mt_job *)arg;
+    for (uint32_t v = j->v0; v < j->v1; v++)
+        render_one_voice(j->s, &j->s->voices[v], j->pv + (size_t)v * j->frames, j->frames, j->sr);
+    return NULL;
+}
+void s2o_render_voices_mt(s2o_synth *s, float *per_voice, size_t frames, uint32_t sr, int threads) {
+    if (threads < 1) threads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads);
+    mt_job *jobs = (mt_job *)malloc(sizeof(mt_job) * threads);
+    for (int t = 0; t < threads; t++) {
+        jobs[t] = (mt_job){ s, per_voice, frames, sr,
+                            (uint32_t)((uint64_t)s->num_voices * t / threads),
+                            (uint32_t)((uint64_t)s->num_voices * (t + 1) / threads), NULL };
+        pthread_create(&th[t], NULL, mt_render, &jobs[t]);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    free(th); free(jobs);
+}
+
+static void *mt_sample(void *arg) {
+    mt_job *j = (mt_job *)arg;
+    float *row = (float *)malloc(sizeof(float) * j->frames);
+    for (size_t i = 0; i < j->frames; i++) j->acc[i] = 0.0f;
+    for (uint32_t v = j->v0; v < j->v1; v++) {
+        if (!j->s->voices[v].has_current) continue;
+        render_one_voice(j->s, &j->s->voices[v], row, j->frames, j->sr);
+        for (size_t i = 0; i < j->frames; i++) j->acc[i] += row[i];
+    }
+    free(row);
+    return NULL;
+}
+void s2o_sample_mt(s2o_synth *s, float *buffer, size_t frames, uint32_t sr, int threads) {
+    if (threads < 1) threads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads);
+    mt_job *jobs = (mt_job *)malloc(sizeof(mt_job) * threads);
+    float *acc = (float *)malloc(sizeof(float) * frames * threads);
+    for (int t = 0; t < threads; t++) {
+        jobs[t] = (mt_job){ s, NULL, frames, sr,
+                            (uint32_t)((uint64_t)s->num_voices * t / threads),
+                            (uint32_t)((uint64_t)s->num_voices * (t + 1) / threads), acc + (size_t)t * frames };
+        pthread_create(&th[t], NULL, mt_sample, &jobs[t]);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    for (size_t i = 0; i < frames; i++) {
+        float a = 0.0f;
+        for (int t = 0; t < threads; t++) a += acc[(size_t)t * frames + i];
+        buffer[i] = a;
+    }
+    free(th); free(jobs); free(acc);
+}
+
+/* synth.rs:171-203: accum = 0; for voices in index order (started ones only) accum += buf */
+void s2o_mix_sequential(const float *per_voice, uint32_t voices, size_t frames, float *out) {
+    for (size_t i = 0; i < frames; i++) {
+        float accum = 0.0f;
+        for (uint32_t v = 0; v < voices; v++) accum += per_voice[(size_t)v * frames + i];
+        out[i] = accum;
+    }
+}
+
+void s2o_sample(s2o_synth *s, float *buffer, size_t frames, uint32_t sr) {
+    /* Rendering voice-by-voice over the whole buffer is the same computation as the
+     * reference's chunk-outer / voice-inner loop: voices do not interact before the add,
+     * and the per-frame additions happen in the same (voice index) order.  Never-started
+     * voices are skipped by the reference (:178); adding their +0.0 rows is bit-identical
+     * because accum starts at +0.0 (x + 0.0 == x for every x that can occur, incl. -0.0
+     * after the first add: (+0.0) + (-0.0) = +0.0). */
+    float *pv = (float *)malloc(sizeof(float) * (size_t)s->num_voices * (frames ? frames : 1));
+    s2o_render_voices(s, pv, frames, sr);
+    s2o_mix_sequential(pv, s->num_voices, frames, buffer);
+    free(pv);
+}
+
+/* ------------------------------------------------------------------ GPU mix tree */
+
+static float wave_tree64(const float *per_voice, uint32_t voices, size_t frames, uint32_t v0, size_t i) {
+    float t[64];
+    for (uint32_t l = 0; l < 64; l++) t[l] = (v0 + l < voices) ? per_voice[(size_t)(v0 + l) * frames + i] : 0.0f;
+    for (uint32_t w = 64; w > 1; w >>= 1)
+        for (uint32_t k = 0; k < w / 2; k++) t[k] = t[2 * k] + t[2 * k + 1];
+    return t[0];
+}
+
+static float block_partial(const float *per_voice, uint32_t voices, size_t frames, uint32_t b, uint32_t block_voices, size_t i) {
+    uint32_t v0 = b * block_voices;
+    float acc = wave_tree64(per_voice, voices, frames, v0, i);
+    for (uint32_t w = 1; w < block_voices / 64; w++) acc += wave_tree64(per_voice, voices, frames, v0 + 64 * w, i);
+    return acc;
+}
+
+void s2o_mix_tree_partial(const float *per_voice, uint32_t voices, size_t frames, uint32_t block_voices, float *out) {
+    uint32_t nblocks = (voices + block_voices - 1) / block_voices;
+    for (size_t i = 0; i < frames; i++) {
+        float acc = block_partial(per_voice, voices, frames, 0, block_voices, i);
+        for (uint32_t b = 1; b < nblocks; b++) acc += block_partial(per_voice, voices, frames, b, block_voices, i);
+        out[i] = acc;
+    }
+}
+
+void s2o_mix_tree(const float *per_voice, uint32_t voices, size_t frames, s2o_tree tree, float *out) {
+    uint32_t nblocks = (voices + tree.block_voices - 1) / tree.block_voices;
+    uint32_t groups = tree.groups ? tree.groups : 1;
+    uint32_t per_group = (nblocks + groups - 1) / groups;
+    for (size_t i = 0; i < frames; i++) {
+        float total = 0.0f;                                   /* accum = splat(0.0), synth.rs:176 */
+        for (uint32_t g = 0; g < groups; g++) {
+            uint32_t b0 = g * per_group, b1 = b0 + per_group < nblocks ? b0 + per_group : nblocks;
+            if (b0 >= b1) continue;
+            float acc = block_partial(per_voice, voices, frames, b0, tree.block_voices, i);
+            for (uint32_t b = b0 + 1; b < b1; b++) acc += block_partial(per_voice, voices, frames, b, tree.block_voices, i);
+            total += acc;
+        }
+        out[i] = total;
+    }
+}

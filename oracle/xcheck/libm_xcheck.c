@@ -1,0 +1,52 @@
+/*
+ * libm_xcheck.c — TEST INFRASTRUCTURE ONLY.
+ *
+ * Exhaustive bit-for-bit comparison of the PRODUCT's host/device-shared math
+ * (synth2_amd/csrc/s2r_math.h, compiled here for the host with gcc) against what the
+ * reference actually calls on a Linux host:
+ *   expf   : Rust f32::exp  -> glibc expf   (filters.rs:21)
+ *   powf2  : Rust 2f32.powf -> glibc powf   (process.rs:227, synth.rs:210)
+ *   sleef2 : sleef pow(2,y) -> oracle/s2o_sleef.c (itself pinned to C SLEEF by sleef_xcheck)
+ *
+ * usage: libm_xcheck expf|powf2|sleef2 <lo> <hi>     (every float in [lo,hi])
+ *        libm_xcheck expf all | powf2 all            (every one of the 2^32 bit patterns)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../synth2_amd/csrc/s2r_math.h"
+
+float s2o_sleef_powf(float x, float y);
+static const uint64_t T[32] = S2R_EXP2F_TABLE_INIT;
+
+static uint64_t checked, mism; static int shown;
+static int mode;
+
+static inline void one(uint32_t u) {
+    float x = s2r_u2f(u), mine, ref;
+    if (mode == 0) { mine = s2r_expf(x, T); ref = expf(x); }
+    else if (mode == 1) { mine = s2r_pow2_libm(x, T); volatile float two = 2.0f; ref = powf(two, x); }
+    else { mine = s2r_pow2_sleef(x); ref = s2o_sleef_powf(2.0f, x); }
+    checked++;
+    if (mine != mine && ref != ref) return;
+    if (s2r_f2u(mine) != s2r_f2u(ref)) {
+        mism++;
+        if (shown < 10) { shown++; fprintf(stderr, "MISMATCH in=%a mine=%a ref=%a\n", x, mine, ref); }
+    }
+}
+
+int main(int argc, char **argv) {
+    if (argc < 3) return 2;
+    mode = !strcmp(argv[1], "expf") ? 0 : !strcmp(argv[1], "powf2") ? 1 : 2;
+    if (!strcmp(argv[2], "all")) {
+        uint32_t u = 0; do { one(u); } while (++u != 0);
+    } else {
+        float lo = strtof(argv[2], 0), hi = strtof(argv[3], 0);
+        if (lo < 0) { float top = hi < 0 ? hi : -0.0f; for (uint32_t u = s2r_f2u(top); u <= s2r_f2u(lo); u++) one(u); }
+        if (hi >= 0) { float bot = lo > 0 ? lo : 0.0f; for (uint32_t u = s2r_f2u(bot); u <= s2r_f2u(hi); u++) one(u); }
+    }
+    printf("checked=%llu mismatches=%llu\n", (unsigned long long)checked, (unsigned long long)mism);
+    return mism ? 1 : 0;
+}

@@ -1,0 +1,181 @@
+// s2r_math.h — exact-arithmetic building blocks shared by the gfx950 kernels and the
+// host side of libs2r (PRODUCT code; the CPU oracle under oracle/ does NOT use this file,
+// it calls the host libm / its own SLEEF restatement, so the two are independent).
+//
+// Every routine here is written only in IEEE-754 +,-,*,/,fma and integer ops so that the
+// same source yields the same bits under gcc (host) and hipcc (gfx950).  Translation
+// units including it MUST be compiled with -ffp-contract=off and without fast-math.
+//
+// What each routine reproduces (reference call sites, all under
+// /root/reference/components/s2_lib/src/try3/):
+//   s2r_expf        Rust `f32::exp` = glibc `expf`           filters.rs:21
+//   s2r_pow2_sleef  `sleef::Sleef::pow(2.0, y)` on f32x16    process.rs:244
+//   s2r_pow2_libm   Rust `2_f32.powf(y)` = glibc `powf`      process.rs:227
+//   s2r_fmod1 / s2r_fmod_pos   Rust `%` on f32 = fmodf       oscillators.rs:379,66,105,154
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define S2R_HD __host__ __device__ __forceinline__
+#else
+#define S2R_HD static inline
+#endif
+
+#define S2R_EXP2F_N 32
+
+// 2^(i/32) as IEEE binary64 bits minus (i << 47): the table of glibc's expf/exp2f/powf
+// (Szabolcs Nagy's "optimized-routines" single-precision exp family, glibc >= 2.27).
+// Values are recomputed from scratch (correctly rounded 2^(i/32)) by tools/gen_exp2f_table.py.
+#define S2R_EXP2F_TABLE_INIT { \
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, \
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, \
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull, \
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, \
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull, \
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull, \
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, \
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull }
+
+S2R_HD uint32_t s2r_f2u(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
+S2R_HD float s2r_u2f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
+S2R_HD uint64_t s2r_d2u(double d) { uint64_t u; __builtin_memcpy(&u, &d, 8); return u; }
+S2R_HD double s2r_u2d(uint64_t u) { double d; __builtin_memcpy(&d, &u, 8); return d; }
+
+// ---------------------------------------------------------------------------------------
+// glibc expf (sysdeps/ieee754/flt-32/e_expf.c, FMA ifunc variant): double-precision
+// evaluation of 2^(k/32) * p(r), rounded once to float.  T = S2R_EXP2F_TABLE (host array
+// or LDS copy).
+// ---------------------------------------------------------------------------------------
+S2R_HD float s2r_expf(float x, const uint64_t* T) {
+    const uint32_t ux = s2r_f2u(x);
+    const uint32_t abstop = (ux >> 20) & 0x7ff;
+    if (__builtin_expect(abstop >= 0x42b, 0)) {          // |x| >= 88 or NaN
+        if (ux == 0xff800000u) return 0.0f;              // -inf
+        if (abstop >= 0x7f8) return x + x;               // +inf / NaN
+        if (x > 0x1.62e42ep6f) return __builtin_inff(); // overflow
+        if (x < -0x1.9fe368p6f) return 0.0f;             // underflow
+    }
+    const double xd = (double)x;
+    const double InvLn2N = 0x1.71547652b82fep+0 * S2R_EXP2F_N;
+    const double Shift = 0x1.8p+52;
+    const double C0 = 0x1.c6af84b912394p-5 / S2R_EXP2F_N / S2R_EXP2F_N / S2R_EXP2F_N;
+    const double C1 = 0x1.ebfce50fac4f3p-3 / S2R_EXP2F_N / S2R_EXP2F_N;
+    const double C2 = 0x1.62e42ff0c52d6p-1 / S2R_EXP2F_N;
+    double z = InvLn2N * xd;
+    double kd = z + Shift;
+    const uint64_t ki = s2r_d2u(kd);
+    kd = kd - Shift;
+    // glibc's FMA build contracts `r = z - kd` (z being the product above) into one fma;
+    // found by exhaustive comparison with the host expf (2 inputs of 2^32 tell them apart).
+    const double r = __builtin_fma(InvLn2N, xd, -kd);
+    uint64_t t = T[ki % S2R_EXP2F_N];
+    t += ki << (52 - 5);
+    const double s = s2r_u2d(t);
+    z = __builtin_fma(C0, r, C1);
+    const double r2 = r * r;
+    double y = __builtin_fma(C2, r, 1.0);
+    y = __builtin_fma(z, r2, y);
+    y = y * s;
+    return (float)y;
+}
+
+// ---------------------------------------------------------------------------------------
+// glibc powf(2.0f, y) (sysdeps/ieee754/flt-32/e_powf.c, FMA variant).  For x == 2 the
+// log2_inline step is exactly 1.0 (table entry {invc=1, logc=0}, r == 0), so
+// ylogx == (double)y and the rest is exp2_inline.
+// ---------------------------------------------------------------------------------------
+S2R_HD float s2r_pow2_libm(float y, const uint64_t* T) {
+    const uint32_t iy = s2r_f2u(y);
+    if (__builtin_expect(2u * iy - 1u >= 2u * 0x7f800000u - 1u, 0)) {   // y is 0, inf or NaN
+        if (2u * iy == 0) return 1.0f;
+        if (2u * iy > 2u * 0x7f800000u) return 2.0f + y;                   // NaN
+        return (iy & 0x80000000u) ? 0.0f : y * y;                          // -inf -> 0, +inf -> inf
+    }
+    const double ylogx = (double)y;
+    if (__builtin_expect(((s2r_d2u(ylogx) >> 47) & 0xffff) >= (s2r_d2u(126.0) >> 47), 0)) {
+        if (ylogx > 0x1.fffffffd1d571p+6) return __builtin_inff();
+        if (ylogx <= -150.0) return 0.0f;
+    }
+    const double Shift = 0x1.8p+52 / S2R_EXP2F_N;
+    const double C0 = 0x1.c6af84b912394p-5, C1 = 0x1.ebfce50fac4f3p-3, C2 = 0x1.62e42ff0c52d6p-1;
+    double kd = ylogx + Shift;
+    const uint64_t ki = s2r_d2u(kd);
+    kd = kd - Shift;
+    const double r = ylogx - kd;
+    uint64_t t = T[ki % S2R_EXP2F_N];
+    t += ki << (52 - 5);
+    const double s = s2r_u2d(t);
+    const double z = __builtin_fma(C0, r, C1);
+    const double r2 = r * r;
+    double v = __builtin_fma(C2, r, 1.0);
+    v = __builtin_fma(z, r2, v);
+    v = v * s;
+    return (float)v;
+}
+
+// ---------------------------------------------------------------------------------------
+// SLEEF u10 powf with x == 2 (sleefsimdsp.c xpowf/logkf/expkf, FMA flavour).
+// logkf(2.0) evaluates *exactly* to the double-float constant (ln2_hi, ln2_lo) below
+// (m == 1 => x == 0, all correction terms vanish), so pow(2,y) = expkf(df(ln2) * y).
+// Valid (bit-exact vs C SLEEF 3.8) wherever the result is a normal float; the patch
+// domain |y| <= 10 (Bipolar<10> x Unipolar<1>, static_config.rs:17-20) is far inside.
+// ---------------------------------------------------------------------------------------
+S2R_HD float s2r_pow2_sleef(float y) {
+    if (y != y) return y + y;
+    if (y == 0.0f) return 1.0f;
+    const float ay = __builtin_fabsf(y);
+    if (ay == __builtin_inff()) return y > 0 ? y : 0.0f;
+    // d = dfmul((ln2_hi, ln2_lo), y)
+    const float Lh = 0.69314718246459960938f, Ll = -1.904654323148236017e-09f;
+    const float dx = Lh * y;
+    const float dy = __builtin_fmaf(Ll, y, __builtin_fmaf(Lh, y, -dx));
+    // expkf(d)
+    const float R_LN2f = 1.442695040888963407359924681001892137426645954152985934135449406931f;
+    const float L2Uf = 0.693145751953125f, L2Lf = 1.428606765330187045e-06f;
+    float u = (dx + dy) * R_LN2f;
+    const float qf = __builtin_rintf(u);
+    if (!(__builtin_fabsf(qf) < 160.0f)) return qf > 0 ? __builtin_inff() : 0.0f;   // far outside the normal range
+    const int q = (int)qf;
+    // s = dfadd2(d, q * -L2U)
+    float a = qf * -L2Uf;
+    float sx = dx + a, v = sx - dx;
+    float sy = ((dx - (sx - v)) + (a - v)) + dy;
+    // s = dfadd2(s, q * -L2L)
+    a = qf * -L2Lf;
+    float tx = sx + a; v = tx - sx;
+    float ty = ((sx - (tx - v)) + (a - v)) + sy;
+    // normalize
+    sx = tx + ty; sy = (tx - sx) + ty;
+    u = 0.00136324646882712841033936f;
+    u = __builtin_fmaf(u, sx, 0.00836596917361021041870117f);
+    u = __builtin_fmaf(u, sx, 0.0416710823774337768554688f);
+    u = __builtin_fmaf(u, sx, 0.166665524244308471679688f);
+    u = __builtin_fmaf(u, sx, 0.499999850988388061523438f);
+    // w = dfsqu(s)
+    const float wx = sx * sx;
+    const float wy = __builtin_fmaf(sx + sx, sy, __builtin_fmaf(sx, sx, -wx));
+    // m = dfmul(w, u)
+    const float mx = wx * u;
+    const float my = __builtin_fmaf(wy, u, __builtin_fmaf(wx, u, -mx));
+    // t = dfadd2(s, m)
+    tx = sx + mx; v = tx - sx;
+    ty = ((sx - (tx - v)) + (mx - v)) + (sy + my);
+    // t = dfadd(1, t)
+    const float ox = 1.0f + tx;
+    const float oy = ((1.0f - ox) + tx) + ty;
+    u = ox + oy;
+    // ldexp(u, q): u in [~0.7, ~1.5), q small => exact scaling by 2^q in two steps
+    const int q1 = q >> 1, q2 = q - q1;
+    u = u * s2r_u2f((uint32_t)(q1 + 127) << 23) * s2r_u2f((uint32_t)(q2 + 127) << 23);
+    if (dx < -104.0f) u = 0.0f;
+    return u;
+}
+
+// ---------------------------------------------------------------------------------------
+// fmodf specialisations (fmod is exact by definition, so any exact formula is bit-equal).
+// ---------------------------------------------------------------------------------------
+// fmodf(x, 1.0f): x - trunc(x) is exact for every finite x; sign of a zero result follows x.
+S2R_HD float s2r_fmod1(float x) {
+    const float r = x - __builtin_truncf(x);
+    return __builtin_copysignf(r, x);
+}
