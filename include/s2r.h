@@ -158,6 +158,23 @@ float s2r_last_render_ms(s2r_synth *s);
 const char *s2r_last_error(const s2r_synth *s);             /* never NULL */
 const char *s2r_status_string(int status);
 
+/* ---- host-only helpers: usable without a device (front-ends that route events to shards,
+ * CPU-only tests of the host logic) ---- */
+
+/* The .synth2 parser on its own; err_buf (may be NULL) receives a message on failure. */
+int s2r_parse_patch_text(const char *text, size_t len, s2r_patch *out, char *err_buf, size_t err_cap);
+
+/* The voice-allocation / release policy of Synth (synth.rs:61-120) for a pool of any size,
+ * O(log V) per event, without rendering.  Offsets advance by s2r_voice_pool_advance. */
+typedef struct s2r_voice_pool s2r_voice_pool;
+s2r_voice_pool *s2r_voice_pool_create(uint32_t total_voices);
+void s2r_voice_pool_destroy(s2r_voice_pool *p);
+uint32_t s2r_voice_pool_note_on(s2r_voice_pool *p, uint8_t note, float velocity);  /* returns the chosen index */
+int64_t s2r_voice_pool_note_off(s2r_voice_pool *p, uint8_t note);                  /* released index or -1 */
+void s2r_voice_pool_advance(s2r_voice_pool *p, uint64_t frames);
+uint32_t s2r_voice_pool_next_voice(const s2r_voice_pool *p);                       /* synth.rs:101-120 */
+int s2r_voice_pool_query(const s2r_voice_pool *p, uint32_t voice_index, s2r_voice_state *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,8 @@
+"""synth2_amd — MI355X-native voice-render path behind s2_lib's buffer-fill API.
+
+csrc/ holds the HIP kernels and the C ABI (libs2r.so, declared in include/s2r.h);
+synth.py is the ctypes mirror of the reference's ``Synth`` used by tests and bench.py.
+"""
+from .synth import (Adsr, Note, Patch, S2rError, SampleRateKhz, Synth, Velocity, VoicePool,  # noqa: F401
+                    default_patch, load_library, parse_patch, sum_partials_device,
+                    OSC_SAW, OSC_SINE, OSC_SQUARE, OSC_TRIANGLE, VOICE_STATE_DTYPE)

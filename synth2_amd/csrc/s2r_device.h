@@ -1,0 +1,86 @@
+// s2r_device.h — kernel argument blocks and launch entry points shared by the host side
+// (s2r_host.cpp) and the gfx950 kernels (s2r_kernels.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include "s2r.h"
+
+// voice flag bits (synth.rs:27-28: the two Option discriminants)
+#define S2R_VF_STARTED 1u    // current_frame_offset.is_some()
+#define S2R_VF_RELEASED 2u   // release_frame_offset.is_some()
+
+// One ADSR resolved for a sample rate.  A, D, R are `Ms::as_samples` (units.rs:44-53);
+// the three slopes are the `y_rise / x_run` of simdtest.rs:247-251, hoisted out of the
+// per-frame work (a correctly rounded division gives the same bits wherever it runs).
+struct S2rEnv {
+    float A;          // attack (samples) == decay_offset
+    float D;          // decay (samples)
+    float S;          // sustain level
+    float R;          // release (samples)
+    float sus_off;    // A + D                         simdtest.rs:282
+    float slope_att;  // 1.0 / A                       simdtest.rs:295-299
+    float slope_dec;  // (S - 1.0) / D                 simdtest.rs:303-307
+    float slope_rel;  // (-S) / R                      simdtest.rs:313-317
+};
+
+// Per-voice state, struct-of-arrays in HBM (one entry per shard voice, padded to a whole
+// number of workgroups).  28 B are read and 12 B written per started voice per fill.
+struct S2rVoiceArrays {
+    float *pitch;         // note_to_pitch(note)             synth.rs:179,208-212
+    uint32_t *offset;     // current_frame_offset            synth.rs:27
+    uint32_t *release;    // release_frame_offset            synth.rs:28
+    uint32_t *flags;      // S2R_VF_*
+    float *phase;         // OscillatorState.phase_accum     oscillators.rs:402-406
+    float *lpf_last;      // LowPassFilterState.last         filters.rs:5-7
+    uint32_t *seed;       // NoiseState.seed                 state.rs:17-21
+};
+
+struct S2rRenderParams {
+    // patch (static_config.rs:4-44), shared by every voice
+    int32_t osc_kind;
+    float osc_gain;
+    float noise_level;
+    float lpf_freq;
+    float amt_osc;        // mod_env_to_osc_freq
+    float amt_lpf;        // mod_env_to_lpf_freq
+    S2rEnv amp;
+    S2rEnv mod;
+    float sr;             // sample_rate as f32 (units.rs:21)
+    float rcp_sr;         // RN(1/sr)
+    int32_t fast_div_sr;  // 1 => x/sr may use the 3-op exact quotient (rate verified exhaustively)
+    uint32_t frames;      // this fill
+    uint32_t n_voices;    // shard voices
+    uint32_t frames_stride; // row stride of block_partials / per_voice (== max_frames or frames)
+    S2rVoiceArrays v;
+    float *block_partials;   // [n_blocks][frames_stride]
+    float *per_voice;        // [n_voices][frames] or nullptr (mix-disabled debug/parity path)
+    const float *sin_table;  // 1024 floats (tables.rs)
+};
+
+// Coalesced note events, one record per touched voice per fill (host folds the event
+// stream of synth.rs:61-80 between two fills into the voice's final state).
+struct S2rVoiceEvent {
+    uint32_t voice;       // shard-local index
+    uint32_t flags;       // bit0: restart (note_on), bit1: release (note_off after the last on)
+    float pitch;          // valid when restart
+    uint32_t seed;        // NoiseState.seed for the restarted voice (reference: 0)
+};
+#define S2R_EV_RESTART 1u
+#define S2R_EV_RELEASE 2u
+
+struct S2rMixParams {
+    const float *block_partials;  // [n_blocks][frames_stride]
+    uint32_t n_blocks;
+    uint32_t blocks_per_group;
+    uint32_t n_groups;
+    uint32_t frames;
+    uint32_t frames_stride;
+    int32_t root_add;             // 1: out = (+0.0) + total  (synth.rs:176), 0: partial only
+    int32_t stereo;               // 1: write interleaved L,R (audio_player.rs:224-228)
+    float *out;
+};
+
+hipError_t s2r_launch_render(const S2rRenderParams &p, uint32_t block_voices, hipStream_t stream);
+hipError_t s2r_launch_mix(const S2rMixParams &p, hipStream_t stream);
+hipError_t s2r_launch_events(const S2rVoiceArrays &v, const S2rVoiceEvent *dev_events, uint32_t n, hipStream_t stream);
+hipError_t s2r_launch_sum_rows(const float *rows, uint32_t n_rows, uint32_t frames, float *out, hipStream_t stream);

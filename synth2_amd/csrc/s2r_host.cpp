@@ -1,0 +1,583 @@
+// s2r_host.cpp — the C ABI of libs2r (include/s2r.h): handle, device memory, voice pool,
+// event folding, launches.  Compiled with hipcc, -ffp-contract=off.
+//
+// Reference boundary being replaced: s2_lib::try3::synth::Synth
+// (/root/reference/components/s2_lib/src/try3/synth.rs:9-203).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "s2r.h"
+#include "s2r_device.h"
+#include "s2r_math.h"
+#include "s2r_patch.h"
+#include "s2r_voices.h"
+
+namespace {
+
+constexpr int kEventSlots = 4;
+
+// components/s2_bin/src/tables.rs:6-10 regenerated; see oracle/s2_oracle.c for the note on
+// the four entries the reference's literal table (tables.rs) rounds one ULP away from zero.
+// CRC-32 of the 4096 table bytes is checked at create so a libm surprise fails loudly.
+constexpr uint32_t kSinTableCrc = 0x55293b66u;
+
+uint32_t crc32_bytes(const void *data, size_t n) {
+    const uint8_t *p = (const uint8_t *)data;
+    uint32_t c = 0xffffffffu;
+    for (size_t i = 0; i < n; i++) {
+        c ^= p[i];
+        for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1u)));
+    }
+    return ~c;
+}
+
+void build_sin_table(float *t) {
+    for (int k = 0; k < 1024; k++) {
+        float i = (float)k / 1024.0f;
+        i = i * 3.14159274101257324f * 2.0f;
+        t[k] = (float)std::sin((double)i);
+    }
+    static const int bump[4] = {395, 399, 610, 627};
+    for (int j = 0; j < 4; j++) t[bump[j]] = s2r_u2f(s2r_f2u(t[bump[j]]) + 1u);
+}
+
+// synth.rs:208-212: 440.0 * 2_f32.powf((note - 69.0) / 12.0), through the host libm's powf —
+// the very call the reference makes.
+void build_pitch_table(float *t) {
+    volatile float two = 2.0f;     // keep it a real powf call
+    for (int n = 0; n < 256; n++) {
+        const float note = (float)n;
+        t[n] = 440.0f * powf(two, (note - 69.0f) / 12.0f);
+    }
+}
+
+// units.rs:44-53
+float ms_as_samples(float ms, uint32_t sample_rate) {
+    const float sr = (float)sample_rate;
+    const float seconds = ms / 1000.0f;
+    return sr * seconds;
+}
+
+S2rEnv resolve_env(const s2r_adsr &a, uint32_t sample_rate) {
+    S2rEnv e;
+    e.A = ms_as_samples(a.attack_ms, sample_rate);
+    e.D = ms_as_samples(a.decay_ms, sample_rate);
+    e.S = a.sustain;
+    e.R = ms_as_samples(a.release_ms, sample_rate);
+    e.sus_off = e.A + e.D;
+    e.slope_att = 1.0f / e.A;
+    e.slope_dec = (e.S - 1.0f) / e.D;
+    e.slope_rel = (-e.S) / e.R;
+    return e;
+}
+
+// Sample rates for which s2r_div_const(x, sr) was compared with x / sr over every float in
+// its window (oracle/xcheck/libm_xcheck.c, mode "div"; tests/test_transcendentals_pinned.py).
+bool fast_div_rate(uint32_t sr) {
+    static const uint32_t ok[] = {8000, 11025, 16000, 22050, 24000, 32000, 44100, 48000, 88200, 96000, 176400, 192000};
+    for (uint32_t r : ok) if (r == sr) return true;
+    return false;
+}
+
+struct EventSlot {
+    S2rVoiceEvent *host = nullptr;   // pinned
+    S2rVoiceEvent *dev = nullptr;
+    hipEvent_t done = nullptr;
+    bool in_flight = false;
+};
+
+}  // namespace
+
+struct s2r_synth {
+    s2r_config cfg{};
+    int device = 0;
+    uint32_t shard_begin = 0, shard_voices = 0, padded_voices = 0, block_voices = 256, n_blocks = 0, mix_groups = 1;
+    s2r_patch patch{};
+    std::unique_ptr<S2rVoicePool> pool;
+    std::vector<uint32_t> seed_override;         // per pool voice; 0 = reference behaviour
+    // event folding (one record per touched shard voice between two fills)
+    std::vector<S2rVoiceEvent> pending;
+    std::vector<int32_t> pending_slot;           // shard-local voice -> index in pending, -1
+    EventSlot slots[kEventSlots];
+    int next_slot = 0;
+    // device
+    hipStream_t stream = nullptr;
+    S2rVoiceArrays v{};
+    void *voice_mem = nullptr;
+    float *block_partials = nullptr;
+    float *out_dev = nullptr;
+    float *out_host = nullptr;                   // pinned, 2*max_frames
+    float *sin_dev = nullptr;
+    float *per_voice_dev = nullptr; size_t per_voice_cap = 0;
+    float pitch_table[256];
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool timing = false, timed = false;
+    uint64_t double_release = 0;
+    std::string err = "";
+};
+
+namespace {
+
+int set_err(s2r_synth *s, int code, const char *fmt, ...) {
+    if (s) {
+        char buf[512];
+        va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+        s->err = buf;
+    }
+    return code;
+}
+
+#define S2R_HIP(s, call)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) return set_err((s), S2R_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+void push_event(s2r_synth *s, uint32_t pool_index, uint32_t flags, float pitch, uint32_t seed) {
+    if (pool_index < s->shard_begin || pool_index >= s->shard_begin + s->shard_voices) return;
+    const uint32_t local = pool_index - s->shard_begin;
+    int32_t slot = s->pending_slot[local];
+    if (slot < 0) {
+        slot = (int32_t)s->pending.size();
+        s->pending_slot[local] = slot;
+        s->pending.push_back(S2rVoiceEvent{local, 0u, 0.0f, 0u});
+    }
+    S2rVoiceEvent &e = s->pending[(size_t)slot];
+    if (flags & S2R_EV_RESTART) { e.flags = S2R_EV_RESTART; e.pitch = pitch; e.seed = seed; }   // wipes an earlier release
+    if (flags & S2R_EV_RELEASE) e.flags |= S2R_EV_RELEASE;
+}
+
+// upload the folded events and apply them on `stream`
+int flush_events(s2r_synth *s, hipStream_t stream) {
+    if (s->pending.empty()) return S2R_OK;
+    EventSlot &sl = s->slots[s->next_slot];
+    s->next_slot = (s->next_slot + 1) % kEventSlots;
+    if (sl.in_flight) { S2R_HIP(s, hipEventSynchronize(sl.done)); sl.in_flight = false; }
+    const uint32_t n = (uint32_t)s->pending.size();
+    std::memcpy(sl.host, s->pending.data(), n * sizeof(S2rVoiceEvent));
+    S2R_HIP(s, hipMemcpyAsync(sl.dev, sl.host, n * sizeof(S2rVoiceEvent), hipMemcpyHostToDevice, stream));
+    S2R_HIP(s, s2r_launch_events(s->v, sl.dev, n, stream));
+    S2R_HIP(s, hipEventRecord(sl.done, stream));
+    sl.in_flight = true;
+    for (const S2rVoiceEvent &e : s->pending) s->pending_slot[e.voice] = -1;
+    s->pending.clear();
+    return S2R_OK;
+}
+
+int check_fill(s2r_synth *s, size_t frames, uint32_t sample_rate) {
+    if (!s) return S2R_ERR_INVALID;
+    if (frames > s->cfg.max_frames) return set_err(s, S2R_ERR_TOO_MANY_FRAMES, "frames %zu > max_frames %u", frames, s->cfg.max_frames);
+    if (sample_rate == 0) return set_err(s, S2R_ERR_INVALID, "sample_rate_hz must be > 0");
+    // process.rs:36,71: offset.checked_add(..).expect("overflow") — the reference panics once a
+    // voice's offset would pass u32::MAX; report it instead of rendering garbage.
+    if (s->pool->oldest_offset() + frames > 0xffffffffull)
+        return set_err(s, S2R_ERR_OFFSET_OVERFLOW, "a voice's frame offset would overflow u32 (the reference panics here)");
+    return S2R_OK;
+}
+
+S2rRenderParams make_params(s2r_synth *s, size_t frames, uint32_t sample_rate) {
+    S2rRenderParams p{};
+    p.osc_kind = s->patch.osc_kind;
+    p.osc_gain = s->patch.osc_gain;
+    p.noise_level = s->patch.noise;
+    p.lpf_freq = s->patch.lpf_freq;
+    p.amt_osc = s->patch.mod_env_to_osc_freq;
+    p.amt_lpf = s->patch.mod_env_to_lpf_freq;
+    p.amp = resolve_env(s->patch.amp_env, sample_rate);
+    p.mod = resolve_env(s->patch.mod_env, sample_rate);
+    p.sr = (float)sample_rate;
+    p.rcp_sr = 1.0f / p.sr;
+    p.fast_div_sr = fast_div_rate(sample_rate) ? 1 : 0;
+    p.frames = (uint32_t)frames;
+    p.n_voices = s->shard_voices;
+    p.frames_stride = s->cfg.max_frames;
+    p.v = s->v;
+    p.block_partials = s->block_partials;
+    p.per_voice = nullptr;
+    p.sin_table = s->sin_dev;
+    return p;
+}
+
+// events -> render -> (mix) on `stream`; the partial or final mix lands in `dev_out`
+int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t stream, float *dev_out,
+                 bool root_add, bool stereo, float *per_voice_dev) {
+    int rc = flush_events(s, stream);
+    if (rc != S2R_OK) return rc;
+    S2rRenderParams p = make_params(s, frames, sample_rate);
+    p.per_voice = per_voice_dev;
+    if (s->timing) S2R_HIP(s, hipEventRecord(s->t0, stream));
+    S2R_HIP(s, s2r_launch_render(p, s->block_voices, stream));
+    if (s->timing) { S2R_HIP(s, hipEventRecord(s->t1, stream)); s->timed = true; }
+    if (dev_out) {
+        S2rMixParams m{};
+        m.block_partials = s->block_partials;
+        m.n_blocks = s->n_blocks;
+        m.n_groups = root_add ? s->mix_groups : 1u;
+        m.blocks_per_group = (s->n_blocks + m.n_groups - 1) / m.n_groups;
+        m.frames = (uint32_t)frames;
+        m.frames_stride = s->cfg.max_frames;
+        m.root_add = root_add ? 1 : 0;
+        m.stereo = stereo ? 1 : 0;
+        m.out = dev_out;
+        S2R_HIP(s, s2r_launch_mix(m, stream));
+    }
+    s->pool->advance(frames);
+    return S2R_OK;
+}
+
+int fill_host(s2r_synth *s, float *out, size_t frames, uint32_t sample_rate, bool stereo) {
+    int rc = check_fill(s, frames, sample_rate);
+    if (rc != S2R_OK) return rc;
+    if (frames == 0) return S2R_OK;
+    if (!out) return set_err(s, S2R_ERR_INVALID, "null output buffer");
+    S2R_HIP(s, hipSetDevice(s->device));
+    rc = enqueue_fill(s, frames, sample_rate, s->stream, s->out_dev, true, stereo, nullptr);
+    if (rc != S2R_OK) return rc;
+    const size_t n = frames * (stereo ? 2 : 1);
+    S2R_HIP(s, hipMemcpyAsync(s->out_host, s->out_dev, n * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    S2R_HIP(s, hipStreamSynchronize(s->stream));
+    std::memcpy(out, s->out_host, n * sizeof(float));
+    return S2R_OK;
+}
+
+void release_all(s2r_synth *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (EventSlot &sl : s->slots) {
+        if (sl.host) (void)hipHostFree(sl.host);
+        if (sl.dev) (void)hipFree(sl.dev);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
+    if (s->voice_mem) (void)hipFree(s->voice_mem);
+    if (s->block_partials) (void)hipFree(s->block_partials);
+    if (s->out_dev) (void)hipFree(s->out_dev);
+    if (s->out_host) (void)hipHostFree(s->out_host);
+    if (s->sin_dev) (void)hipFree(s->sin_dev);
+    if (s->per_voice_dev) (void)hipFree(s->per_voice_dev);
+    if (s->t0) (void)hipEventDestroy(s->t0);
+    if (s->t1) (void)hipEventDestroy(s->t1);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t s2r_abi_version(void) { return S2R_ABI_VERSION; }
+
+const char *s2r_status_string(int status) {
+    switch (status) {
+    case S2R_OK: return "ok";
+    case S2R_ERR_INVALID: return "invalid argument";
+    case S2R_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case S2R_ERR_HIP: return "HIP runtime error";
+    case S2R_ERR_PATCH_SYNTAX: return ".synth2 syntax error";
+    case S2R_ERR_PATCH_RANGE: return "patch value out of range";
+    case S2R_ERR_TOO_MANY_FRAMES: return "frames exceed max_frames";
+    case S2R_ERR_OFFSET_OVERFLOW: return "voice frame offset overflow";
+    case S2R_ERR_OUT_OF_MEMORY: return "out of memory";
+    default: return "unknown status";
+    }
+}
+
+int s2r_create(const s2r_config *cfg, s2r_synth **out) {
+    if (!cfg || !out || cfg->struct_size != sizeof(s2r_config)) return S2R_ERR_INVALID;
+    *out = nullptr;
+    if (cfg->total_voices == 0 || cfg->max_frames == 0) return S2R_ERR_INVALID;
+    const uint32_t shard_voices = cfg->shard_voices ? cfg->shard_voices : cfg->total_voices - cfg->shard_begin;
+    if ((uint64_t)cfg->shard_begin + shard_voices > cfg->total_voices || shard_voices == 0) return S2R_ERR_INVALID;
+    const uint32_t bv = cfg->block_voices ? cfg->block_voices : 256u;
+    if (bv < 64 || bv > 1024 || (bv & 63u)) return S2R_ERR_INVALID;
+
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return S2R_ERR_NO_DEVICE;
+    int dev = cfg->device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) return S2R_ERR_NO_DEVICE; }
+    if (dev >= n_dev) return S2R_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return S2R_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return S2R_ERR_NO_DEVICE;   // code objects are gfx950 only
+
+    s2r_synth *s = new (std::nothrow) s2r_synth();
+    if (!s) return S2R_ERR_OUT_OF_MEMORY;
+    s->cfg = *cfg;
+    s->device = dev;
+    s->shard_begin = cfg->shard_begin;
+    s->shard_voices = shard_voices;
+    s->block_voices = bv;
+    s->n_blocks = (shard_voices + bv - 1) / bv;
+    s->padded_voices = s->n_blocks * bv;
+    s->mix_groups = cfg->mix_groups ? cfg->mix_groups : 1u;
+    s2r_default_patch(&s->patch);
+    s->pool.reset(new S2rVoicePool(cfg->total_voices));
+    s->seed_override.assign(cfg->total_voices, 0u);
+    s->pending_slot.assign(shard_voices, -1);
+    build_pitch_table(s->pitch_table);
+
+#define CREATE_HIP(call)                                                                   \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            fprintf(stderr, "libs2r: %s failed: %s\n", #call, hipGetErrorString(e_));      \
+            release_all(s);                                                                \
+            return e_ == hipErrorOutOfMemory ? S2R_ERR_OUT_OF_MEMORY : S2R_ERR_HIP;        \
+        }                                                                                  \
+    } while (0)
+
+    CREATE_HIP(hipSetDevice(dev));
+    CREATE_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    const size_t pv = s->padded_voices;
+    CREATE_HIP(hipMalloc(&s->voice_mem, pv * 7 * sizeof(uint32_t)));
+    CREATE_HIP(hipMemsetAsync(s->voice_mem, 0, pv * 7 * sizeof(uint32_t), s->stream));
+    uint32_t *base = (uint32_t *)s->voice_mem;
+    s->v.pitch = (float *)(base + 0 * pv);
+    s->v.offset = base + 1 * pv;
+    s->v.release = base + 2 * pv;
+    s->v.flags = base + 3 * pv;
+    s->v.phase = (float *)(base + 4 * pv);
+    s->v.lpf_last = (float *)(base + 5 * pv);
+    s->v.seed = base + 6 * pv;
+    CREATE_HIP(hipMalloc((void **)&s->block_partials, (size_t)s->n_blocks * cfg->max_frames * sizeof(float)));
+    CREATE_HIP(hipMalloc((void **)&s->out_dev, (size_t)2 * cfg->max_frames * sizeof(float)));
+    CREATE_HIP(hipHostMalloc((void **)&s->out_host, (size_t)2 * cfg->max_frames * sizeof(float), hipHostMallocDefault));
+    for (EventSlot &sl : s->slots) {
+        CREATE_HIP(hipHostMalloc((void **)&sl.host, (size_t)shard_voices * sizeof(S2rVoiceEvent), hipHostMallocDefault));
+        CREATE_HIP(hipMalloc((void **)&sl.dev, (size_t)shard_voices * sizeof(S2rVoiceEvent)));
+        CREATE_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    }
+    CREATE_HIP(hipEventCreate(&s->t0));
+    CREATE_HIP(hipEventCreate(&s->t1));
+    {
+        float table[1024];
+        build_sin_table(table);
+        if (crc32_bytes(table, sizeof table) != kSinTableCrc) {
+            fprintf(stderr, "libs2r: regenerated SIN_TABLE does not match the reference table (CRC mismatch)\n");
+            release_all(s);
+            return S2R_ERR_INVALID;
+        }
+        CREATE_HIP(hipMalloc((void **)&s->sin_dev, sizeof table));
+        CREATE_HIP(hipMemcpy(s->sin_dev, table, sizeof table, hipMemcpyHostToDevice));
+    }
+    CREATE_HIP(hipStreamSynchronize(s->stream));
+#undef CREATE_HIP
+    *out = s;
+    return S2R_OK;
+}
+
+void s2r_destroy(s2r_synth *s) { release_all(s); }
+
+int s2r_set_patch(s2r_synth *s, const s2r_patch *patch) {
+    if (!s || !patch) return S2R_ERR_INVALID;
+    std::string err;
+    int rc = s2r_validate_patch(patch, &err);
+    if (rc != S2R_OK) return set_err(s, rc, "%s", err.c_str());
+    s->patch = *patch;
+    return S2R_OK;
+}
+
+int s2r_get_patch(const s2r_synth *s, s2r_patch *out) {
+    if (!s || !out) return S2R_ERR_INVALID;
+    *out = s->patch;
+    return S2R_OK;
+}
+
+int s2r_load_patch(s2r_synth *s, const char *text, size_t len) {
+    if (!s || (!text && len)) return S2R_ERR_INVALID;
+    s2r_patch p;
+    std::string err;
+    int rc = s2r_parse_patch(text ? text : "", len, &p, nullptr, &err);
+    if (rc != S2R_OK) return set_err(s, rc, "%s", err.c_str());
+    s->patch = p;
+    return S2R_OK;
+}
+
+int s2r_parse_patch_text(const char *text, size_t len, s2r_patch *out, char *err_buf, size_t err_cap) {
+    if ((!text && len) || !out) return S2R_ERR_INVALID;
+    std::string err;
+    int rc = s2r_parse_patch(text ? text : "", len, out, nullptr, &err);
+    if (err_buf && err_cap) { std::snprintf(err_buf, err_cap, "%s", err.c_str()); }
+    return rc;
+}
+
+int s2r_note_on_ex(s2r_synth *s, uint8_t note, float velocity, uint32_t *voice_index_out) {
+    if (!s) return S2R_ERR_INVALID;
+    const uint32_t i = s->pool->note_on(note, velocity);
+    if (voice_index_out) *voice_index_out = i;
+    push_event(s, i, S2R_EV_RESTART, s->pitch_table[note], s->seed_override[i]);
+    return S2R_OK;
+}
+
+int s2r_note_on(s2r_synth *s, uint8_t note, float velocity) { return s2r_note_on_ex(s, note, velocity, nullptr); }
+
+int s2r_note_off(s2r_synth *s, uint8_t note) {
+    if (!s) return S2R_ERR_INVALID;
+    const int64_t i = s->pool->note_off(note);
+    if (i >= 0) push_event(s, (uint32_t)i, S2R_EV_RELEASE, 0.0f, 0u);
+    return S2R_OK;
+}
+
+int s2r_fill(s2r_synth *s, float *mono_out, size_t frames, uint32_t sample_rate_hz) {
+    return fill_host(s, mono_out, frames, sample_rate_hz, false);
+}
+
+int s2r_fill_stereo(s2r_synth *s, float *interleaved_lr_out, size_t frames, uint32_t sample_rate_hz) {
+    return fill_host(s, interleaved_lr_out, frames, sample_rate_hz, true);
+}
+
+int s2r_fill_device(s2r_synth *s, float *dev_partial_out, size_t frames, uint32_t sample_rate_hz, void *hip_stream) {
+    int rc = check_fill(s, frames, sample_rate_hz);
+    if (rc != S2R_OK) return rc;
+    if (frames == 0) return S2R_OK;
+    if (!dev_partial_out) return set_err(s, S2R_ERR_INVALID, "null device output buffer");
+    S2R_HIP(s, hipSetDevice(s->device));
+    return enqueue_fill(s, frames, sample_rate_hz, (hipStream_t)hip_stream, dev_partial_out, false, false, nullptr);
+}
+
+int s2r_sum_partials_device(const float *dev_rows, uint32_t n_rows, size_t frames, float *dev_out, void *hip_stream) {
+    if (!dev_rows || !dev_out || n_rows == 0) return S2R_ERR_INVALID;
+    return s2r_launch_sum_rows(dev_rows, n_rows, (uint32_t)frames, dev_out, (hipStream_t)hip_stream) == hipSuccess ? S2R_OK : S2R_ERR_HIP;
+}
+
+int s2r_render_voices(s2r_synth *s, float *per_voice_out, size_t frames, uint32_t sample_rate_hz) {
+    int rc = check_fill(s, frames, sample_rate_hz);
+    if (rc != S2R_OK) return rc;
+    if (frames == 0) return S2R_OK;
+    if (!per_voice_out) return set_err(s, S2R_ERR_INVALID, "null output buffer");
+    S2R_HIP(s, hipSetDevice(s->device));
+    const size_t need = (size_t)s->shard_voices * frames;
+    if (need > s->per_voice_cap) {
+        if (s->per_voice_dev) { S2R_HIP(s, hipFree(s->per_voice_dev)); s->per_voice_dev = nullptr; s->per_voice_cap = 0; }
+        S2R_HIP(s, hipMalloc((void **)&s->per_voice_dev, need * sizeof(float)));
+        s->per_voice_cap = need;
+    }
+    rc = enqueue_fill(s, frames, sample_rate_hz, s->stream, nullptr, false, false, s->per_voice_dev);
+    if (rc != S2R_OK) return rc;
+    S2R_HIP(s, hipMemcpyAsync(per_voice_out, s->per_voice_dev, need * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    S2R_HIP(s, hipStreamSynchronize(s->stream));
+    return S2R_OK;
+}
+
+int s2r_export_state(s2r_synth *s, s2r_voice_state *voices) {
+    if (!s || !voices) return S2R_ERR_INVALID;
+    S2R_HIP(s, hipSetDevice(s->device));
+    int rc = flush_events(s, s->stream);
+    if (rc != S2R_OK) return rc;
+    const size_t pv = s->padded_voices;
+    std::vector<uint32_t> h(pv * 7);
+    S2R_HIP(s, hipMemcpyAsync(h.data(), s->voice_mem, pv * 7 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    S2R_HIP(s, hipStreamSynchronize(s->stream));
+    for (uint32_t i = 0; i < s->shard_voices; i++) {
+        const S2rHostVoice &hv = s->pool->voice(s->shard_begin + i);
+        s2r_voice_state &o = voices[i];
+        std::memset(&o, 0, sizeof o);
+        const uint32_t fl = h[3 * pv + i];
+        o.note = hv.note;
+        o.started = (fl & S2R_VF_STARTED) ? 1 : 0;
+        o.released = (fl & S2R_VF_RELEASED) ? 1 : 0;
+        o.current_frame_offset = h[1 * pv + i];
+        o.release_frame_offset = h[2 * pv + i];
+        o.pitch_hz = s2r_u2f(h[0 * pv + i]);
+        o.phase_accum = s2r_u2f(h[4 * pv + i]);
+        o.lpf_last = s2r_u2f(h[5 * pv + i]);
+        o.noise_seed = h[6 * pv + i];
+        o.velocity = hv.velocity;
+    }
+    return S2R_OK;
+}
+
+int s2r_import_state(s2r_synth *s, const s2r_voice_state *voices) {
+    if (!s || !voices) return S2R_ERR_INVALID;
+    S2R_HIP(s, hipSetDevice(s->device));
+    // pending events refer to the state being replaced
+    for (const S2rVoiceEvent &e : s->pending) s->pending_slot[e.voice] = -1;
+    s->pending.clear();
+    const size_t pv = s->padded_voices;
+    std::vector<uint32_t> h(pv * 7, 0u);
+    for (uint32_t i = 0; i < s->shard_voices; i++) {
+        const s2r_voice_state &in = voices[i];
+        h[0 * pv + i] = s2r_f2u(in.started ? in.pitch_hz : 0.0f);
+        h[1 * pv + i] = in.current_frame_offset;
+        h[2 * pv + i] = in.release_frame_offset;
+        h[3 * pv + i] = (in.started ? S2R_VF_STARTED : 0u) | ((in.started && in.released) ? S2R_VF_RELEASED : 0u);
+        h[4 * pv + i] = s2r_f2u(in.phase_accum);
+        h[5 * pv + i] = s2r_f2u(in.lpf_last);
+        h[6 * pv + i] = in.noise_seed;
+        s->pool->set_voice(s->shard_begin + i, in.note, in.started != 0, in.released != 0,
+                           in.current_frame_offset, in.release_frame_offset, in.velocity);
+    }
+    s->pool->rebuild();
+    S2R_HIP(s, hipMemcpyAsync(s->voice_mem, h.data(), pv * 7 * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+    S2R_HIP(s, hipStreamSynchronize(s->stream));
+    return S2R_OK;
+}
+
+int s2r_set_noise_seed(s2r_synth *s, uint32_t voice_index, uint32_t seed) {
+    if (!s || voice_index >= s->pool->size()) return S2R_ERR_INVALID;
+    s->seed_override[voice_index] = seed;
+    if (voice_index >= s->shard_begin && voice_index < s->shard_begin + s->shard_voices) {
+        S2R_HIP(s, hipSetDevice(s->device));
+        int rc = flush_events(s, s->stream);
+        if (rc != S2R_OK) return rc;
+        S2R_HIP(s, hipMemcpyAsync(s->v.seed + (voice_index - s->shard_begin), &s->seed_override[voice_index],
+                                  sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+        S2R_HIP(s, hipStreamSynchronize(s->stream));
+    }
+    return S2R_OK;
+}
+
+uint32_t s2r_shard_voices(const s2r_synth *s) { return s ? s->shard_voices : 0; }
+uint32_t s2r_block_voices(const s2r_synth *s) { return s ? s->block_voices : 0; }
+uint64_t s2r_double_release_count(const s2r_synth *s) { return s ? s->double_release : 0; }
+
+int s2r_set_timing(s2r_synth *s, int enabled) {
+    if (!s) return S2R_ERR_INVALID;
+    s->timing = enabled != 0;
+    s->timed = false;
+    return S2R_OK;
+}
+
+float s2r_last_render_ms(s2r_synth *s) {
+    if (!s || !s->timing || !s->timed) return -1.0f;
+    if (hipEventSynchronize(s->t1) != hipSuccess) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, s->t0, s->t1) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+const char *s2r_last_error(const s2r_synth *s) { return s ? s->err.c_str() : "null handle"; }
+
+// ---- host-only helpers: the voice-allocation policy without a device (tests, front-ends
+// that route events to shards) ----
+struct s2r_voice_pool { S2rVoicePool pool; explicit s2r_voice_pool(uint32_t n) : pool(n) {} };
+
+s2r_voice_pool *s2r_voice_pool_create(uint32_t total_voices) {
+    if (total_voices == 0) return nullptr;
+    return new (std::nothrow) s2r_voice_pool(total_voices);
+}
+void s2r_voice_pool_destroy(s2r_voice_pool *p) { delete p; }
+uint32_t s2r_voice_pool_note_on(s2r_voice_pool *p, uint8_t note, float velocity) { return p->pool.note_on(note, velocity); }
+int64_t s2r_voice_pool_note_off(s2r_voice_pool *p, uint8_t note) { return p->pool.note_off(note); }
+void s2r_voice_pool_advance(s2r_voice_pool *p, uint64_t frames) { p->pool.advance(frames); }
+uint32_t s2r_voice_pool_next_voice(const s2r_voice_pool *p) { return p->pool.next_voice(); }
+int s2r_voice_pool_query(const s2r_voice_pool *p, uint32_t voice_index, s2r_voice_state *out) {
+    if (!p || !out || voice_index >= p->pool.size()) return S2R_ERR_INVALID;
+    const S2rHostVoice &v = p->pool.voice(voice_index);
+    std::memset(out, 0, sizeof *out);
+    out->note = v.note; out->started = v.started; out->released = v.released; out->velocity = v.velocity;
+    if (v.started) {
+        out->current_frame_offset = p->pool.offset_of(voice_index);
+        if (v.released) out->release_frame_offset = p->pool.release_offset_of(voice_index);
+    }
+    return S2R_OK;
+}
+
+}  // extern "C"

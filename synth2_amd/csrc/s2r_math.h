@@ -11,7 +11,7 @@
 //   s2r_expf        Rust `f32::exp` = glibc `expf`           filters.rs:21
 //   s2r_pow2_sleef  `sleef::Sleef::pow(2.0, y)` on f32x16    process.rs:244
 //   s2r_pow2_libm   Rust `2_f32.powf(y)` = glibc `powf`      process.rs:227
-//   s2r_fmod1 / s2r_fmod_pos   Rust `%` on f32 = fmodf       oscillators.rs:379,66,105,154
+//   s2r_fmod1 / s2r_fmod_period  Rust `%` on f32 = fmodf     oscillators.rs:379,66,105,154
 #pragma once
 #include <stdint.h>
 
@@ -121,10 +121,11 @@ S2R_HD float s2r_pow2_libm(float y, const uint64_t* T) {
 // domain |y| <= 10 (Bipolar<10> x Unipolar<1>, static_config.rs:17-20) is far inside.
 // ---------------------------------------------------------------------------------------
 S2R_HD float s2r_pow2_sleef(float y) {
-    if (y != y) return y + y;
-    if (y == 0.0f) return 1.0f;
-    const float ay = __builtin_fabsf(y);
-    if (ay == __builtin_inff()) return y > 0 ? y : 0.0f;
+    // Outside |y| < 150 (NaN, inf, certain over/underflow) — never reached from a valid patch.
+    if (__builtin_expect(!(__builtin_fabsf(y) < 150.0f), 0)) {
+        if (y != y) return y + y;
+        return y > 0 ? __builtin_inff() : 0.0f;
+    }
     // d = dfmul((ln2_hi, ln2_lo), y)
     const float Lh = 0.69314718246459960938f, Ll = -1.904654323148236017e-09f;
     const float dx = Lh * y;
@@ -134,7 +135,6 @@ S2R_HD float s2r_pow2_sleef(float y) {
     const float L2Uf = 0.693145751953125f, L2Lf = 1.428606765330187045e-06f;
     float u = (dx + dy) * R_LN2f;
     const float qf = __builtin_rintf(u);
-    if (!(__builtin_fabsf(qf) < 160.0f)) return qf > 0 ? __builtin_inff() : 0.0f;   // far outside the normal range
     const int q = (int)qf;
     // s = dfadd2(d, q * -L2U)
     float a = qf * -L2Uf;
@@ -144,7 +144,7 @@ S2R_HD float s2r_pow2_sleef(float y) {
     a = qf * -L2Lf;
     float tx = sx + a; v = tx - sx;
     float ty = ((sx - (tx - v)) + (a - v)) + sy;
-    // normalize
+    // s = dfnormalize(s)
     sx = tx + ty; sy = (tx - sx) + ty;
     u = 0.00136324646882712841033936f;
     u = __builtin_fmaf(u, sx, 0.00836596917361021041870117f);
@@ -164,11 +164,32 @@ S2R_HD float s2r_pow2_sleef(float y) {
     const float ox = 1.0f + tx;
     const float oy = ((1.0f - ox) + tx) + ty;
     u = ox + oy;
-    // ldexp(u, q): u in [~0.7, ~1.5), q small => exact scaling by 2^q in two steps
+    // vldexp(u, q): u in (0.7, 1.5), |q| <= 217 => two exact power-of-two scalings
     const int q1 = q >> 1, q2 = q - q1;
     u = u * s2r_u2f((uint32_t)(q1 + 127) << 23) * s2r_u2f((uint32_t)(q2 + 127) << 23);
     if (dx < -104.0f) u = 0.0f;
-    return u;
+    return (y == 0.0f) ? 1.0f : u;    // xpowf: "if (y == 0 || x == 1) result = 1"
+}
+
+// Correctly rounded x / c for a divisor that is constant over a launch; rc = RN(1/c).
+// q0 = RN(x*rc); e = x - q0*c exactly (fma); q = RN(q0 + e*rc)  (Markstein's correction).
+// Exhaustively verified against true division for the divisors the kernels use it with
+// (65535 and the whitelisted sample rates): oracle/xcheck/libm_xcheck.c mode "div".
+// Outside a safe exponent window (and for 0, inf, NaN) it falls back to the real quotient.
+S2R_HD float s2r_div_const(float x, float c, float rc) {
+    const float q0 = x * rc;
+    const float e = __builtin_fmaf(-q0, c, x);
+    float q = __builtin_fmaf(e, rc, q0);
+    const float ax = __builtin_fabsf(x);
+    if (__builtin_expect(!(ax > 0x1p-60f && ax < 0x1p60f), 0)) q = x / c;
+    return q;
+}
+
+// Rust `as u32` / Simd::cast::<u32>() on f32: saturating, NaN -> 0.
+S2R_HD uint32_t s2r_f32_as_u32(float f) {
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)f;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -178,4 +199,17 @@ S2R_HD float s2r_pow2_sleef(float y) {
 S2R_HD float s2r_fmod1(float x) {
     const float r = x - __builtin_truncf(x);
     return __builtin_copysignf(r, x);
+}
+
+// fmodf(off, period) at the oscillator call sites (oscillators.rs:66,105,154; lookup.rs:195),
+// where off = fma(period, phase, 0.0) with phase in [0,1): almost always 0 <= off < period
+// and the result is `off` itself.  Everything else goes to the exact library fmodf
+// (device: ocml's __ocml_fmod_f32 via HIP's fmodf; LLVM's own `frem` expansion is NOT exact).
+S2R_HD float s2r_fmod_period(float off, float period) {
+    if (__builtin_expect(off >= 0.0f && off < period, 1)) return off;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return ::fmodf(off, period);
+#else
+    return __builtin_fmodf(off, period);
+#endif
 }

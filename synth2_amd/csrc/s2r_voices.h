@@ -1,0 +1,135 @@
+// s2r_voices.h — host-side voice pool: the allocation and release policy of
+// s2_lib::try3::synth::Synth (synth.rs:61-120) for a pool of any size, in O(log V) per event
+// instead of the reference's O(V) scans, with identical choices:
+//
+//   next_voice (synth.rs:101-120): the voice with the greatest current_frame_offset, an idle
+//     voice counting as u32::MAX, first index on ties (strict `>`).  All started voices
+//     advance in lockstep (every fill adds `frames` to each), so "greatest offset" ==
+//     "earliest start"; we keep voices ordered by (start_clock, index) and idle voices by
+//     index.  (u32 saturation of very old offsets is unreachable: the reference panics at
+//     that point, process.rs:36, and s2r_fill reports S2R_ERR_OFFSET_OVERFLOW before it.)
+//   note_off (synth.rs:72-96): the LAST index whose note matches and which is active
+//     (started and not yet released).
+//
+// Pure C++ (no HIP) so it is unit-testable on a CPU-only machine.
+#pragma once
+#include <cstdint>
+#include <set>
+#include <utility>
+#include <vector>
+
+struct S2rHostVoice {
+    uint8_t note = 0;
+    bool started = false;
+    bool released = false;
+    float velocity = 0.0f;
+    uint64_t start_clock = 0;      // pool clock (frames) at note_on
+    uint64_t release_clock = 0;    // pool clock at note_off
+};
+
+class S2rVoicePool {
+  public:
+    explicit S2rVoicePool(uint32_t total) : voices_(total) {
+        for (uint32_t i = 0; i < total; i++) idle_.insert(idle_.end(), i);
+    }
+    uint32_t size() const { return (uint32_t)voices_.size(); }
+    uint64_t clock() const { return now_; }
+    const S2rHostVoice &voice(uint32_t i) const { return voices_[i]; }
+
+    // synth.rs:101-120
+    uint32_t next_voice() const {
+        if (!idle_.empty()) return *idle_.begin();
+        return started_.begin()->second;
+    }
+
+    // synth.rs:61-70; returns the chosen index
+    uint32_t note_on(uint8_t note, float velocity) {
+        const uint32_t i = next_voice();
+        S2rHostVoice &v = voices_[i];
+        if (v.started) {
+            started_.erase({v.start_clock, i});
+            if (!v.released) active_[v.note].erase(i);
+        } else {
+            idle_.erase(i);
+        }
+        v.note = note; v.velocity = velocity;
+        v.started = true; v.released = false;
+        v.start_clock = now_; v.release_clock = 0;
+        started_.insert({now_, i});
+        active_[note].insert(i);
+        return i;
+    }
+
+    // synth.rs:72-96; returns the released index or -1 when no active voice holds `note`
+    int64_t note_off(uint8_t note) {
+        std::set<uint32_t> &a = active_[note];
+        if (a.empty()) return -1;
+        const uint32_t i = *a.rbegin();
+        a.erase(i);
+        voices_[i].released = true;
+        voices_[i].release_clock = now_;
+        return i;
+    }
+
+    // every started voice's offset grows by `frames` (synth.rs:197)
+    void advance(uint64_t frames) { now_ += frames; }
+
+    // current_frame_offset of a started voice (saturating like synth.rs:197)
+    uint32_t offset_of(uint32_t i) const {
+        const uint64_t d = now_ - voices_[i].start_clock;
+        return d > 0xffffffffull ? 0xffffffffu : (uint32_t)d;
+    }
+    uint32_t release_offset_of(uint32_t i) const {
+        const uint64_t d = voices_[i].release_clock - voices_[i].start_clock;
+        return d > 0xffffffffull ? 0xffffffffu : (uint32_t)d;
+    }
+    // greatest current_frame_offset among started voices (0 if none)
+    uint64_t oldest_offset() const {
+        if (started_.empty()) return 0;
+        return now_ - started_.begin()->first;
+    }
+
+    // restore one voice (import_state); call rebuild() afterwards
+    void set_voice(uint32_t i, uint8_t note, bool started, bool released, uint32_t offset,
+                   uint32_t release_offset, float velocity) {
+        S2rHostVoice &v = voices_[i];
+        v.note = note; v.started = started; v.released = started && released; v.velocity = velocity;
+        // keep the clock monotone: make sure now_ >= offset so start_clock does not underflow
+        if (started && now_ < offset) pending_min_clock_ = std::max<uint64_t>(pending_min_clock_, offset);
+        pending_.push_back({i, offset, release_offset});
+    }
+    void rebuild() {
+        if (now_ < pending_min_clock_) {
+            // shift the whole time base forward; relative offsets are unchanged
+            const uint64_t shift = pending_min_clock_ - now_;
+            for (auto &v : voices_) { v.start_clock += shift; v.release_clock += shift; }
+            now_ += shift;
+        }
+        for (const auto &p : pending_) {
+            S2rHostVoice &v = voices_[p.i];
+            if (v.started) {
+                v.start_clock = now_ - p.offset;
+                v.release_clock = v.released ? v.start_clock + p.release_offset : 0;
+            }
+        }
+        pending_.clear(); pending_min_clock_ = 0;
+        idle_.clear(); started_.clear();
+        for (auto &a : active_) a.clear();
+        for (uint32_t i = 0; i < voices_.size(); i++) {
+            const S2rHostVoice &v = voices_[i];
+            if (!v.started) { idle_.insert(idle_.end(), i); continue; }
+            started_.insert({v.start_clock, i});
+            if (!v.released) active_[v.note].insert(i);
+        }
+    }
+
+  private:
+    struct Pending { uint32_t i, offset, release_offset; };
+    std::vector<S2rHostVoice> voices_;
+    std::set<uint32_t> idle_;
+    std::set<std::pair<uint64_t, uint32_t>> started_;
+    std::set<uint32_t> active_[256];
+    std::vector<Pending> pending_;
+    uint64_t pending_min_clock_ = 0;
+    uint64_t now_ = 0;
+};

@@ -1,0 +1,321 @@
+"""Host-side mirror of ``s2_lib::try3::synth`` over the C ABI of libs2r (include/s2r.h).
+
+Python is only the test / bench driver here (the reference's host language, Rust, is not in
+this image; rust/s2_lib_gpu holds the uncompiled Rust shim and include/s2_synth.hpp the C++
+one).  Names and argument meaning follow the reference
+(/root/reference/components/s2_lib/src/try3/synth.rs:9-21,53-80,154-156;
+units.rs:11-14):
+
+    synth = Synth()                      # Synth::new()
+    synth.note_on(Note(69), Velocity(1.0))
+    synth.sample(buffer, SampleRateKhz(48000))
+    synth.note_off(Note(69))
+
+There is no CPU fallback: importing works anywhere, constructing a Synth needs libs2r.so and
+a gfx950 device and raises otherwise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+OSC_SQUARE, OSC_SAW, OSC_TRIANGLE, OSC_SINE = 0, 1, 2, 3
+
+S2R_OK = 0
+S2R_ERR_INVALID = -1
+S2R_ERR_NO_DEVICE = -2
+S2R_ERR_HIP = -3
+S2R_ERR_PATCH_SYNTAX = -4
+S2R_ERR_PATCH_RANGE = -5
+S2R_ERR_TOO_MANY_FRAMES = -6
+S2R_ERR_OFFSET_OVERFLOW = -7
+S2R_ERR_OUT_OF_MEMORY = -8
+
+
+class S2rError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("libs2r status %d: %s" % (status, message))
+        self.status = status
+
+
+class Adsr(C.Structure):
+    """static_config.rs:38-44"""
+    _fields_ = [("attack_ms", C.c_float), ("decay_ms", C.c_float), ("sustain", C.c_float), ("release_ms", C.c_float)]
+
+
+class Patch(C.Structure):
+    """static_config.rs:4-24 (sc::Layer)"""
+    _fields_ = [("osc_kind", C.c_int32), ("osc_gain", C.c_float), ("noise", C.c_float), ("lpf_freq", C.c_float),
+                ("amp_env", Adsr), ("mod_env", Adsr),
+                ("mod_env_to_osc_freq", C.c_float), ("mod_env_to_lpf_freq", C.c_float)]
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("total_voices", C.c_uint32), ("shard_begin", C.c_uint32),
+                ("shard_voices", C.c_uint32), ("max_frames", C.c_uint32), ("device", C.c_int32),
+                ("block_voices", C.c_uint32), ("mix_groups", C.c_uint32)]
+
+
+class VoiceState(C.Structure):
+    _fields_ = [("note", C.c_uint8), ("started", C.c_uint8), ("released", C.c_uint8), ("_pad", C.c_uint8),
+                ("current_frame_offset", C.c_uint32), ("release_frame_offset", C.c_uint32),
+                ("pitch_hz", C.c_float), ("phase_accum", C.c_float), ("lpf_last", C.c_float),
+                ("noise_seed", C.c_uint32), ("velocity", C.c_float)]
+
+
+VOICE_STATE_DTYPE = np.dtype([("note", np.uint8), ("started", np.uint8), ("released", np.uint8), ("_pad", np.uint8),
+                              ("current_frame_offset", np.uint32), ("release_frame_offset", np.uint32),
+                              ("pitch_hz", np.float32), ("phase_accum", np.float32), ("lpf_last", np.float32),
+                              ("noise_seed", np.uint32), ("velocity", np.float32)])
+assert VOICE_STATE_DTYPE.itemsize == C.sizeof(VoiceState)
+
+
+class Note(int):
+    """synth.rs:16 ``pub struct Note(pub u8)``"""
+    def __new__(cls, v):
+        if not 0 <= int(v) <= 255:
+            raise ValueError("Note is a u8")
+        return super().__new__(cls, int(v))
+
+
+class Velocity(float):
+    """synth.rs:18 ``pub struct Velocity(pub Unipolar<1>)`` (stored, never used in rendering)"""
+
+
+class SampleRateKhz(int):
+    """units.rs:14 — named Khz in the reference but holds Hz (units.rs:21)"""
+
+
+_lib = None
+_f32p = C.POINTER(C.c_float)
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load_library():
+    """dlopen libs2r.so; builds it first when hipcc is present and the sources are newer."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    try:
+        if _build.needs_build():
+            path = _build.build()
+    except Exception:
+        if not os.path.exists(path):
+            raise
+    L = C.CDLL(path)
+    H = C.c_void_p
+    sig = {
+        "s2r_abi_version": (C.c_uint32, []),
+        "s2r_status_string": (C.c_char_p, [C.c_int]),
+        "s2r_create": (C.c_int, [C.POINTER(Config), C.POINTER(H)]),
+        "s2r_destroy": (None, [H]),
+        "s2r_load_patch": (C.c_int, [H, C.c_char_p, C.c_size_t]),
+        "s2r_set_patch": (C.c_int, [H, C.POINTER(Patch)]),
+        "s2r_get_patch": (C.c_int, [H, C.POINTER(Patch)]),
+        "s2r_default_patch": (None, [C.POINTER(Patch)]),
+        "s2r_note_on": (C.c_int, [H, C.c_uint8, C.c_float]),
+        "s2r_note_on_ex": (C.c_int, [H, C.c_uint8, C.c_float, C.POINTER(C.c_uint32)]),
+        "s2r_note_off": (C.c_int, [H, C.c_uint8]),
+        "s2r_fill": (C.c_int, [H, _f32p, C.c_size_t, C.c_uint32]),
+        "s2r_fill_stereo": (C.c_int, [H, _f32p, C.c_size_t, C.c_uint32]),
+        "s2r_fill_device": (C.c_int, [H, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
+        "s2r_sum_partials_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_size_t, C.c_void_p, C.c_void_p]),
+        "s2r_render_voices": (C.c_int, [H, _f32p, C.c_size_t, C.c_uint32]),
+        "s2r_export_state": (C.c_int, [H, C.c_void_p]),
+        "s2r_import_state": (C.c_int, [H, C.c_void_p]),
+        "s2r_set_noise_seed": (C.c_int, [H, C.c_uint32, C.c_uint32]),
+        "s2r_shard_voices": (C.c_uint32, [H]),
+        "s2r_block_voices": (C.c_uint32, [H]),
+        "s2r_double_release_count": (C.c_uint64, [H]),
+        "s2r_set_timing": (C.c_int, [H, C.c_int]),
+        "s2r_last_render_ms": (C.c_float, [H]),
+        "s2r_last_error": (C.c_char_p, [H]),
+        "s2r_parse_patch_text": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(Patch), C.c_char_p, C.c_size_t]),
+        "s2r_voice_pool_create": (H, [C.c_uint32]),
+        "s2r_voice_pool_destroy": (None, [H]),
+        "s2r_voice_pool_note_on": (C.c_uint32, [H, C.c_uint8, C.c_float]),
+        "s2r_voice_pool_note_off": (C.c_int64, [H, C.c_uint8]),
+        "s2r_voice_pool_advance": (None, [H, C.c_uint64]),
+        "s2r_voice_pool_next_voice": (C.c_uint32, [H]),
+        "s2r_voice_pool_query": (C.c_int, [H, C.c_uint32, C.POINTER(VoiceState)]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def default_patch():
+    """Synth::default_config() (synth.rs:125-152)"""
+    p = Patch()
+    load_library().s2r_default_patch(C.byref(p))
+    return p
+
+
+def parse_patch(text):
+    """.synth2 text -> Patch (host only, no device needed)"""
+    L = load_library()
+    p = Patch()
+    raw = text.encode() if isinstance(text, str) else bytes(text)
+    err = C.create_string_buffer(256)
+    rc = L.s2r_parse_patch_text(raw, len(raw), C.byref(p), err, len(err))
+    if rc != S2R_OK:
+        raise S2rError(rc, err.value.decode())
+    return p
+
+
+class VoicePool:
+    """The allocation policy of Synth (synth.rs:61-120) without a device."""
+
+    def __init__(self, total_voices):
+        self.L = load_library()
+        self.p = self.L.s2r_voice_pool_create(total_voices)
+        if not self.p:
+            raise MemoryError("s2r_voice_pool_create")
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            self.L.s2r_voice_pool_destroy(self.p)
+            self.p = None
+
+    def note_on(self, note, velocity=1.0):
+        return self.L.s2r_voice_pool_note_on(self.p, note, velocity)
+
+    def note_off(self, note):
+        return self.L.s2r_voice_pool_note_off(self.p, note)
+
+    def advance(self, frames):
+        self.L.s2r_voice_pool_advance(self.p, frames)
+
+    def next_voice(self):
+        return self.L.s2r_voice_pool_next_voice(self.p)
+
+    def query(self, i):
+        st = VoiceState()
+        rc = self.L.s2r_voice_pool_query(self.p, i, C.byref(st))
+        if rc != S2R_OK:
+            raise S2rError(rc, "voice pool query")
+        return st
+
+
+class Synth:
+    """``s2_lib::try3::synth::Synth`` on an MI355X.
+
+    ``num_voices`` replaces the reference's ``NUM_VOICES = 8`` (synth.rs:7).  For multi-GPU
+    runs every rank builds a Synth over the same pool with its own ``shard_begin`` /
+    ``shard_voices`` and feeds it the same note events.
+    """
+
+    def __init__(self, num_voices=8, max_frames=2048, device=-1, shard_begin=0, shard_voices=0,
+                 block_voices=0, mix_groups=0):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        cfg = Config(C.sizeof(Config), num_voices, shard_begin, shard_voices, max_frames, device, block_voices, mix_groups)
+        rc = self.L.s2r_create(C.byref(cfg), C.byref(self.h))
+        if rc != S2R_OK:
+            self.h = None
+            raise S2rError(rc, self.L.s2r_status_string(rc).decode())
+        self.num_voices = num_voices
+        self.max_frames = max_frames
+        self.shard_voices = self.L.s2r_shard_voices(self.h)
+        self.block_voices = self.L.s2r_block_voices(self.h)
+
+    # Synth::new() (synth.rs:54-59)
+    @classmethod
+    def new(cls):
+        return cls()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.s2r_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc):
+        if rc != S2R_OK:
+            raise S2rError(rc, self.L.s2r_last_error(self.h).decode() or self.L.s2r_status_string(rc).decode())
+
+    # --- patch ---
+    def load_patch(self, text):
+        raw = text.encode() if isinstance(text, str) else bytes(text)
+        self._check(self.L.s2r_load_patch(self.h, raw, len(raw)))
+
+    def set_patch(self, patch):
+        self._check(self.L.s2r_set_patch(self.h, C.byref(patch)))
+
+    def get_patch(self):
+        p = Patch()
+        self._check(self.L.s2r_get_patch(self.h, C.byref(p)))
+        return p
+
+    # --- events (synth.rs:61-80) ---
+    def note_on(self, note, velocity=Velocity(1.0)):
+        idx = C.c_uint32()
+        self._check(self.L.s2r_note_on_ex(self.h, int(note), float(velocity), C.byref(idx)))
+        return idx.value
+
+    def note_off(self, note):
+        self._check(self.L.s2r_note_off(self.h, int(note)))
+
+    # --- Synth::sample(&mut [f32], SampleRateKhz) (synth.rs:154-169) ---
+    def sample(self, buffer, sample_rate=SampleRateKhz(48000)):
+        """Overwrites ``buffer`` (1-D float32, C-contiguous) and returns it."""
+        if isinstance(buffer, int):
+            buffer = np.empty(buffer, dtype=np.float32)
+        assert buffer.dtype == np.float32 and buffer.flags["C_CONTIGUOUS"] and buffer.ndim == 1
+        self._check(self.L.s2r_fill(self.h, buffer.ctypes.data_as(_f32p), buffer.size, int(sample_rate)))
+        return buffer
+
+    def sample_stereo(self, frames, sample_rate=SampleRateKhz(48000)):
+        out = np.empty(2 * frames, dtype=np.float32)
+        self._check(self.L.s2r_fill_stereo(self.h, out.ctypes.data_as(_f32p), frames, int(sample_rate)))
+        return out.reshape(frames, 2)
+
+    def render_voices(self, frames, sample_rate=SampleRateKhz(48000)):
+        """Mix disabled: (shard_voices, frames) float32."""
+        out = np.empty((self.shard_voices, frames), dtype=np.float32)
+        self._check(self.L.s2r_render_voices(self.h, out.ctypes.data_as(_f32p), frames, int(sample_rate)))
+        return out
+
+    def fill_device(self, dev_ptr, frames, sample_rate=SampleRateKhz(48000), stream=None):
+        """Partial mix of this shard into device memory at ``dev_ptr`` on ``stream`` (async)."""
+        self._check(self.L.s2r_fill_device(self.h, C.c_void_p(dev_ptr), frames, int(sample_rate),
+                                           C.c_void_p(stream) if stream else None))
+
+    # --- state ---
+    def export_state(self):
+        arr = np.zeros(self.shard_voices, dtype=VOICE_STATE_DTYPE)
+        self._check(self.L.s2r_export_state(self.h, arr.ctypes.data))
+        return arr
+
+    def import_state(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=VOICE_STATE_DTYPE)
+        assert arr.size == self.shard_voices
+        self._check(self.L.s2r_import_state(self.h, arr.ctypes.data))
+
+    def set_noise_seed(self, voice_index, seed):
+        self._check(self.L.s2r_set_noise_seed(self.h, voice_index, seed))
+
+    def set_timing(self, enabled=True):
+        self._check(self.L.s2r_set_timing(self.h, 1 if enabled else 0))
+
+    def last_render_ms(self):
+        return float(self.L.s2r_last_render_ms(self.h))
+
+
+def sum_partials_device(rows_ptr, n_rows, frames, out_ptr, stream=None):
+    """out = (+0.0 + row0) + row1 + ... on device, rank order (multi-GPU root combine)."""
+    rc = load_library().s2r_sum_partials_device(C.c_void_p(rows_ptr), n_rows, frames, C.c_void_p(out_ptr),
+                                                C.c_void_p(stream) if stream else None)
+    if rc != S2R_OK:
+        raise S2rError(rc, "s2r_sum_partials_device")

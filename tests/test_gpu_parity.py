@@ -1,0 +1,254 @@
+"""GPU parity: the HIP path, called through the C ABI (synth2_amd.Synth -> libs2r.so), against
+the CPU oracle on the same seeded note streams.  The bar is BIT-EXACT float32 (tolerance 0
+ULP) per voice, and bit-exact for the mix when the oracle sums through the documented tree;
+the deviation from the reference's sequential voice order is reported, not asserted to be 0.
+north_star tolerance: within 1 ULP fp32 of the CPU s2_lib path.
+"""
+import numpy as np
+import pytest
+
+from helpers import Pair, assert_bits_equal, lcg, make_patch, ulp_diff
+from oracle import s2o
+import synth2_amd as s2
+
+pytestmark = pytest.mark.gpu
+
+SR = 48000
+
+
+def test_c1_one_voice_default_patch():
+    """BASELINE config 0: example.synth2 (empty body == default patch), 1 voice, 48 kHz,
+    1024-frame buffers; note 69 on at frame 0, off at frame 24000."""
+    pr = Pair(8)
+    pr.gpu.load_patch("synth mySynth {\n\n}\n")
+    pr.note_on(69)
+    frames_done = 0
+    released = False
+    for _ in range(40):
+        if not released and frames_done + 1024 > 24000:
+            # fills of 1024 cannot land exactly on 24000: split the buffer like s2_bin would
+            n = 24000 - frames_done
+            g, o, pv = pr.sample(n)
+            assert_bits_equal(g, o, "pre-release partial buffer")
+            pr.note_off(69)
+            released = True
+            g, o, pv = pr.sample(1024 - n)
+            assert_bits_equal(g, o, "post-release partial buffer")
+            frames_done += 1024
+            continue
+        g, o, pv = pr.sample(1024)
+        assert_bits_equal(g, o, "buffer at frame %d" % frames_done)
+        # with one voice the tree and the reference's sequential order coincide
+        assert_bits_equal(o, s2o.mix_sequential(pv), "tree vs sequential, 1 voice")
+        frames_done += 1024
+    assert np.any(g == 0.0)      # envelope has ended
+
+
+@pytest.mark.parametrize("osc", [s2.OSC_SQUARE, s2.OSC_SAW, s2.OSC_TRIANGLE, s2.OSC_SINE])
+@pytest.mark.parametrize("fm", [0.0, 3.5])
+def test_per_voice_all_oscillators(osc, fm):
+    """every oscillator kind, with and without oscillator FM (mod_env_to_osc_freq), mix off"""
+    patch = make_patch(osc_kind=osc, mod_env_to_osc_freq=fm, noise=0.25, osc_gain=0.75)
+    patch.mod_env.attack_ms = 5.0
+    patch.mod_env.sustain = 0.3
+    patch.mod_env.release_ms = 40.0
+    pr = Pair(64, patch)
+    for v in range(40):
+        pr.note_on(30 + (v * 7) % 70)
+    for k in range(6):
+        g, o = pr.render_voices(512)
+        assert_bits_equal(g, o, "osc %d fm %g block %d" % (osc, fm, k))
+        if k == 2:
+            for v in range(0, 40, 3):
+                pr.note_off(30 + (v * 7) % 70)
+
+
+def test_c2_1024_voices_one_workgroup():
+    """BASELINE config 1: 1024 voices, default patch, one 1024-thread workgroup"""
+    _run_c2(block_voices=1024)
+
+
+def test_c2_1024_voices_blocks_of_256():
+    _run_c2(block_voices=256)
+
+
+def _run_c2(block_voices):
+    V = 1024
+    pr = Pair(V, block_voices=block_voices)
+    for v in range(V):
+        pr.note_on(36 + (v % 61))
+    # per-note release countdown derived from the LCG so every ADSR stage is live
+    worst = 0
+    for b in range(24):
+        if b >= 2:
+            for note in range(36, 97):
+                if lcg(note * 131 + b) % 5 == 0:
+                    pr.note_off(note)
+        g, o, pv = pr.sample(1024)
+        assert_bits_equal(g, o, "C2 buffer %d (block_voices %d)" % (b, block_voices))
+        worst = max(worst, ulp_diff(o, s2o.mix_sequential(pv)))
+    print("C2 tree-vs-sequential mix deviation: %d ULP max" % worst)
+
+
+@pytest.mark.parametrize("frames", [1, 7, 15, 17, 100, 1000, 1023])
+def test_tail_frames_use_scalar_path(frames):
+    """frames % 16 != 0: the tail goes through the scalar path with its different semantics
+    (multiplicative gains, release from the current level, libm powf) — process.rs:39-48"""
+    patch = make_patch(noise=0.5, osc_gain=0.5, mod_env_to_osc_freq=1.25)
+    pr = Pair(16, patch)
+    for v in range(10):
+        pr.note_on(40 + 3 * v)
+    for k in range(5):
+        g, o = pr.render_voices(frames)
+        assert_bits_equal(g, o, "tail %d call %d" % (frames, k))
+        if k == 1:
+            pr.note_off(43)
+            pr.note_off(61)
+
+
+def test_reference_call_pattern_16_frame_fills():
+    """s2_bin applies MIDI between 16-frame sample() calls (main.rs:138-143)"""
+    pr = Pair(8)
+    rng = np.random.RandomState(7)
+    held = []
+    for k in range(400):
+        r = rng.randint(0, 20)
+        if r == 0:
+            n = int(rng.randint(40, 90))
+            pr.note_on(n)
+            held.append(n)
+        elif r == 1 and held:
+            pr.note_off(held.pop(rng.randint(len(held))))
+        g, o, pv = pr.sample(16)
+        assert_bits_equal(g, o, "16-frame fill %d" % k)
+
+
+def test_voice_stealing_and_retrigger():
+    pr = Pair(8)
+    for n in range(60, 72):          # 12 note-ons into 8 voices: steals the oldest
+        pr.note_on(n)
+        g, o, _ = pr.sample(64)
+        assert_bits_equal(g, o)
+    pr.note_on(60); pr.note_on(60)   # same note twice, then off releases the LAST active match
+    pr.note_off(60)
+    g, o, _ = pr.sample(256)
+    assert_bits_equal(g, o)
+    pr.note_off(60)
+    pr.note_off(60)                  # nothing active any more: no-op
+    g, o, _ = pr.sample(256)
+    assert_bits_equal(g, o)
+
+
+def test_note_on_and_off_between_same_fill():
+    pr = Pair(8)
+    pr.note_on(64); pr.note_off(64)  # release offset 0
+    pr.note_on(70)
+    for _ in range(4):
+        g, o, _ = pr.sample(512)
+        assert_bits_equal(g, o)
+
+
+def test_seeded_noise_variant():
+    """NoiseState.seed = v so voices are decorrelated (SURVEY §8d variant)"""
+    V = 256
+    seeds = ((np.arange(V, dtype=np.uint64) * 2654435761) % (1 << 32)).astype(np.uint32)
+    pr = Pair(V, make_patch(noise=1.0), seeds=seeds)
+    for v in range(V):
+        pr.note_on(36 + v % 61)
+    for _ in range(3):
+        g, o = pr.render_voices(256)
+        assert_bits_equal(g, o, "seeded noise")
+
+
+def test_mix_groups_reproduce_multi_gpu_order():
+    """1 GPU with mix_groups=2 == the order a 2-GPU run produces; and two shard handles,
+    partial mixes combined in rank order, give the same bits."""
+    V = 1024
+    pr = Pair(V, mix_groups=2)
+    sh = [s2.Synth(V, shard_begin=r * 512, shard_voices=512) for r in range(2)]
+    for v in range(V):
+        pr.note_on(36 + (v % 61))
+        for s in sh:
+            s.note_on(36 + (v % 61))
+    import torch
+    for b in range(3):
+        g, o, pv = pr.sample(1024)
+        assert_bits_equal(g, o, "groups=2 vs oracle tree")
+        rows = torch.empty((2, 1024), dtype=torch.float32, device="cuda")
+        out = torch.empty(1024, dtype=torch.float32, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        for r, s in enumerate(sh):
+            s.fill_device(rows[r].data_ptr(), 1024, SR, st)
+        s2.sum_partials_device(rows.data_ptr(), 2, 1024, out.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert_bits_equal(out.cpu().numpy(), g, "2 shards combined vs 1 GPU with mix_groups=2")
+        for r in range(2):
+            assert_bits_equal(rows[r].cpu().numpy(), s2o.mix_tree_partial(pv[r * 512:(r + 1) * 512], 256), "shard %d partial" % r)
+
+
+def test_stereo_is_mono_on_both_channels():
+    pr = Pair(8)
+    pr.note_on(57)
+    lr = pr.gpu.sample_stereo(512)
+    o = s2o.mix_tree(pr.cpu.render_voices(512), pr.block_voices, 1)
+    assert_bits_equal(lr[:, 0], o)
+    assert_bits_equal(lr[:, 1], o)
+
+
+def test_export_import_roundtrip_and_large_offsets():
+    """checkpoint/resume; offsets past 2^24 where u32->f32 rounds (SURVEY §7 hard parts)"""
+    pr = Pair(8)
+    for n in (50, 62, 74):
+        pr.note_on(n)
+    g, o, _ = pr.sample(1024)
+    st = pr.gpu.export_state()
+    # push voices far out: the oracle gets the same edit
+    for v in range(3):
+        st["current_frame_offset"][v] = (1 << 24) + 12345 * (v + 1)
+        pr.cpu.voice(v).current_frame_offset = int(st["current_frame_offset"][v])
+    st["released"][1] = 1
+    st["release_frame_offset"][1] = (1 << 24) + 20000
+    pr.cpu.voice(1).has_release = 1
+    pr.cpu.voice(1).release_frame_offset = (1 << 24) + 20000
+    pr.gpu.import_state(st)
+    for _ in range(3):
+        g, o, _ = pr.sample(1024)
+        assert_bits_equal(g, o, "after import at 2^24+")
+    st2 = pr.gpu.export_state()
+    for v in range(3):
+        assert st2["current_frame_offset"][v] == pr.cpu.voice(v).current_frame_offset
+        assert np.float32(st2["phase_accum"][v]).view(np.uint32) == np.float32(pr.cpu.voice(v).state.phase_accum).view(np.uint32)
+        assert np.float32(st2["lpf_last"][v]).view(np.uint32) == np.float32(pr.cpu.voice(v).state.lpf_last).view(np.uint32)
+
+
+def test_noise_division_all_u16_values():
+    """hash_noise's 3-op exact quotient v/65535 on the device for all 65536 values: offsets
+    0..65535*k hit every low-16 pattern of h; compare a long noise-only render."""
+    patch = make_patch(noise=1.0, osc_gain=0.0)
+    patch.amp_env.attack_ms = 0.0
+    pr = Pair(64, patch)
+    pr.note_on(69)
+    for _ in range(5):
+        g, o = pr.render_voices(2048)
+        assert_bits_equal(g[0], o[0], "noise quotient")
+
+
+def test_error_statuses():
+    s = s2.Synth(8, max_frames=256)
+    with pytest.raises(s2.S2rError) as e:
+        s.sample(np.empty(257, dtype=np.float32))
+    assert e.value.status == -6
+    st = s.export_state()
+    st["started"][0] = 1
+    st["current_frame_offset"][0] = 0xFFFFFFF0
+    s.import_state(st)
+    with pytest.raises(s2.S2rError) as e:
+        s.sample(np.empty(32, dtype=np.float32))
+    assert e.value.status == -7          # the reference panics here (process.rs:36)
+    with pytest.raises(s2.S2rError) as e:
+        s.load_patch("synth x { osc.gain = 3 }")
+    assert e.value.status == -5
+    with pytest.raises(s2.S2rError) as e:
+        s.load_patch("synth x { bogus = 3 }")
+    assert e.value.status == -4
+    assert s.sample(np.empty(0, dtype=np.float32)).size == 0      # empty buffer is fine
