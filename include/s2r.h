@@ -77,6 +77,9 @@ typedef struct {
                                       0 => 256.  Part of the mix-tree spec */
     uint32_t mix_groups;           /* >= 1: second-level grouping of the block partials so a
                                       1-GPU run reproduces the G-GPU summation order; 0 => 1 */
+    uint32_t lanes_per_voice;      /* 1, 2 or 4 GPU lanes cooperating on one voice (a pure
+                                      scheduling knob: results are bit-identical); 0 => auto
+                                      from the shard size */
 } s2r_config;
 
 /* One voice's complete state, for checkpoint/resume and tests.
@@ -116,6 +119,13 @@ int s2r_note_on_ex(s2r_synth *s, uint8_t note, float velocity, uint32_t *voice_i
 /* Synth::note_off(Note) (synth.rs:72-96): last active voice holding `note`. */
 int s2r_note_off(s2r_synth *s, uint8_t note);
 
+/* A batch of note_on / note_off calls applied in order — what s2_bin's
+ * apply_all_midi_messages loop does between two sample() calls (main.rs:170-187), in one
+ * crossing of the boundary. */
+typedef enum { S2R_NOTE_OFF = 0, S2R_NOTE_ON = 1 } s2r_note_kind;
+typedef struct { uint8_t kind; uint8_t note; uint8_t _pad[2]; float velocity; } s2r_note_event;
+int s2r_note_events(s2r_synth *s, const s2r_note_event *events, size_t n);
+
 /* Synth::sample(&mut [f32], SampleRateKhz) (synth.rs:154-169).  `sample_rate_hz` is what
  * the reference calls SampleRateKhz but holds Hz (units.rs:14).  Full 16-frame chunks take
  * the x16 code path, a tail of frames % 16 the scalar path, restarting per call
@@ -149,6 +159,7 @@ int s2r_set_noise_seed(s2r_synth *s, uint32_t voice_index, uint32_t seed);
 uint32_t s2r_abi_version(void);
 uint32_t s2r_shard_voices(const s2r_synth *s);
 uint32_t s2r_block_voices(const s2r_synth *s);
+uint32_t s2r_lanes_per_voice(const s2r_synth *s);
 uint64_t s2r_double_release_count(const s2r_synth *s);      /* synth.rs:77 warn counter */
 /* device time of the most recent fill's render kernel in milliseconds (HIP events recorded
  * on the library's stream around the launch); < 0 if timing is off.  Enable with

@@ -98,7 +98,7 @@ struct EventSlot {
 struct s2r_synth {
     s2r_config cfg{};
     int device = 0;
-    uint32_t shard_begin = 0, shard_voices = 0, padded_voices = 0, block_voices = 256, n_blocks = 0, mix_groups = 1;
+    uint32_t shard_begin = 0, shard_voices = 0, padded_voices = 0, block_voices = 256, n_blocks = 0, mix_groups = 1, lanes = 1;
     s2r_patch patch{};
     std::unique_ptr<S2rVoicePool> pool;
     std::vector<uint32_t> seed_override;         // per pool voice; 0 = reference behaviour
@@ -194,7 +194,9 @@ S2rRenderParams make_params(s2r_synth *s, size_t frames, uint32_t sample_rate) {
     p.mod = resolve_env(s->patch.mod_env, sample_rate);
     p.sr = (float)sample_rate;
     p.rcp_sr = 1.0f / p.sr;
-    p.fast_div_sr = fast_div_rate(sample_rate) ? 1 : 0;
+    // 2^-10 <= pow2 <= 2^10 (|mod * amount| <= 10), so lpf_freq in [2^-30, 2^30] keeps the
+    // dividend inside the window the 3-op quotient was verified for
+    p.fast_div_sr = (fast_div_rate(sample_rate) && s->patch.lpf_freq >= 0x1p-30f && s->patch.lpf_freq <= 0x1p30f) ? 1 : 0;
     p.frames = (uint32_t)frames;
     p.n_voices = s->shard_voices;
     p.frames_stride = s->cfg.max_frames;
@@ -213,7 +215,7 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
     S2rRenderParams p = make_params(s, frames, sample_rate);
     p.per_voice = per_voice_dev;
     if (s->timing) S2R_HIP(s, hipEventRecord(s->t0, stream));
-    S2R_HIP(s, s2r_launch_render(p, s->block_voices, stream));
+    S2R_HIP(s, s2r_launch_render(p, s->block_voices, s->lanes, stream));
     if (s->timing) { S2R_HIP(s, hipEventRecord(s->t1, stream)); s->timed = true; }
     if (dev_out) {
         S2rMixParams m{};
@@ -317,6 +319,15 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
     s->n_blocks = (shard_voices + bv - 1) / bv;
     s->padded_voices = s->n_blocks * bv;
     s->mix_groups = cfg->mix_groups ? cfg->mix_groups : 1u;
+    {
+        // lanes per voice: enough waves to give every SIMD of the 256 CUs a few (64 k voices at
+        // one lane per voice are exactly one wave per SIMD)
+        uint32_t l = cfg->lanes_per_voice;
+        if (l == 0) l = shard_voices <= 65536u ? 4u : (shard_voices <= 131072u ? 2u : 1u);
+        while (l > 1 && bv * l > 1024u) l >>= 1;
+        if (l != 1 && l != 2 && l != 4) { delete s; return S2R_ERR_INVALID; }
+        s->lanes = l;
+    }
     s2r_default_patch(&s->patch);
     s->pool.reset(new S2rVoicePool(cfg->total_voices));
     s->seed_override.assign(cfg->total_voices, 0u);
@@ -422,6 +433,23 @@ int s2r_note_off(s2r_synth *s, uint8_t note) {
     if (!s) return S2R_ERR_INVALID;
     const int64_t i = s->pool->note_off(note);
     if (i >= 0) push_event(s, (uint32_t)i, S2R_EV_RELEASE, 0.0f, 0u);
+    return S2R_OK;
+}
+
+int s2r_note_events(s2r_synth *s, const s2r_note_event *events, size_t n) {
+    if (!s || (!events && n)) return S2R_ERR_INVALID;
+    for (size_t k = 0; k < n; k++) {
+        const s2r_note_event &e = events[k];
+        if (e.kind == S2R_NOTE_ON) {
+            const uint32_t i = s->pool->note_on(e.note, e.velocity);
+            push_event(s, i, S2R_EV_RESTART, s->pitch_table[e.note], s->seed_override[i]);
+        } else if (e.kind == S2R_NOTE_OFF) {
+            const int64_t i = s->pool->note_off(e.note);
+            if (i >= 0) push_event(s, (uint32_t)i, S2R_EV_RELEASE, 0.0f, 0u);
+        } else {
+            return set_err(s, S2R_ERR_INVALID, "event %zu: unknown kind %u", k, (unsigned)e.kind);
+        }
+    }
     return S2R_OK;
 }
 
@@ -536,6 +564,7 @@ int s2r_set_noise_seed(s2r_synth *s, uint32_t voice_index, uint32_t seed) {
 
 uint32_t s2r_shard_voices(const s2r_synth *s) { return s ? s->shard_voices : 0; }
 uint32_t s2r_block_voices(const s2r_synth *s) { return s ? s->block_voices : 0; }
+uint32_t s2r_lanes_per_voice(const s2r_synth *s) { return s ? s->lanes : 0; }
 uint64_t s2r_double_release_count(const s2r_synth *s) { return s ? s->double_release : 0; }
 
 int s2r_set_timing(s2r_synth *s, int enabled) {

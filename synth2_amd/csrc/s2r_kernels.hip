@@ -31,16 +31,6 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_mov(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
 }
-__device__ __forceinline__ float wave_sum_lane63(float v) {
-    v = v + dpp_mov<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]  : pairs
-    v = v + dpp_mov<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]  : quads
-    v = v + dpp_mov<0x141, 0xf>(v);   // row_half_mirror      : 8
-    v = v + dpp_mov<0x140, 0xf>(v);   // row_mirror           : 16 (row totals in every lane)
-    v = v + dpp_mov<0x142, 0xa>(v);   // row_bcast15 -> rows 1,3 : (r0+r1), (r2+r3)
-    v = v + dpp_mov<0x143, 0xc>(v);   // row_bcast31 -> rows 2,3 : total in lane 63
-    return v;
-}
-
 // ---------------------------------------------------------------------------------------
 // per-voice registers
 // ---------------------------------------------------------------------------------------
@@ -54,8 +44,6 @@ struct VoiceRegs {
     uint32_t seed_rot;        // rotl(seed, 5), hashnoise.rs:61-63
     // x16 ADSR per-voice constants (simdtest.rs:283-286)
     float ro_a, end_a, ro_m, end_m;
-    // hoisted oscillator constants when mod_env_to_osc_freq == 0 (period never changes)
-    float period, inv_period, slope1, slope2, half_period;
 };
 
 // old/simdtest.rs:270-331 AdsrX16::sample for one frame.  `ro`/`end` are the per-voice
@@ -103,31 +91,45 @@ __device__ __forceinline__ float hash_noise(uint32_t seed_rot, float t) {
     const uint32_t off = s2r_f32_as_u32(t);                     // offset.cast::<u32>()
     const uint32_t h = (seed_rot ^ off) * 0x9e3779b9u;          // hash_word_x16, :57-68
     const float value = (float)(h & 0xffffu);                   // cast::<u16>() then ::<f32>()
-    const float q = s2r_div_const(value, 65535.0f, 0x1.0001p-16f);   // value / u16_max
+    // value / u16_max: integers 0..65535 are inside the exhaustively verified window
+    const float q = s2r_div_const_nocheck(value, 65535.0f, 0x1.0001p-16f);
     return __builtin_fmaf(q, 2.0f, -1.0f);                      // (q * 2) is exact, then - 1
 }
 
-// oscillators.rs basic::{Square,Saw,Triangle,Table}Oscillator[X16]::sample given the
-// phased offset.  `FM` selects per-frame slopes vs. the hoisted per-voice ones.
-template <int OSC, bool FM>
-__device__ __forceinline__ float osc_value(const VoiceRegs &r, float period, float off, const float *sSin) {
-    const float x = s2r_fmod_period(off, period);               // offset % period
+// Per-frame oscillator constants.  With mod_env_to_osc_freq == 0 they never change and live
+// in VoiceRegs; with FM they are part of the frame's closed-form work.
+struct OscK {
+    float period, inv_period;
+    float a, b, c;      // SAW: a = -2/period | SQUARE: a = period/2 | TRIANGLE: a = period/2, b = -2/a, c = 2/a
+};
+
+template <int OSC>
+__device__ __forceinline__ OscK make_osck(float period) {
+    OscK k;
+    k.period = period;
+    k.inv_period = 1.0f / period;                                // oscillators.rs:378
+    k.a = k.b = k.c = 0.0f;
+    if (OSC == S2R_OSC_SAW) k.a = -2.0f / period;                // oscillators.rs:107-112
+    if (OSC == S2R_OSC_SQUARE) k.a = period / 2.0f;              // :68-69
+    if (OSC == S2R_OSC_TRIANGLE) { k.a = period / 2.0f; k.b = -2.0f / k.a; k.c = 2.0f / k.a; }   // :156-172
+    return k;
+}
+
+// oscillators.rs basic::{Square,Saw,Triangle,Table}Oscillator[X16]::sample given the phased offset
+template <int OSC>
+__device__ __forceinline__ float osc_value(const OscK &k, float off, const float *sSin) {
+    const float x = s2r_fmod_period(off, k.period);             // offset % period
     if (OSC == S2R_OSC_SAW) {
-        const float slope = FM ? (-2.0f / period) : r.slope1;   // :107-112
-        return __builtin_fmaf(slope, x, 1.0f);
+        return __builtin_fmaf(k.a, x, 1.0f);
     } else if (OSC == S2R_OSC_SQUARE) {
-        const float half = FM ? (period / 2.0f) : r.half_period;    // :68-73
-        return x < half ? 1.0f : -1.0f;
+        return x < k.a ? 1.0f : -1.0f;
     } else if (OSC == S2R_OSC_TRIANGLE) {
-        const float half = FM ? (period / 2.0f) : r.half_period;    // :156-176
-        const float s1 = FM ? (-2.0f / half) : r.slope1;
-        const float s2 = FM ? (2.0f / half) : r.slope2;
-        const float first = __builtin_fmaf(s1, x, 1.0f);
-        const float second = __builtin_fmaf(s2, x - half, -1.0f);
-        return x < half ? first : second;
+        const float first = __builtin_fmaf(k.b, x, 1.0f);
+        const float second = __builtin_fmaf(k.c, x - k.a, -1.0f);
+        return x < k.a ? first : second;
     } else {
         // lookup.rs:46-85 table_lookup_exclusive_x16 on SIN_TABLE (len 1024)
-        const float tv = x * 1024.0f / period;                  // :63
+        const float tv = x * 1024.0f / k.period;                // :63
         const uint32_t i1 = s2r_f32_as_u32(tv);                 // :64
         const uint32_t i2 = (i1 + 1u) & 1023u;                  // :67  (% 1024, wrapping add)
         const float s1 = i1 < 1024u ? sSin[i1] : 0.0f;          // :72 gather_or_default
@@ -136,44 +138,57 @@ __device__ __forceinline__ float osc_value(const VoiceRegs &r, float period, flo
     }
 }
 
-// filters.rs:16-34 LowPassFilter::process
-__device__ __forceinline__ float lpf_step(const S2rRenderParams &p, float f_lpf, float in, float &last, const uint64_t *sT) {
+// filters.rs:20-21: x = exp(-2 pi f / sr)
+template <bool FASTDIV>
+__device__ __forceinline__ float lpf_coeff(const S2rRenderParams &p, float f_lpf, const uint64_t *sT) {
     const float num = (-2.0f * 3.14159274101257324f) * f_lpf;   // -2.0 * pi * freq
-    const float arg = p.fast_div_sr ? s2r_div_const(num, p.sr, p.rcp_sr) : (num / p.sr);
-    const float x = s2r_expf(arg, sT);
+    const float arg = FASTDIV ? s2r_div_const_nocheck(num, p.sr, p.rcp_sr) : (num / p.sr);
+    return s2r_expf(arg, sT);
+}
+
+// filters.rs:23-33: out = a0.mul_add(input, -b1 * last) with a0 = 1 - x, b1 = -x
+__device__ __forceinline__ float lpf_apply(float x, float in, float &last) {
     const float a0 = 1.0f - x;
-    const float out = __builtin_fmaf(a0, in, x * last);         // a0.mul_add(input, -b1 * last), b1 = -x
+    const float out = __builtin_fmaf(a0, in, x * last);
     last = out;
     return out;
 }
 
-// One frame of process_layer_x16 (process.rs:88-99,137-174,306-379) for one voice.
-template <int OSC, bool FM>
-__device__ __forceinline__ float frame_x16(const S2rRenderParams &p, VoiceRegs &r, uint32_t oi,
-                                           const uint64_t *sT, const float *sSin) {
+// The part of a frame that is closed-form in the frame offset (no recurrence): envelopes,
+// filter coefficient, noise (+ the oscillator constants under FM).  process.rs:137-174 and
+// the noise/LPF-coefficient halves of process.rs:306-379.
+struct FrameCF {
+    float amp;       // amp envelope                         process.rs:144
+    float xc;        // exp(-2 pi f_lpf / sr)                filters.rs:21
+    float nz;        // noise(offset) + noise level          process.rs:347-356 (ADD)
+};
+
+template <int OSC, bool FM, bool FASTDIV>
+__device__ __forceinline__ void closed_form_x16(const S2rRenderParams &p, const VoiceRegs &r, uint32_t oi,
+                                                const uint64_t *sT, FrameCF &cf, OscK &k) {
     const float t = (float)oi;                                   // offsets as f32 (simdtest.rs:277-279, process.rs:348)
-    const float amp = adsr_x16(p.amp, r.ro_a, r.end_a, t);       // process.rs:144
+    cf.amp = adsr_x16(p.amp, r.ro_a, r.end_a, t);                // process.rs:144
     const float mod = adsr_x16(p.mod, r.ro_m, r.end_m, t);       // process.rs:145
-    float period, inv_period;
     if (FM) {
-        const float f_osc = s2r_pow2_sleef(mod * p.amt_osc) * r.pitch;   // process.rs:146-147,231-250
-        period = p.sr / f_osc;                                   // units.rs:32-42
-        inv_period = 1.0f / period;                              // oscillators.rs:378
-    } else {
-        period = r.period; inv_period = r.inv_period;
+        const float f_osc = s2r_pow2_sleef_core(mod * p.amt_osc) * r.pitch;   // process.rs:146-147,231-250
+        k = make_osck<OSC>(p.sr / f_osc);                        // units.rs:32-42
     }
-    const float f_lpf = s2r_pow2_sleef(mod * p.amt_lpf) * p.lpf_freq;   // process.rs:148-152
+    const float f_lpf = s2r_pow2_sleef_core(mod * p.amt_lpf) * p.lpf_freq;    // process.rs:148-152
+    cf.xc = lpf_coeff<FASTDIV>(p, f_lpf, sT);
+    cf.nz = hash_noise(r.seed_rot, t) + p.noise_level;
+}
 
+// The recurrence step of a frame: phase accumulation, oscillator, LPF, gain.
+template <int OSC>
+__device__ __forceinline__ float recur_x16(const S2rRenderParams &p, VoiceRegs &r, const FrameCF &cf, const OscK &k,
+                                           const float *sSin) {
     const float ph = r.phase;                                    // oscillators.rs:391-400
-    r.phase = s2r_fmod1(ph + inv_period);
-    const float off = __builtin_fmaf(period, ph, 0.0f);          // phased_offset_x16, :235
-    const float osc = osc_value<OSC, FM>(r, period, off, sSin);
-
-    const float osc_s = osc + p.osc_gain;                        // process.rs:342-345 (ADD)
-    const float noise_s = hash_noise(r.seed_rot, t) + p.noise_level;   // process.rs:347-356 (ADD)
-    const float s = osc_s + noise_s;                             // process.rs:358
-    const float y = lpf_step(p, f_lpf, s, r.last, sT);           // process.rs:363-371
-    return y * amp;                                              // process.rs:373-376
+    r.phase = s2r_fmod1(ph + k.inv_period);
+    const float off = __builtin_fmaf(k.period, ph, 0.0f);        // phased_offset_x16, :235
+    const float osc = osc_value<OSC>(k, off, sSin);
+    const float s = (osc + p.osc_gain) + cf.nz;                  // process.rs:342-345 (ADD), :358
+    const float y = lpf_apply(cf.xc, s, r.last);                 // process.rs:363-371
+    return y * cf.amp;                                           // process.rs:373-376
 }
 
 // One frame of process_layer (scalar "sisd" path: process.rs:101-135,252-304).
@@ -186,22 +201,49 @@ __device__ float frame_sisd(const S2rRenderParams &p, VoiceRegs &r, uint32_t oi,
     const float mod = adsr_scalar(p.mod, t, rel);
     const float f_osc = s2r_pow2_libm(mod * p.amt_osc, sT) * r.pitch;    // process.rs:221-229
     const float f_lpf = s2r_pow2_libm(mod * p.amt_lpf, sT) * p.lpf_freq;
-    const float period = p.sr / f_osc;
+    const OscK k = make_osck<OSC>(p.sr / f_osc);
     const float ph = r.phase;
-    const float off = __builtin_fmaf(period, ph, 0.0f);                  // oscillators.rs:212
-    const float osc = osc_value<OSC, true>(r, period, off, sSin);
-    r.phase = s2r_fmod1(ph + 1.0f / period);                             // oscillators.rs:377-381
+    const float off = __builtin_fmaf(k.period, ph, 0.0f);                // oscillators.rs:212
+    const float osc = osc_value<OSC>(k, off, sSin);
+    r.phase = s2r_fmod1(ph + k.inv_period);                              // oscillators.rs:377-381
     const float osc_s = osc * p.osc_gain;                                // process.rs:287 (MULTIPLY)
-    const float noise_s = hash_noise(r.seed_rot, t) * p.noise_level;     // process.rs:292 (MULTIPLY)
+    const float noise_s = (hash_noise(r.seed_rot, t)) * p.noise_level;   // process.rs:292 (MULTIPLY)
     const float s = osc_s + noise_s;
-    const float y = lpf_step(p, f_lpf, s, r.last, sT);
+    const float x = lpf_coeff<false>(p, f_lpf, sT);
+    const float y = lpf_apply(x, s, r.last);
     return y * amp;
 }
 
+// quad_perm broadcast of sub-lane K inside each group of L consecutive lanes
+template <int L, int K>
+__device__ __forceinline__ float bcast_sub(float v) {
+    constexpr int ctrl = (L == 4) ? (K * 0x55) : ((K) | (K << 2) | ((2 + K) << 4) | ((2 + K) << 6));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false));
+}
+
+// wave64 sum where every voice's value is replicated over L consecutive lanes: the first
+// log2(L) butterfly steps are skipped, leaving the balanced tree over the wave's 64/L voices.
+template <int L>
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+    if (L == 1) v = v + dpp_mov<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]  : pairs
+    if (L <= 2) v = v + dpp_mov<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]  : quads
+    v = v + dpp_mov<0x141, 0xf>(v);               // row_half_mirror      : 8
+    v = v + dpp_mov<0x140, 0xf>(v);               // row_mirror           : 16 (row totals in every lane)
+    v = v + dpp_mov<0x142, 0xa>(v);               // row_bcast15 -> rows 1,3 : (r0+r1), (r2+r3)
+    v = v + dpp_mov<0x143, 0xc>(v);               // row_bcast31 -> rows 2,3 : total in lane 63
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------
-// render kernel: grid = ceil(n_voices / blockDim.x), blockDim.x = block_voices (64..1024).
+// render kernel.  L lanes per voice (1, 2 or 4): the closed-form work of L consecutive
+// frames is spread over the voice's L lanes (each lane does ONE of the L frames), the
+// results are exchanged with quad_perm DPP moves and every lane then runs the short
+// recurrence for all L frames redundantly.  This multiplies the number of waves by L for
+// the same voice count (64k voices are only one wave per SIMD at L = 1) at the price of
+// L x the recurrence work, which is ~10% of a frame.
+//   grid = ceil(n_voices / block_voices), blockDim.x = block_voices * L.
 // ---------------------------------------------------------------------------------------
-template <int OSC, bool FM>
+template <int OSC, bool FM, bool FASTDIV, int L>
 __global__ void __launch_bounds__(1024) s2r_render_kernel(const S2rRenderParams p) {
     __shared__ uint64_t sT[S2R_EXP2F_N];
     __shared__ float sW[2][kMaxWaves][kChunk];
@@ -209,13 +251,15 @@ __global__ void __launch_bounds__(1024) s2r_render_kernel(const S2rRenderParams 
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6, n_waves = blockDim.x >> 6;
-    const uint32_t vi = blockIdx.x * blockDim.x + tid;
+    const uint32_t sub = tid & (L - 1);                          // which of the L frames this lane prepares
+    const uint32_t block_voices = blockDim.x / L;
+    const uint32_t vi = blockIdx.x * block_voices + tid / L;
 
     if (tid < S2R_EXP2F_N) sT[tid] = c_exp2f_table[tid];
     if (OSC == S2R_OSC_SINE)
         for (uint32_t i = tid; i < 1024u; i += blockDim.x) sSin[i] = p.sin_table[i];
 
-    // ---- load per-voice state (coalesced SoA reads) ----
+    // ---- load per-voice state (coalesced SoA reads; the L lanes of a voice read the same words) ----
     const bool in_range = vi < p.n_voices;
     const uint32_t flags = in_range ? p.v.flags[vi] : 0u;
     const bool live = (flags & S2R_VF_STARTED) != 0u;          // synth.rs:178
@@ -233,19 +277,16 @@ __global__ void __launch_bounds__(1024) s2r_render_kernel(const S2rRenderParams 
     r.ro_a = __builtin_fmaxf(rel_f, p.amp.sus_off); r.end_a = r.ro_a + p.amp.R;
     r.ro_m = __builtin_fmaxf(rel_f, p.mod.sus_off); r.end_m = r.ro_m + p.mod.R;
 
-    // mod_env_to_osc_freq == 0: pow(2, mod*0) == 1 exactly, so freq == pitch and the period
-    // (and everything derived by one correctly rounded division) is constant per voice.
-    r.period = p.sr / (1.0f * r.pitch);
-    r.inv_period = 1.0f / r.period;
-    r.half_period = r.period / 2.0f;
-    if (OSC == S2R_OSC_TRIANGLE) { r.slope1 = -2.0f / r.half_period; r.slope2 = 2.0f / r.half_period; }
-    else { r.slope1 = -2.0f / r.period; r.slope2 = 0.0f; }
+    // mod_env_to_osc_freq == 0: pow(2, mod*0) == 1 exactly, so freq == 1.0 * pitch and the
+    // period (and everything derived from it by correctly rounded divisions) is constant.
+    OscK k_const = make_osck<OSC>(p.sr / (1.0f * r.pitch));
 
     __syncthreads();
 
     const bool wave_live = __ballot(live) != 0ull;
     const uint32_t n_chunks = p.frames / kChunk, tail = p.frames % kChunk;
     const size_t pv_base = (size_t)vi * p.frames;
+    const bool pv_write = p.per_voice != nullptr && in_range && sub == 0;
     float *bp = p.block_partials + (size_t)blockIdx.x * p.frames_stride;
     uint32_t buf = 0;
 
@@ -255,39 +296,67 @@ __global__ void __launch_bounds__(1024) s2r_render_kernel(const S2rRenderParams 
         const uint32_t f0 = c * kChunk;
         if (wave_live) {
             if (c < n_chunks) {
-#pragma unroll 2
-                for (uint32_t i = 0; i < kChunk; ++i) {
-                    float out = frame_x16<OSC, FM>(p, r, r.offset + f0 + i, sT, sSin);
-                    out = live ? out : 0.0f;
-                    if (p.per_voice && in_range) p.per_voice[pv_base + f0 + i] = out;
-                    const float tot = wave_sum_lane63(out);
-                    if (lane == 63u) sW[buf][wave][i] = tot;
+                for (uint32_t g = 0; g < kChunk; g += L) {
+                    // closed-form work of frame f0+g+sub on this lane
+                    FrameCF cf; OscK kf = k_const;
+                    closed_form_x16<OSC, FM, FASTDIV>(p, r, r.offset + f0 + g + sub, sT, cf, kf);
+                    // recurrence for the L frames of the group, every lane of the voice alike
+#define S2R_STEP(K)                                                                              \
+                    if constexpr (K < L) {                                                       \
+                        FrameCF c2; OscK k2 = k_const;                                           \
+                        if constexpr (L == 1) { c2 = cf; k2 = kf; }                              \
+                        else {                                                                   \
+                            c2.amp = bcast_sub<L, K>(cf.amp); c2.xc = bcast_sub<L, K>(cf.xc);    \
+                            c2.nz = bcast_sub<L, K>(cf.nz);                                      \
+                            if (FM) {                                                            \
+                                k2.period = bcast_sub<L, K>(kf.period);                          \
+                                k2.inv_period = bcast_sub<L, K>(kf.inv_period);                  \
+                                if (OSC != S2R_OSC_SINE) k2.a = bcast_sub<L, K>(kf.a);           \
+                                if (OSC == S2R_OSC_TRIANGLE) { k2.b = bcast_sub<L, K>(kf.b); k2.c = bcast_sub<L, K>(kf.c); } \
+                            }                                                                    \
+                        }                                                                        \
+                        float out = recur_x16<OSC>(p, r, c2, k2, sSin);                          \
+                        out = live ? out : 0.0f;                                                 \
+                        if (pv_write) p.per_voice[pv_base + f0 + g + K] = out;                   \
+                        const float tot = wave_sum_lane63<L>(out);                               \
+                        if (lane == 63u) sW[buf][wave][g + K] = tot;                             \
+                    }
+                    S2R_STEP(0) S2R_STEP(1) S2R_STEP(2) S2R_STEP(3)
+#undef S2R_STEP
                 }
             } else {
                 for (uint32_t i = 0; i < tail; ++i) {
                     float out = frame_sisd<OSC>(p, r, r.offset + f0 + i, sT, sSin);
                     out = live ? out : 0.0f;
-                    if (p.per_voice && in_range) p.per_voice[pv_base + f0 + i] = out;
-                    const float tot = wave_sum_lane63(out);
+                    if (pv_write) p.per_voice[pv_base + f0 + i] = out;
+                    const float tot = wave_sum_lane63<L>(out);
                     if (lane == 63u) sW[buf][wave][i] = tot;
                 }
             }
         } else {
             if (lane < n_here) sW[buf][wave][lane] = 0.0f;
-            if (p.per_voice && in_range)
+            if (pv_write)
                 for (uint32_t i = 0; i < n_here; ++i) p.per_voice[pv_base + f0 + i] = 0.0f;
         }
         __syncthreads();
-        if (tid < n_here) {                       // waves of the block, in wave order
-            float acc = sW[buf][0][tid];
-            for (uint32_t w = 1; w < n_waves; ++w) acc += sW[buf][w][tid];
+        if (tid < n_here) {
+            // 64-voice sums first (L waves each, pairwise), then those in order: the same tree
+            // for every L (oracle/s2_oracle.c: block_partial)
+            float acc = 0.0f;
+            for (uint32_t w = 0; w < n_waves; w += L) {
+                float s64;
+                if (L == 1) s64 = sW[buf][w][tid];
+                else if (L == 2) s64 = sW[buf][w][tid] + sW[buf][w + 1][tid];
+                else s64 = (sW[buf][w][tid] + sW[buf][w + 1][tid]) + (sW[buf][w + 2][tid] + sW[buf][w + 3][tid]);
+                acc = (w == 0) ? s64 : acc + s64;
+            }
             bp[f0 + tid] = acc;
         }
         buf ^= 1u;
     }
 
     // ---- write back the recurrence state ----
-    if (live) {
+    if (live && sub == 0) {
         const uint32_t o = r.offset;
         p.v.offset[vi] = (o > 0xffffffffu - p.frames) ? 0xffffffffu : o + p.frames;   // synth.rs:197
         p.v.phase[vi] = r.phase;
@@ -308,8 +377,15 @@ __global__ void s2r_mix_kernel(const S2rMixParams m) {
         uint32_t b1 = b0 + m.blocks_per_group;
         if (b1 > m.n_blocks) b1 = m.n_blocks;
         if (b0 >= b1) continue;
-        float acc = m.block_partials[(size_t)b0 * m.frames_stride + f];
-        for (uint32_t b = b0 + 1; b < b1; ++b) acc += m.block_partials[(size_t)b * m.frames_stride + f];
+        // the adds are sequential by specification; the loads are not, so fetch 16 rows at a time
+        float acc = 0.0f;
+        for (uint32_t b = b0; b < b1; b += 16) {
+            float v[16];
+#pragma unroll
+            for (uint32_t j = 0; j < 16; ++j) v[j] = (b + j < b1) ? m.block_partials[(size_t)(b + j) * m.frames_stride + f] : 0.0f;
+#pragma unroll
+            for (uint32_t j = 0; j < 16; ++j) if (b + j < b1) acc = (b + j == b0) ? v[j] : acc + v[j];
+        }
         total = (m.root_add || g > 0) ? total + acc : acc;
     }
     if (m.stereo) { m.out[2 * f] = total; m.out[2 * f + 1] = total; }
@@ -348,25 +424,39 @@ __global__ void s2r_events_kernel(const S2rVoiceArrays v, const S2rVoiceEvent *e
     }
 }
 
-template <int OSC>
-hipError_t launch_osc(const S2rRenderParams &p, uint32_t block_voices, hipStream_t stream) {
+template <int OSC, bool FM, bool FASTDIV>
+hipError_t launch_l(const S2rRenderParams &p, uint32_t block_voices, uint32_t lanes, hipStream_t stream) {
     const uint32_t grid = (p.n_voices + block_voices - 1) / block_voices;
-    // pow(2, mod * amount) == 1 exactly iff amount is +-0 (mod is always finite and >= 0)
-    if (p.amt_osc == 0.0f) hipLaunchKernelGGL((s2r_render_kernel<OSC, false>), dim3(grid), dim3(block_voices), 0, stream, p);
-    else hipLaunchKernelGGL((s2r_render_kernel<OSC, true>), dim3(grid), dim3(block_voices), 0, stream, p);
+    const dim3 block(block_voices * lanes);
+    switch (lanes) {
+    case 1: hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, FASTDIV, 1>), dim3(grid), block, 0, stream, p); break;
+    case 2: hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, FASTDIV, 2>), dim3(grid), block, 0, stream, p); break;
+    case 4: hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, FASTDIV, 4>), dim3(grid), block, 0, stream, p); break;
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
+}
+
+template <int OSC>
+hipError_t launch_osc(const S2rRenderParams &p, uint32_t block_voices, uint32_t lanes, hipStream_t stream) {
+    // pow(2, mod * amount) == 1 exactly iff amount is +-0 (mod is always finite and >= 0)
+    const bool fm = p.amt_osc != 0.0f;
+    const bool fd = p.fast_div_sr != 0;
+    if (fm) return fd ? launch_l<OSC, true, true>(p, block_voices, lanes, stream) : launch_l<OSC, true, false>(p, block_voices, lanes, stream);
+    return fd ? launch_l<OSC, false, true>(p, block_voices, lanes, stream) : launch_l<OSC, false, false>(p, block_voices, lanes, stream);
 }
 
 }  // namespace
 
-hipError_t s2r_launch_render(const S2rRenderParams &p, uint32_t block_voices, hipStream_t stream) {
+hipError_t s2r_launch_render(const S2rRenderParams &p, uint32_t block_voices, uint32_t lanes_per_voice, hipStream_t stream) {
     if (p.n_voices == 0 || p.frames == 0) return hipSuccess;
     if (block_voices < 64 || block_voices > 1024 || (block_voices & 63u)) return hipErrorInvalidValue;
+    if (block_voices * lanes_per_voice > 1024) return hipErrorInvalidValue;
     switch (p.osc_kind) {
-    case S2R_OSC_SQUARE: return launch_osc<S2R_OSC_SQUARE>(p, block_voices, stream);
-    case S2R_OSC_SAW: return launch_osc<S2R_OSC_SAW>(p, block_voices, stream);
-    case S2R_OSC_TRIANGLE: return launch_osc<S2R_OSC_TRIANGLE>(p, block_voices, stream);
-    case S2R_OSC_SINE: return launch_osc<S2R_OSC_SINE>(p, block_voices, stream);
+    case S2R_OSC_SQUARE: return launch_osc<S2R_OSC_SQUARE>(p, block_voices, lanes_per_voice, stream);
+    case S2R_OSC_SAW: return launch_osc<S2R_OSC_SAW>(p, block_voices, lanes_per_voice, stream);
+    case S2R_OSC_TRIANGLE: return launch_osc<S2R_OSC_TRIANGLE>(p, block_voices, lanes_per_voice, stream);
+    case S2R_OSC_SINE: return launch_osc<S2R_OSC_SINE>(p, block_voices, lanes_per_voice, stream);
     default: return hipErrorInvalidValue;
     }
 }

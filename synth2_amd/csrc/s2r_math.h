@@ -47,14 +47,6 @@ S2R_HD double s2r_u2d(uint64_t u) { double d; __builtin_memcpy(&d, &u, 8); retur
 // or LDS copy).
 // ---------------------------------------------------------------------------------------
 S2R_HD float s2r_expf(float x, const uint64_t* T) {
-    const uint32_t ux = s2r_f2u(x);
-    const uint32_t abstop = (ux >> 20) & 0x7ff;
-    if (__builtin_expect(abstop >= 0x42b, 0)) {          // |x| >= 88 or NaN
-        if (ux == 0xff800000u) return 0.0f;              // -inf
-        if (abstop >= 0x7f8) return x + x;               // +inf / NaN
-        if (x > 0x1.62e42ep6f) return __builtin_inff(); // overflow
-        if (x < -0x1.9fe368p6f) return 0.0f;             // underflow
-    }
     const double xd = (double)x;
     const double InvLn2N = 0x1.71547652b82fep+0 * S2R_EXP2F_N;
     const double Shift = 0x1.8p+52;
@@ -76,7 +68,18 @@ S2R_HD float s2r_expf(float x, const uint64_t* T) {
     double y = __builtin_fma(C2, r, 1.0);
     y = __builtin_fma(z, r2, y);
     y = y * s;
-    return (float)y;
+    float res = (float)y;
+    // |x| >= 88 or NaN: the value above is meaningless there (no traps, table index is masked);
+    // replace it.  Kept after the main path so the common case is straight-line code.
+    const uint32_t ux = s2r_f2u(x);
+    const uint32_t abstop = (ux >> 20) & 0x7ff;
+    if (__builtin_expect(abstop >= 0x42b, 0)) {
+        if (ux == 0xff800000u) res = 0.0f;                       // -inf
+        else if (abstop >= 0x7f8) res = x + x;                   // +inf / NaN
+        else if (x > 0x1.62e42ep6f) res = __builtin_inff();     // overflow
+        else if (x < -0x1.9fe368p6f) res = 0.0f;                 // underflow
+    }
+    return res;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -120,12 +123,9 @@ S2R_HD float s2r_pow2_libm(float y, const uint64_t* T) {
 // Valid (bit-exact vs C SLEEF 3.8) wherever the result is a normal float; the patch
 // domain |y| <= 10 (Bipolar<10> x Unipolar<1>, static_config.rs:17-20) is far inside.
 // ---------------------------------------------------------------------------------------
-S2R_HD float s2r_pow2_sleef(float y) {
-    // Outside |y| < 150 (NaN, inf, certain over/underflow) — never reached from a valid patch.
-    if (__builtin_expect(!(__builtin_fabsf(y) < 150.0f), 0)) {
-        if (y != y) return y + y;
-        return y > 0 ? __builtin_inff() : 0.0f;
-    }
+// core: requires |y| < 150 (the kernels call it with |y| <= 10, guaranteed by the patch ranges
+// s2r_set_patch enforces: mod env in [0,1] x Bipolar<10>)
+S2R_HD float s2r_pow2_sleef_core(float y) {
     // d = dfmul((ln2_hi, ln2_lo), y)
     const float Lh = 0.69314718246459960938f, Ll = -1.904654323148236017e-09f;
     const float dx = Lh * y;
@@ -171,11 +171,25 @@ S2R_HD float s2r_pow2_sleef(float y) {
     return (y == 0.0f) ? 1.0f : u;    // xpowf: "if (y == 0 || x == 1) result = 1"
 }
 
+S2R_HD float s2r_pow2_sleef(float y) {
+    // Outside |y| < 150 (NaN, inf, certain over/underflow) — never reached from a valid patch.
+    if (__builtin_expect(!(__builtin_fabsf(y) < 150.0f), 0)) {
+        if (y != y) return y + y;
+        return y > 0 ? __builtin_inff() : 0.0f;
+    }
+    return s2r_pow2_sleef_core(y);
+}
+
 // Correctly rounded x / c for a divisor that is constant over a launch; rc = RN(1/c).
 // q0 = RN(x*rc); e = x - q0*c exactly (fma); q = RN(q0 + e*rc)  (Markstein's correction).
 // Exhaustively verified against true division for the divisors the kernels use it with
 // (65535 and the whitelisted sample rates): oracle/xcheck/libm_xcheck.c mode "div".
 // Outside a safe exponent window (and for 0, inf, NaN) it falls back to the real quotient.
+S2R_HD float s2r_div_const_nocheck(float x, float c, float rc) {   // caller guarantees the window
+    const float q0 = x * rc;
+    const float e = __builtin_fmaf(-q0, c, x);
+    return __builtin_fmaf(e, rc, q0);
+}
 S2R_HD float s2r_div_const(float x, float c, float rc) {
     const float q0 = x * rc;
     const float e = __builtin_fmaf(-q0, c, x);
@@ -187,6 +201,12 @@ S2R_HD float s2r_div_const(float x, float c, float rc) {
 
 // Rust `as u32` / Simd::cast::<u32>() on f32: saturating, NaN -> 0.
 S2R_HD uint32_t s2r_f32_as_u32(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // v_cvt_u32_f32 truncates, clamps to [0, 0xffffffff] and maps NaN to 0: exactly `as u32`
+    uint32_t r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
+#endif
     if (!(f > 0.0f)) return 0u;
     if (f >= 4294967296.0f) return 0xffffffffu;
     return (uint32_t)f;
@@ -206,7 +226,10 @@ S2R_HD float s2r_fmod1(float x) {
 // and the result is `off` itself.  Everything else goes to the exact library fmodf
 // (device: ocml's __ocml_fmod_f32 via HIP's fmodf; LLVM's own `frem` expansion is NOT exact).
 S2R_HD float s2r_fmod_period(float off, float period) {
-    if (__builtin_expect(off >= 0.0f && off < period, 1)) return off;
+    // 0 <= off < period, tested on the bit patterns with ONE unsigned compare: a negative or
+    // NaN `off` has a larger pattern than any positive finite period (period > 0 is an
+    // invariant: pitch > 0, sr > 0, pow2 > 0).
+    if (__builtin_expect(s2r_f2u(off) < s2r_f2u(period) && period > 0.0f, 1)) return off;
 #if defined(__HIP_DEVICE_COMPILE__)
     return ::fmodf(off, period);
 #else

@@ -1,6 +1,6 @@
 // s2r_voices.h — host-side voice pool: the allocation and release policy of
 // s2_lib::try3::synth::Synth (synth.rs:61-120) for a pool of any size, in O(log V) per event
-// instead of the reference's O(V) scans, with identical choices:
+// instead of the reference's O(V) scans (binary heaps, lazy deletion), with identical choices:
 //
 //   next_voice (synth.rs:101-120): the voice with the greatest current_frame_offset, an idle
 //     voice counting as u32::MAX, first index on ties (strict `>`).  All started voices
@@ -13,8 +13,10 @@
 //
 // Pure C++ (no HIP) so it is unit-testable on a CPU-only machine.
 #pragma once
+#include <algorithm>
 #include <cstdint>
-#include <set>
+#include <functional>
+#include <queue>
 #include <utility>
 #include <vector>
 
@@ -23,52 +25,60 @@ struct S2rHostVoice {
     bool started = false;
     bool released = false;
     float velocity = 0.0f;
+    uint32_t gen = 0;              // bumped by every note_on: invalidates stale heap entries
     uint64_t start_clock = 0;      // pool clock (frames) at note_on
     uint64_t release_clock = 0;    // pool clock at note_off
 };
 
 class S2rVoicePool {
   public:
-    explicit S2rVoicePool(uint32_t total) : voices_(total) {
-        for (uint32_t i = 0; i < total; i++) idle_.insert(idle_.end(), i);
-    }
+    explicit S2rVoicePool(uint32_t total) : voices_(total) { rebuild(); }
     uint32_t size() const { return (uint32_t)voices_.size(); }
     uint64_t clock() const { return now_; }
     const S2rHostVoice &voice(uint32_t i) const { return voices_[i]; }
 
     // synth.rs:101-120
     uint32_t next_voice() const {
-        if (!idle_.empty()) return *idle_.begin();
-        return started_.begin()->second;
+        if (idle_head_ < idle_.size()) return idle_[idle_head_];
+        return started_.top().second;
     }
 
     // synth.rs:61-70; returns the chosen index
     uint32_t note_on(uint8_t note, float velocity) {
-        const uint32_t i = next_voice();
-        S2rHostVoice &v = voices_[i];
-        if (v.started) {
-            started_.erase({v.start_clock, i});
-            if (!v.released) active_[v.note].erase(i);
+        uint32_t i;
+        if (idle_head_ < idle_.size()) {
+            i = idle_[idle_head_++];
         } else {
-            idle_.erase(i);
+            // the chosen voice is always the heap's top, so the heap never holds stale entries
+            i = started_.top().second;
+            started_.pop();
+            S2rHostVoice &old = voices_[i];
+            if (!old.released) active_valid_[old.note]--;      // its active_ entry goes stale (gen bump)
         }
+        S2rHostVoice &v = voices_[i];
         v.note = note; v.velocity = velocity;
         v.started = true; v.released = false;
+        v.gen++;
         v.start_clock = now_; v.release_clock = 0;
-        started_.insert({now_, i});
-        active_[note].insert(i);
+        started_.push({now_, i});
+        push_active(note, i, v.gen);
         return i;
     }
 
     // synth.rs:72-96; returns the released index or -1 when no active voice holds `note`
     int64_t note_off(uint8_t note) {
-        std::set<uint32_t> &a = active_[note];
-        if (a.empty()) return -1;
-        const uint32_t i = *a.rbegin();
-        a.erase(i);
-        voices_[i].released = true;
-        voices_[i].release_clock = now_;
-        return i;
+        ActiveHeap &a = active_[note];
+        while (!a.empty()) {
+            const uint32_t i = a.top().first, g = a.top().second;
+            a.pop();
+            S2rHostVoice &v = voices_[i];
+            if (v.gen != g || !v.started || v.released || v.note != note) continue;   // stale
+            v.released = true;
+            v.release_clock = now_;
+            active_valid_[note]--;
+            return i;
+        }
+        return -1;
     }
 
     // every started voice's offset grows by `frames` (synth.rs:197)
@@ -86,7 +96,7 @@ class S2rVoicePool {
     // greatest current_frame_offset among started voices (0 if none)
     uint64_t oldest_offset() const {
         if (started_.empty()) return 0;
-        return now_ - started_.begin()->first;
+        return now_ - started_.top().first;
     }
 
     // restore one voice (import_state); call rebuild() afterwards
@@ -94,13 +104,12 @@ class S2rVoicePool {
                    uint32_t release_offset, float velocity) {
         S2rHostVoice &v = voices_[i];
         v.note = note; v.started = started; v.released = started && released; v.velocity = velocity;
-        // keep the clock monotone: make sure now_ >= offset so start_clock does not underflow
         if (started && now_ < offset) pending_min_clock_ = std::max<uint64_t>(pending_min_clock_, offset);
         pending_.push_back({i, offset, release_offset});
     }
     void rebuild() {
         if (now_ < pending_min_clock_) {
-            // shift the whole time base forward; relative offsets are unchanged
+            // shift the whole time base forward so no start_clock underflows; offsets are unchanged
             const uint64_t shift = pending_min_clock_ - now_;
             for (auto &v : voices_) { v.start_clock += shift; v.release_clock += shift; }
             now_ += shift;
@@ -113,22 +122,45 @@ class S2rVoicePool {
             }
         }
         pending_.clear(); pending_min_clock_ = 0;
-        idle_.clear(); started_.clear();
-        for (auto &a : active_) a.clear();
+        idle_.clear(); idle_head_ = 0;
+        started_ = StartedHeap();
+        for (int n = 0; n < 256; n++) { active_[n] = ActiveHeap(); active_valid_[n] = 0; }
         for (uint32_t i = 0; i < voices_.size(); i++) {
             const S2rHostVoice &v = voices_[i];
-            if (!v.started) { idle_.insert(idle_.end(), i); continue; }
-            started_.insert({v.start_clock, i});
-            if (!v.released) active_[v.note].insert(i);
+            if (!v.started) { idle_.push_back(i); continue; }
+            started_.push({v.start_clock, i});
+            if (!v.released) push_active(v.note, i, v.gen);
         }
     }
 
   private:
     struct Pending { uint32_t i, offset, release_offset; };
+    typedef std::pair<uint64_t, uint32_t> StartedKey;                 // (start_clock, index)
+    typedef std::priority_queue<StartedKey, std::vector<StartedKey>, std::greater<StartedKey>> StartedHeap;
+    typedef std::priority_queue<std::pair<uint32_t, uint32_t>> ActiveHeap;   // max (index, gen)
+
+    void push_active(uint8_t note, uint32_t i, uint32_t gen) {
+        ActiveHeap &a = active_[note];
+        a.push({i, gen});
+        active_valid_[note]++;
+        // stale entries (voices stolen while still held) are dropped lazily; compact when they dominate
+        if (a.size() > 2 * (size_t)active_valid_[note] + 1024) {
+            ActiveHeap fresh;
+            while (!a.empty()) {
+                const auto e = a.top(); a.pop();
+                const S2rHostVoice &v = voices_[e.first];
+                if (v.gen == e.second && v.started && !v.released && v.note == note) fresh.push(e);
+            }
+            a.swap(fresh);
+        }
+    }
+
     std::vector<S2rHostVoice> voices_;
-    std::set<uint32_t> idle_;
-    std::set<std::pair<uint64_t, uint32_t>> started_;
-    std::set<uint32_t> active_[256];
+    std::vector<uint32_t> idle_;        // ascending; consumed from idle_head_ (voices never go idle again)
+    size_t idle_head_ = 0;
+    StartedHeap started_;               // one entry per started voice
+    ActiveHeap active_[256];
+    uint32_t active_valid_[256] = {};
     std::vector<Pending> pending_;
     uint64_t pending_min_clock_ = 0;
     uint64_t now_ = 0;

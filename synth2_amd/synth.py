@@ -55,7 +55,7 @@ class Patch(C.Structure):
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("total_voices", C.c_uint32), ("shard_begin", C.c_uint32),
                 ("shard_voices", C.c_uint32), ("max_frames", C.c_uint32), ("device", C.c_int32),
-                ("block_voices", C.c_uint32), ("mix_groups", C.c_uint32)]
+                ("block_voices", C.c_uint32), ("mix_groups", C.c_uint32), ("lanes_per_voice", C.c_uint32)]
 
 
 class VoiceState(C.Structure):
@@ -70,6 +70,8 @@ VOICE_STATE_DTYPE = np.dtype([("note", np.uint8), ("started", np.uint8), ("relea
                               ("pitch_hz", np.float32), ("phase_accum", np.float32), ("lpf_last", np.float32),
                               ("noise_seed", np.uint32), ("velocity", np.float32)])
 assert VOICE_STATE_DTYPE.itemsize == C.sizeof(VoiceState)
+NOTE_EVENT_DTYPE = np.dtype([("kind", np.uint8), ("note", np.uint8), ("_pad", np.uint8, (2,)), ("velocity", np.float32)])
+assert NOTE_EVENT_DTYPE.itemsize == 8
 
 
 class Note(int):
@@ -122,6 +124,7 @@ def load_library():
         "s2r_note_on": (C.c_int, [H, C.c_uint8, C.c_float]),
         "s2r_note_on_ex": (C.c_int, [H, C.c_uint8, C.c_float, C.POINTER(C.c_uint32)]),
         "s2r_note_off": (C.c_int, [H, C.c_uint8]),
+        "s2r_note_events": (C.c_int, [H, C.c_void_p, C.c_size_t]),
         "s2r_fill": (C.c_int, [H, _f32p, C.c_size_t, C.c_uint32]),
         "s2r_fill_stereo": (C.c_int, [H, _f32p, C.c_size_t, C.c_uint32]),
         "s2r_fill_device": (C.c_int, [H, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
@@ -132,6 +135,7 @@ def load_library():
         "s2r_set_noise_seed": (C.c_int, [H, C.c_uint32, C.c_uint32]),
         "s2r_shard_voices": (C.c_uint32, [H]),
         "s2r_block_voices": (C.c_uint32, [H]),
+        "s2r_lanes_per_voice": (C.c_uint32, [H]),
         "s2r_double_release_count": (C.c_uint64, [H]),
         "s2r_set_timing": (C.c_int, [H, C.c_int]),
         "s2r_last_render_ms": (C.c_float, [H]),
@@ -215,10 +219,11 @@ class Synth:
     """
 
     def __init__(self, num_voices=8, max_frames=2048, device=-1, shard_begin=0, shard_voices=0,
-                 block_voices=0, mix_groups=0):
+                 block_voices=0, mix_groups=0, lanes_per_voice=0):
         self.L = load_library()
         self.h = C.c_void_p()
-        cfg = Config(C.sizeof(Config), num_voices, shard_begin, shard_voices, max_frames, device, block_voices, mix_groups)
+        cfg = Config(C.sizeof(Config), num_voices, shard_begin, shard_voices, max_frames, device, block_voices, mix_groups,
+                     lanes_per_voice)
         rc = self.L.s2r_create(C.byref(cfg), C.byref(self.h))
         if rc != S2R_OK:
             self.h = None
@@ -227,6 +232,7 @@ class Synth:
         self.max_frames = max_frames
         self.shard_voices = self.L.s2r_shard_voices(self.h)
         self.block_voices = self.L.s2r_block_voices(self.h)
+        self.lanes_per_voice = self.L.s2r_lanes_per_voice(self.h)
 
     # Synth::new() (synth.rs:54-59)
     @classmethod
@@ -266,6 +272,12 @@ class Synth:
 
     def note_off(self, note):
         self._check(self.L.s2r_note_off(self.h, int(note)))
+
+    def note_events(self, events):
+        """A batch of events (structured array NOTE_EVENT_DTYPE: kind 1=on 0=off, note, velocity),
+        applied in order in one call — s2_bin's apply_all_midi_messages (main.rs:170-187)."""
+        ev = np.ascontiguousarray(events, dtype=NOTE_EVENT_DTYPE)
+        self._check(self.L.s2r_note_events(self.h, ev.ctypes.data, ev.size))
 
     # --- Synth::sample(&mut [f32], SampleRateKhz) (synth.rs:154-169) ---
     def sample(self, buffer, sample_rate=SampleRateKhz(48000)):

@@ -42,8 +42,9 @@ def lcg(seed):
 class Pair:
     """An oracle synth and a GPU synth driven in lockstep."""
 
-    def __init__(self, num_voices, patch=None, max_frames=2048, block_voices=0, mix_groups=0, seeds=None):
-        self.gpu = s2.Synth(num_voices, max_frames=max_frames, block_voices=block_voices, mix_groups=mix_groups)
+    def __init__(self, num_voices, patch=None, max_frames=2048, block_voices=0, mix_groups=0, seeds=None, lanes=0):
+        self.gpu = s2.Synth(num_voices, max_frames=max_frames, block_voices=block_voices, mix_groups=mix_groups,
+                            lanes_per_voice=lanes)
         self.cpu = s2o.OracleSynth(num_voices)
         self.block_voices = self.gpu.block_voices
         self.groups = mix_groups or 1

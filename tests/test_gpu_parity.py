@@ -44,20 +44,22 @@ def test_c1_one_voice_default_patch():
     assert np.any(g == 0.0)      # envelope has ended
 
 
+@pytest.mark.parametrize("lanes", [1, 2, 4])
 @pytest.mark.parametrize("osc", [s2.OSC_SQUARE, s2.OSC_SAW, s2.OSC_TRIANGLE, s2.OSC_SINE])
 @pytest.mark.parametrize("fm", [0.0, 3.5])
-def test_per_voice_all_oscillators(osc, fm):
+def test_per_voice_all_oscillators(osc, fm, lanes):
     """every oscillator kind, with and without oscillator FM (mod_env_to_osc_freq), mix off"""
     patch = make_patch(osc_kind=osc, mod_env_to_osc_freq=fm, noise=0.25, osc_gain=0.75)
     patch.mod_env.attack_ms = 5.0
     patch.mod_env.sustain = 0.3
     patch.mod_env.release_ms = 40.0
-    pr = Pair(64, patch)
+    pr = Pair(64, patch, lanes=lanes)
+    assert pr.gpu.lanes_per_voice == lanes
     for v in range(40):
         pr.note_on(30 + (v * 7) % 70)
     for k in range(6):
         g, o = pr.render_voices(512)
-        assert_bits_equal(g, o, "osc %d fm %g block %d" % (osc, fm, k))
+        assert_bits_equal(g, o, "osc %d fm %g lanes %d block %d" % (osc, fm, lanes, k))
         if k == 2:
             for v in range(0, 40, 3):
                 pr.note_off(30 + (v * 7) % 70)
@@ -65,16 +67,29 @@ def test_per_voice_all_oscillators(osc, fm):
 
 def test_c2_1024_voices_one_workgroup():
     """BASELINE config 1: 1024 voices, default patch, one 1024-thread workgroup"""
-    _run_c2(block_voices=1024)
+    _run_c2(block_voices=1024, lanes=1)
 
 
-def test_c2_1024_voices_blocks_of_256():
-    _run_c2(block_voices=256)
+@pytest.mark.parametrize("lanes", [1, 2, 4])
+def test_c2_1024_voices_blocks_of_256(lanes):
+    _run_c2(block_voices=256, lanes=lanes)
 
 
-def _run_c2(block_voices):
+def test_sample_rate_without_fast_division():
+    """a rate outside the verified whitelist takes the true-division kernel variant"""
+    pr = Pair(64)
+    for v in range(20):
+        pr.note_on(40 + v)
+    for _ in range(3):
+        g, o, _pv = pr.sample(512, 37123)
+        assert_bits_equal(g, o, "sr 37123")
+        g, o, _pv = pr.sample(512, 44100)
+        assert_bits_equal(g, o, "sr 44100")
+
+
+def _run_c2(block_voices, lanes):
     V = 1024
-    pr = Pair(V, block_voices=block_voices)
+    pr = Pair(V, block_voices=block_voices, lanes=lanes)
     for v in range(V):
         pr.note_on(36 + (v % 61))
     # per-note release countdown derived from the LCG so every ADSR stage is live
@@ -90,12 +105,13 @@ def _run_c2(block_voices):
     print("C2 tree-vs-sequential mix deviation: %d ULP max" % worst)
 
 
+@pytest.mark.parametrize("lanes", [1, 4])
 @pytest.mark.parametrize("frames", [1, 7, 15, 17, 100, 1000, 1023])
-def test_tail_frames_use_scalar_path(frames):
+def test_tail_frames_use_scalar_path(frames, lanes):
     """frames % 16 != 0: the tail goes through the scalar path with its different semantics
     (multiplicative gains, release from the current level, libm powf) — process.rs:39-48"""
     patch = make_patch(noise=0.5, osc_gain=0.5, mod_env_to_osc_freq=1.25)
-    pr = Pair(16, patch)
+    pr = Pair(16, patch, lanes=lanes)
     for v in range(10):
         pr.note_on(40 + 3 * v)
     for k in range(5):
