@@ -20,6 +20,7 @@ __constant__ uint64_t c_exp2f_table[S2R_EXP2F_N] = S2R_EXP2F_TABLE_INIT;
 
 constexpr int kMaxWaves = 16;      // 1024-thread workgroup
 constexpr int kChunk = 16;         // the reference's x16 chunk (synth.rs:158, process.rs:25)
+constexpr uint32_t kSuper = 64;    // frames between two cross-wave combines (one lane of the row buffer each)
 
 // ---------------------------------------------------------------------------------------
 // wave64 sum by DPP.  After the six steps lane 63 holds
@@ -140,10 +141,13 @@ __device__ __forceinline__ float osc_value(const OscK &k, float off, const float
 
 // filters.rs:20-21: x = exp(-2 pi f / sr)
 template <bool FASTDIV>
-__device__ __forceinline__ float lpf_coeff(const S2rRenderParams &p, float f_lpf, const uint64_t *sT) {
+__device__ __forceinline__ float lpf_arg(const S2rRenderParams &p, float f_lpf) {
     const float num = (-2.0f * 3.14159274101257324f) * f_lpf;   // -2.0 * pi * freq
-    const float arg = FASTDIV ? s2r_div_const_nocheck(num, p.sr, p.rcp_sr) : (num / p.sr);
-    return s2r_expf(arg, sT);
+    return FASTDIV ? s2r_div_const_nocheck(num, p.sr, p.rcp_sr) : (num / p.sr);
+}
+template <bool FASTDIV>
+__device__ __forceinline__ float lpf_coeff(const S2rRenderParams &p, float f_lpf, const uint64_t *sT) {
+    return s2r_expf(lpf_arg<FASTDIV>(p, f_lpf), sT);
 }
 
 // filters.rs:23-33: out = a0.mul_add(input, -b1 * last) with a0 = 1 - x, b1 = -x
@@ -167,15 +171,19 @@ template <int OSC, bool FM, bool FASTDIV>
 __device__ __forceinline__ void closed_form_x16(const S2rRenderParams &p, const VoiceRegs &r, uint32_t oi,
                                                 const uint64_t *sT, FrameCF &cf, OscK &k) {
     const float t = (float)oi;                                   // offsets as f32 (simdtest.rs:277-279, process.rs:348)
-    cf.amp = adsr_x16(p.amp, r.ro_a, r.end_a, t);                // process.rs:144
     const float mod = adsr_x16(p.mod, r.ro_m, r.end_m, t);       // process.rs:145
+    const float f_lpf = s2r_pow2_sleef_core(mod * p.amt_lpf) * p.lpf_freq;    // process.rs:148-152
+    // exp(-2 pi f / sr): reduce the argument and issue the LDS table read now, finish after the
+    // independent envelope / noise / FM work so the read's latency is covered
+    const float arg = lpf_arg<FASTDIV>(p, f_lpf);
+    const s2r_expf_partial ep = s2r_expf_begin(arg, sT);
+    cf.amp = adsr_x16(p.amp, r.ro_a, r.end_a, t);                // process.rs:144
+    cf.nz = hash_noise(r.seed_rot, t) + p.noise_level;
     if (FM) {
         const float f_osc = s2r_pow2_sleef_core(mod * p.amt_osc) * r.pitch;   // process.rs:146-147,231-250
         k = make_osck<OSC>(p.sr / f_osc);                        // units.rs:32-42
     }
-    const float f_lpf = s2r_pow2_sleef_core(mod * p.amt_lpf) * p.lpf_freq;    // process.rs:148-152
-    cf.xc = lpf_coeff<FASTDIV>(p, f_lpf, sT);
-    cf.nz = hash_noise(r.seed_rot, t) + p.noise_level;
+    cf.xc = s2r_expf_end(arg, ep);
 }
 
 // The recurrence step of a frame: phase accumulation, oscillator, LPF, gain.
@@ -234,6 +242,12 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
     return v;
 }
 
+// lane 63's wave total of frame `i` goes to lane (i & 63) of the row buffer
+__device__ __forceinline__ float park_total(float rowbuf, float tot, uint32_t i, uint32_t lane) {
+    const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), 63));
+    return lane == (i & 63u) ? s : rowbuf;
+}
+
 // ---------------------------------------------------------------------------------------
 // render kernel.  L lanes per voice (1, 2 or 4): the closed-form work of L consecutive
 // frames is spread over the voice's L lanes (each lane does ONE of the L frames), the
@@ -246,7 +260,7 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
 template <int OSC, bool FM, bool FASTDIV, int L>
 __global__ void __launch_bounds__(1024) s2r_render_kernel(const S2rRenderParams p) {
     __shared__ uint64_t sT[S2R_EXP2F_N];
-    __shared__ float sW[2][kMaxWaves][kChunk];
+    __shared__ float sW[2][kMaxWaves][kSuper];
     __shared__ float sSin[OSC == S2R_OSC_SINE ? 1024 : 1];
 
     const uint32_t tid = threadIdx.x;
@@ -284,62 +298,61 @@ __global__ void __launch_bounds__(1024) s2r_render_kernel(const S2rRenderParams 
     __syncthreads();
 
     const bool wave_live = __ballot(live) != 0ull;
-    const uint32_t n_chunks = p.frames / kChunk, tail = p.frames % kChunk;
+    const uint32_t x16_frames = p.frames & ~(uint32_t)(kChunk - 1);      // frames in full 16-chunks
     const size_t pv_base = (size_t)vi * p.frames;
-    const bool pv_write = p.per_voice != nullptr && in_range && sub == 0;
+    const bool pv_lane = in_range && sub == 0;
     float *bp = p.block_partials + (size_t)blockIdx.x * p.frames_stride;
     uint32_t buf = 0;
 
-    for (uint32_t c = 0; c <= n_chunks; ++c) {
-        const uint32_t n_here = c < n_chunks ? kChunk : tail;
-        if (n_here == 0) break;
-        const uint32_t f0 = c * kChunk;
+    // Frames are walked in super-chunks of 64: the wave total of frame i is parked in lane
+    // (i & 63) of `rowbuf` (v_readlane + v_writelane, no exec juggling, no LDS), and once per
+    // super-chunk the 64 totals go to LDS in one coalesced write for the cross-wave combine.
+    for (uint32_t sc0 = 0; sc0 < p.frames; sc0 += kSuper) {
+        const uint32_t n_sc = (p.frames - sc0 < kSuper) ? (p.frames - sc0) : kSuper;
+        const uint32_t n_x16 = (x16_frames > sc0) ? ((x16_frames - sc0 < n_sc) ? (x16_frames - sc0) : n_sc) : 0u;
+        float rowbuf = 0.0f;
         if (wave_live) {
-            if (c < n_chunks) {
-                for (uint32_t g = 0; g < kChunk; g += L) {
-                    // closed-form work of frame f0+g+sub on this lane
-                    FrameCF cf; OscK kf = k_const;
-                    closed_form_x16<OSC, FM, FASTDIV>(p, r, r.offset + f0 + g + sub, sT, cf, kf);
-                    // recurrence for the L frames of the group, every lane of the voice alike
+            for (uint32_t g = 0; g < n_x16; g += L) {
+                // closed-form work of frame sc0+g+sub on this lane
+                FrameCF cf; OscK kf = k_const;
+                closed_form_x16<OSC, FM, FASTDIV>(p, r, r.offset + sc0 + g + sub, sT, cf, kf);
+                // recurrence for the L frames of the group, every lane of the voice alike
 #define S2R_STEP(K)                                                                              \
-                    if constexpr (K < L) {                                                       \
-                        FrameCF c2; OscK k2 = k_const;                                           \
-                        if constexpr (L == 1) { c2 = cf; k2 = kf; }                              \
-                        else {                                                                   \
-                            c2.amp = bcast_sub<L, K>(cf.amp); c2.xc = bcast_sub<L, K>(cf.xc);    \
-                            c2.nz = bcast_sub<L, K>(cf.nz);                                      \
-                            if (FM) {                                                            \
-                                k2.period = bcast_sub<L, K>(kf.period);                          \
-                                k2.inv_period = bcast_sub<L, K>(kf.inv_period);                  \
-                                if (OSC != S2R_OSC_SINE) k2.a = bcast_sub<L, K>(kf.a);           \
-                                if (OSC == S2R_OSC_TRIANGLE) { k2.b = bcast_sub<L, K>(kf.b); k2.c = bcast_sub<L, K>(kf.c); } \
-                            }                                                                    \
+                if constexpr (K < L) {                                                           \
+                    FrameCF c2; OscK k2 = k_const;                                               \
+                    if constexpr (L == 1) { c2 = cf; k2 = kf; }                                  \
+                    else {                                                                       \
+                        c2.amp = bcast_sub<L, K>(cf.amp); c2.xc = bcast_sub<L, K>(cf.xc);        \
+                        c2.nz = bcast_sub<L, K>(cf.nz);                                          \
+                        if (FM) {                                                                \
+                            k2.period = bcast_sub<L, K>(kf.period);                              \
+                            k2.inv_period = bcast_sub<L, K>(kf.inv_period);                      \
+                            if (OSC != S2R_OSC_SINE) k2.a = bcast_sub<L, K>(kf.a);               \
+                            if (OSC == S2R_OSC_TRIANGLE) { k2.b = bcast_sub<L, K>(kf.b); k2.c = bcast_sub<L, K>(kf.c); } \
                         }                                                                        \
-                        float out = recur_x16<OSC>(p, r, c2, k2, sSin);                          \
-                        out = live ? out : 0.0f;                                                 \
-                        if (pv_write) p.per_voice[pv_base + f0 + g + K] = out;                   \
-                        const float tot = wave_sum_lane63<L>(out);                               \
-                        if (lane == 63u) sW[buf][wave][g + K] = tot;                             \
-                    }
-                    S2R_STEP(0) S2R_STEP(1) S2R_STEP(2) S2R_STEP(3)
+                    }                                                                            \
+                    float out = recur_x16<OSC>(p, r, c2, k2, sSin);                              \
+                    out = live ? out : 0.0f;                                                     \
+                    if (p.per_voice) { if (pv_lane) p.per_voice[pv_base + sc0 + g + K] = out; }  \
+                    const float tot = wave_sum_lane63<L>(out);                                   \
+                    rowbuf = park_total(rowbuf, tot, g + K, lane);                               \
+                }
+                S2R_STEP(0) S2R_STEP(1) S2R_STEP(2) S2R_STEP(3)
 #undef S2R_STEP
-                }
-            } else {
-                for (uint32_t i = 0; i < tail; ++i) {
-                    float out = frame_sisd<OSC>(p, r, r.offset + f0 + i, sT, sSin);
-                    out = live ? out : 0.0f;
-                    if (pv_write) p.per_voice[pv_base + f0 + i] = out;
-                    const float tot = wave_sum_lane63<L>(out);
-                    if (lane == 63u) sW[buf][wave][i] = tot;
-                }
             }
-        } else {
-            if (lane < n_here) sW[buf][wave][lane] = 0.0f;
-            if (pv_write)
-                for (uint32_t i = 0; i < n_here; ++i) p.per_voice[pv_base + f0 + i] = 0.0f;
+            for (uint32_t i = n_x16; i < n_sc; ++i) {                    // scalar tail (< 16 frames, last super-chunk)
+                float out = frame_sisd<OSC>(p, r, r.offset + sc0 + i, sT, sSin);
+                out = live ? out : 0.0f;
+                if (p.per_voice) { if (pv_lane) p.per_voice[pv_base + sc0 + i] = out; }
+                const float tot = wave_sum_lane63<L>(out);
+                rowbuf = park_total(rowbuf, tot, i, lane);
+            }
+        } else if (p.per_voice) {
+            if (pv_lane) for (uint32_t i = 0; i < n_sc; ++i) p.per_voice[pv_base + sc0 + i] = 0.0f;
         }
+        sW[buf][wave][lane] = rowbuf;
         __syncthreads();
-        if (tid < n_here) {
+        if (tid < n_sc) {
             // 64-voice sums first (L waves each, pairwise), then those in order: the same tree
             // for every L (oracle/s2_oracle.c: block_partial)
             float acc = 0.0f;
@@ -350,7 +363,7 @@ __global__ void __launch_bounds__(1024) s2r_render_kernel(const S2rRenderParams 
                 else s64 = (sW[buf][w][tid] + sW[buf][w + 1][tid]) + (sW[buf][w + 2][tid] + sW[buf][w + 3][tid]);
                 acc = (w == 0) ? s64 : acc + s64;
             }
-            bp[f0 + tid] = acc;
+            bp[sc0 + tid] = acc;
         }
         buf ^= 1u;
     }

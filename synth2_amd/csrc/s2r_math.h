@@ -46,24 +46,34 @@ S2R_HD double s2r_u2d(uint64_t u) { double d; __builtin_memcpy(&d, &u, 8); retur
 // evaluation of 2^(k/32) * p(r), rounded once to float.  T = S2R_EXP2F_TABLE (host array
 // or LDS copy).
 // ---------------------------------------------------------------------------------------
-S2R_HD float s2r_expf(float x, const uint64_t* T) {
+typedef struct s2r_expf_partial { double r; uint64_t ki; uint64_t t; } s2r_expf_partial;
+
+// first half: argument reduction and the table read (on the GPU an LDS read whose latency the
+// caller hides behind independent work before calling s2r_expf_end)
+S2R_HD s2r_expf_partial s2r_expf_begin(float x, const uint64_t* T) {
     const double xd = (double)x;
     const double InvLn2N = 0x1.71547652b82fep+0 * S2R_EXP2F_N;
     const double Shift = 0x1.8p+52;
-    const double C0 = 0x1.c6af84b912394p-5 / S2R_EXP2F_N / S2R_EXP2F_N / S2R_EXP2F_N;
-    const double C1 = 0x1.ebfce50fac4f3p-3 / S2R_EXP2F_N / S2R_EXP2F_N;
-    const double C2 = 0x1.62e42ff0c52d6p-1 / S2R_EXP2F_N;
-    double z = InvLn2N * xd;
+    const double z = InvLn2N * xd;
     double kd = z + Shift;
-    const uint64_t ki = s2r_d2u(kd);
+    s2r_expf_partial p;
+    p.ki = s2r_d2u(kd);
     kd = kd - Shift;
     // glibc's FMA build contracts `r = z - kd` (z being the product above) into one fma;
     // found by exhaustive comparison with the host expf (2 inputs of 2^32 tell them apart).
-    const double r = __builtin_fma(InvLn2N, xd, -kd);
-    uint64_t t = T[ki % S2R_EXP2F_N];
-    t += ki << (52 - 5);
+    p.r = __builtin_fma(InvLn2N, xd, -kd);
+    p.t = T[p.ki % S2R_EXP2F_N];
+    return p;
+}
+
+S2R_HD float s2r_expf_end(float x, const s2r_expf_partial p) {
+    const double C0 = 0x1.c6af84b912394p-5 / S2R_EXP2F_N / S2R_EXP2F_N / S2R_EXP2F_N;
+    const double C1 = 0x1.ebfce50fac4f3p-3 / S2R_EXP2F_N / S2R_EXP2F_N;
+    const double C2 = 0x1.62e42ff0c52d6p-1 / S2R_EXP2F_N;
+    const double r = p.r;
+    const uint64_t t = p.t + (p.ki << (52 - 5));
     const double s = s2r_u2d(t);
-    z = __builtin_fma(C0, r, C1);
+    const double z = __builtin_fma(C0, r, C1);
     const double r2 = r * r;
     double y = __builtin_fma(C2, r, 1.0);
     y = __builtin_fma(z, r2, y);
@@ -81,6 +91,8 @@ S2R_HD float s2r_expf(float x, const uint64_t* T) {
     }
     return res;
 }
+
+S2R_HD float s2r_expf(float x, const uint64_t* T) { return s2r_expf_end(x, s2r_expf_begin(x, T)); }
 
 // ---------------------------------------------------------------------------------------
 // glibc powf(2.0f, y) (sysdeps/ieee754/flt-32/e_powf.c, FMA variant).  For x == 2 the

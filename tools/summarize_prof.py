@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Summarise a tools/profile_gpu.sh output directory: per-kernel average duration from the
+kernel trace and per-dispatch averages of every PMC counter, as one small text/JSON file
+suitable for committing under profiles/.
+
+usage: tools/summarize_prof.py gpurun_out/prof_<tag> [kernel-substring] > profiles/rNN/<tag>.json
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def main():
+    root = sys.argv[1]
+    want = sys.argv[2] if len(sys.argv) > 2 else "s2r_render_kernel"
+    out = {"source": root, "kernel_filter": want}
+    for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
+        rows = list(csv.DictReader(open(f)))
+        out["kernel_stats"] = [{"name": r["Name"][:120], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+                                "pct": float(r["Percentage"])} for r in rows[:8]]
+    for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
+        rows = [r for r in csv.DictReader(open(f)) if want in r["Kernel_Name"]]
+        if rows:
+            r = rows[-1]
+            out["dispatch"] = {k: r[k] for k in ("Kernel_Name", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count",
+                                                  "SGPR_Count", "Workgroup_Size_X", "Grid_Size_X") if k in r}
+            d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+            out["dispatch"]["avg_ns"] = sum(d) / len(d)
+            out["dispatch"]["n"] = len(d)
+    counters = defaultdict(list)
+    for sub in ("pmc1", "pmc2", "pmc_fetch", "pmc_write"):
+        for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if want in r.get("Kernel_Name", ""):
+                    counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out["pmc_avg_per_dispatch"] = {k: sum(v) / len(v) for k, v in sorted(counters.items())}
+    out["pmc_dispatches"] = {k: len(v) for k, v in sorted(counters.items())}
+    json.dump(out, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main()
