@@ -21,6 +21,103 @@ __constant__ uint64_t c_exp2f_table[S2R_EXP2F_N] = S2R_EXP2F_TABLE_INIT;
 constexpr int kMaxWaves = 16;      // 1024-thread workgroup
 constexpr int kChunk = 16;         // the reference's x16 chunk (synth.rs:158, process.rs:25)
 constexpr uint32_t kSuper = 64;    // frames between two cross-wave combines (one lane of the row buffer each)
+constexpr int kP = 4;              // frames whose closed-form work one lane carries at once (ILP)
+
+// The closed-form part of kP = 4 consecutive frames is evaluated together on 4-wide vectors.
+// Measured on MI355X (tools/ubench/issue_rates.hip): a SIMD retires one DEPENDENT VALU op per
+// ~4.4 cycles however many waves it holds, but ~2.2-2.8 cycles per op once each wave offers two
+// to four independent instructions — so the parallelism has to come from inside the wave.
+// Element-wise vector code is exactly that (and the add/mul/fma halves become v_pk_*_f32).
+// Each lane of every vector op is the same IEEE operation as the scalar code in s2r_math.h.
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef int i4 __attribute__((ext_vector_type(4)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long ul4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f4 vfma(f4 a, f4 b, f4 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ d4 vfma(d4 a, d4 b, d4 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f4 splat(float x) { return (f4)(x); }
+
+// s2r_pow2_sleef_core (s2r_math.h) on four lanes
+__device__ __forceinline__ f4 pow2_sleef_core4(f4 y) {
+    const f4 Lh = splat(0.69314718246459960938f), Ll = splat(-1.904654323148236017e-09f);
+    const f4 dx = Lh * y;
+    const f4 dy = vfma(Ll, y, vfma(Lh, y, -dx));
+    const f4 R_LN2f = splat(1.442695040888963407359924681001892137426645954152985934135449406931f);
+    const f4 L2Uf = splat(0.693145751953125f), L2Lf = splat(1.428606765330187045e-06f);
+    f4 u = (dx + dy) * R_LN2f;
+    const f4 qf = __builtin_elementwise_rint(u);
+    const i4 q = __builtin_convertvector(qf, i4);
+    f4 a = qf * -L2Uf;
+    f4 sx = dx + a, v = sx - dx;
+    f4 sy = ((dx - (sx - v)) + (a - v)) + dy;
+    a = qf * -L2Lf;
+    f4 tx = sx + a; v = tx - sx;
+    f4 ty = ((sx - (tx - v)) + (a - v)) + sy;
+    sx = tx + ty; sy = (tx - sx) + ty;
+    u = splat(0.00136324646882712841033936f);
+    u = vfma(u, sx, splat(0.00836596917361021041870117f));
+    u = vfma(u, sx, splat(0.0416710823774337768554688f));
+    u = vfma(u, sx, splat(0.166665524244308471679688f));
+    u = vfma(u, sx, splat(0.499999850988388061523438f));
+    const f4 wx = sx * sx;
+    const f4 wy = vfma(sx + sx, sy, vfma(sx, sx, -wx));
+    const f4 mx = wx * u;
+    const f4 my = vfma(wy, u, vfma(wx, u, -mx));
+    tx = sx + mx; v = tx - sx;
+    ty = ((sx - (tx - v)) + (mx - v)) + (sy + my);
+    const f4 ox = splat(1.0f) + tx;
+    const f4 oy = ((splat(1.0f) - ox) + tx) + ty;
+    u = ox + oy;
+    const i4 q1 = q >> 1, q2 = q - q1;
+    u = u * (f4)((u4)(q1 + 127) << 23) * (f4)((u4)(q2 + 127) << 23);
+    u = (dx < splat(-104.0f)) ? splat(0.0f) : u;
+    return (y == splat(0.0f)) ? splat(1.0f) : u;
+}
+
+// s2r_div_const_nocheck on four lanes
+__device__ __forceinline__ f4 div_const_nocheck4(f4 x, float c, float rc) {
+    const f4 q0 = x * splat(rc);
+    const f4 e = vfma(-q0, splat(c), x);
+    return vfma(e, splat(rc), q0);
+}
+
+// s2r_expf on four lanes: the four LDS table reads are independent and issued together
+__device__ __forceinline__ f4 expf4(f4 x, const uint64_t *T) {
+    const d4 xd = __builtin_convertvector(x, d4);
+    const d4 InvLn2N = (d4)(0x1.71547652b82fep+0 * S2R_EXP2F_N);
+    const d4 Shift = (d4)(0x1.8p+52);
+    const d4 C0 = (d4)(0x1.c6af84b912394p-5 / S2R_EXP2F_N / S2R_EXP2F_N / S2R_EXP2F_N);
+    const d4 C1 = (d4)(0x1.ebfce50fac4f3p-3 / S2R_EXP2F_N / S2R_EXP2F_N);
+    const d4 C2 = (d4)(0x1.62e42ff0c52d6p-1 / S2R_EXP2F_N);
+    const d4 z0 = InvLn2N * xd;
+    d4 kd = z0 + Shift;
+    const ul4 ki = (ul4)kd;
+    kd = kd - Shift;
+    const d4 r = vfma(InvLn2N, xd, -kd);
+    ul4 t;
+    t.x = T[ki.x % S2R_EXP2F_N]; t.y = T[ki.y % S2R_EXP2F_N];
+    t.z = T[ki.z % S2R_EXP2F_N]; t.w = T[ki.w % S2R_EXP2F_N];
+    t += ki << (52 - 5);
+    const d4 s = (d4)t;
+    const d4 z = vfma(C0, r, C1);
+    const d4 r2 = r * r;
+    d4 y = vfma(C2, r, (d4)(1.0));
+    y = vfma(z, r2, y);
+    y = y * s;
+    f4 res = __builtin_convertvector(y, f4);
+    // |x| >= 88 or NaN in any lane: redo those lanes with the scalar routine (rare)
+    const u4 abstop = (((u4)x) >> 20) & 0x7ffu;
+    const i4 special = abstop >= 0x42bu;
+    if (__builtin_expect((special.x | special.y | special.z | special.w) != 0, 0)) {
+        if (special.x) res.x = s2r_expf(x.x, T);
+        if (special.y) res.y = s2r_expf(x.y, T);
+        if (special.z) res.z = s2r_expf(x.z, T);
+        if (special.w) res.w = s2r_expf(x.w, T);
+    }
+    return res;
+}
 
 // ---------------------------------------------------------------------------------------
 // wave64 sum by DPP.  After the six steps lane 63 holds
@@ -47,19 +144,42 @@ struct VoiceRegs {
     float ro_a, end_a, ro_m, end_m;
 };
 
-// old/simdtest.rs:270-331 AdsrX16::sample for one frame.  `ro`/`end` are the per-voice
-// release_offset.max(sustain_offset) and + release.  Lines are mul then add, separately
-// rounded (simdtest.rs:247-261).
-__device__ __forceinline__ float adsr_x16(const S2rEnv &e, float ro, float end, float t) {
-    const float att = e.slope_att * t + 0.0f;
-    const float dec = e.slope_dec * (t - e.A) + 1.0f;
-    const float rel = e.slope_rel * (t - ro) + e.S;
-    float v = 0.0f;                  // in_end
-    v = (t < end) ? rel : v;         // in_release
-    v = (t < ro) ? e.S : v;          // in_sustain
-    v = (t < e.sus_off) ? dec : v;   // in_decay
-    v = (t < e.A) ? att : v;         // in_attack
-    return v;
+// The x16 ADSR (old/simdtest.rs:270-331) is a cascade of four `t < threshold` tests selecting one
+// of five expressions.  Within a fill t only grows, so a voice's stage only ever moves forward
+// (at most four times in its life): keep the ACTIVE stage's line  slope * (t - base) + y0  and
+// its end threshold in registers and re-run the cascade only when t reaches that threshold.
+// The value produced is the reference's selected expression, operation for operation.
+struct EnvRun {
+    float slope, base, y0, thr;
+    int stage;                  // 0 attack, 1 decay, 2 sustain, 3 release, 4 end
+};
+
+// registers of stage `stage` (branch-free selects so the struct stays in registers)
+__device__ __forceinline__ EnvRun env_make(int stage, const S2rEnv &e, float ro, float end) {
+    EnvRun s;
+    s.stage = stage;
+    s.slope = stage == 0 ? e.slope_att : stage == 1 ? e.slope_dec : stage == 3 ? e.slope_rel : 0.0f;
+    s.base  = stage == 1 ? e.A : stage == 3 ? ro : 0.0f;
+    s.y0    = stage == 1 ? 1.0f : (stage == 2 || stage == 3) ? e.S : 0.0f;
+    s.thr   = stage == 0 ? e.A : stage == 1 ? e.sus_off : stage == 2 ? ro : stage == 3 ? end : __builtin_inff();
+    //  0: (1/A) * t + 0        1: ((S-1)/D) * (t-A) + 1     2: S  (0*t + S == S)
+    //  3: (-S/R) * (t-ro) + S  4: 0
+    return s;
+}
+
+// the cascade: leave every stage whose `t < threshold` test fails (simdtest.rs:288-292)
+__device__ __forceinline__ EnvRun env_advance(EnvRun s, const S2rEnv &e, float ro, float end, float t) {
+    int stage = s.stage;
+    float thr = s.thr;
+    while (stage < 4 && !(t < thr)) {
+        stage++;
+        thr = stage == 1 ? e.sus_off : stage == 2 ? ro : stage == 3 ? end : __builtin_inff();
+    }
+    return env_make(stage, e, ro, end);
+}
+
+__device__ __forceinline__ float env_value(const EnvRun &s, float t) {
+    return s.slope * (t - s.base) + s.y0;       // mul then add, separately rounded (simdtest.rs:247-261)
 }
 
 // math.rs:11-19 with feature fma: slope = rise / run; slope.mul_add(x, y0)
@@ -160,30 +280,75 @@ __device__ __forceinline__ float lpf_apply(float x, float in, float &last) {
 
 // The part of a frame that is closed-form in the frame offset (no recurrence): envelopes,
 // filter coefficient, noise (+ the oscillator constants under FM).  process.rs:137-174 and
-// the noise/LPF-coefficient halves of process.rs:306-379.
+// the noise/LPF-coefficient halves of process.rs:306-379.  One scalar frame:
 struct FrameCF {
     float amp;       // amp envelope                         process.rs:144
     float xc;        // exp(-2 pi f_lpf / sr)                filters.rs:21
     float nz;        // noise(offset) + noise level          process.rs:347-356 (ADD)
 };
+// ... and kP = 4 consecutive frames at once:
+struct FrameCF4 { f4 amp, xc, nz; };
+struct OscK4 { f4 period, inv_period, a, b, c; };
 
+template <int OSC>
+__device__ __forceinline__ OscK4 make_osck4(f4 period) {
+    OscK4 k;
+    k.period = period;
+    k.inv_period = splat(1.0f) / period;                         // oscillators.rs:378
+    k.a = k.b = k.c = splat(0.0f);
+    if (OSC == S2R_OSC_SAW) k.a = splat(-2.0f) / period;         // oscillators.rs:107-112
+    if (OSC == S2R_OSC_SQUARE) k.a = period / splat(2.0f);       // :68-69
+    if (OSC == S2R_OSC_TRIANGLE) { k.a = period / splat(2.0f); k.b = splat(-2.0f) / k.a; k.c = splat(2.0f) / k.a; }
+    return k;
+}
+
+// hashnoise.rs:33-51 on four offsets
+__device__ __forceinline__ f4 hash_noise4(uint32_t seed_rot, f4 t) {
+    u4 off;
+    off.x = s2r_f32_as_u32(t.x); off.y = s2r_f32_as_u32(t.y); off.z = s2r_f32_as_u32(t.z); off.w = s2r_f32_as_u32(t.w);
+    const u4 h = (off ^ seed_rot) * 0x9e3779b9u;
+    const f4 value = __builtin_convertvector(h & 0xffffu, f4);
+    const f4 q = div_const_nocheck4(value, 65535.0f, 0x1.0001p-16f);
+    return vfma(q, splat(2.0f), splat(-1.0f));
+}
+
+// frames oi .. oi+3 of one voice
 template <int OSC, bool FM, bool FASTDIV>
-__device__ __forceinline__ void closed_form_x16(const S2rRenderParams &p, const VoiceRegs &r, uint32_t oi,
-                                                const uint64_t *sT, FrameCF &cf, OscK &k) {
-    const float t = (float)oi;                                   // offsets as f32 (simdtest.rs:277-279, process.rs:348)
-    const float mod = adsr_x16(p.mod, r.ro_m, r.end_m, t);       // process.rs:145
-    const float f_lpf = s2r_pow2_sleef_core(mod * p.amt_lpf) * p.lpf_freq;    // process.rs:148-152
-    // exp(-2 pi f / sr): reduce the argument and issue the LDS table read now, finish after the
-    // independent envelope / noise / FM work so the read's latency is covered
-    const float arg = lpf_arg<FASTDIV>(p, f_lpf);
-    const s2r_expf_partial ep = s2r_expf_begin(arg, sT);
-    cf.amp = adsr_x16(p.amp, r.ro_a, r.end_a, t);                // process.rs:144
-    cf.nz = hash_noise(r.seed_rot, t) + p.noise_level;
-    if (FM) {
-        const float f_osc = s2r_pow2_sleef_core(mod * p.amt_osc) * r.pitch;   // process.rs:146-147,231-250
-        k = make_osck<OSC>(p.sr / f_osc);                        // units.rs:32-42
+__device__ __forceinline__ void closed_form_x4(const S2rRenderParams &p, const VoiceRegs &r, EnvRun &ea, EnvRun &em,
+                                               float &thr_min, uint32_t oi, const uint64_t *sT,
+                                               FrameCF4 &cf, OscK4 &k) {
+    const u4 ou = (u4)(oi) + (u4){0u, 1u, 2u, 3u};               // offsets_x16: wrapping u32 add (process.rs:213-219)
+    const f4 t = __builtin_convertvector(ou, f4);                // offsets as f32 (simdtest.rs:277-279, process.rs:348)
+    f4 amp, mod;
+    if (__builtin_expect(!(t.w < thr_min), 0)) {
+        // an envelope stage ends inside these four frames: walk them one by one
+#define S2R_ENV_STEP(C)                                                                   \
+        {                                                                                 \
+            const float tj = t.C;                                                         \
+            if (!(tj < thr_min)) {                                                        \
+                ea = env_advance(ea, p.amp, r.ro_a, r.end_a, tj);                         \
+                em = env_advance(em, p.mod, r.ro_m, r.end_m, tj);                         \
+                thr_min = __builtin_fminf(ea.thr, em.thr);                                \
+            }                                                                             \
+            amp.C = env_value(ea, tj);                                                    \
+            mod.C = env_value(em, tj);                                                    \
+        }
+        S2R_ENV_STEP(x) S2R_ENV_STEP(y) S2R_ENV_STEP(z) S2R_ENV_STEP(w)
+#undef S2R_ENV_STEP
+    } else {
+        amp = splat(ea.slope) * (t - splat(ea.base)) + splat(ea.y0);          // process.rs:144
+        mod = splat(em.slope) * (t - splat(em.base)) + splat(em.y0);          // process.rs:145
     }
-    cf.xc = s2r_expf_end(arg, ep);
+    cf.amp = amp;
+    const f4 f_lpf = pow2_sleef_core4(mod * splat(p.amt_lpf)) * splat(p.lpf_freq);   // process.rs:148-152
+    const f4 num = splat(-2.0f * 3.14159274101257324f) * f_lpf;  // -2.0 * pi * freq   (filters.rs:21)
+    const f4 arg = FASTDIV ? div_const_nocheck4(num, p.sr, p.rcp_sr) : (num / splat(p.sr));
+    cf.xc = expf4(arg, sT);
+    cf.nz = hash_noise4(r.seed_rot, t) + splat(p.noise_level);   // process.rs:347-356 (ADD)
+    if (FM) {
+        const f4 f_osc = pow2_sleef_core4(mod * splat(p.amt_osc)) * splat(r.pitch);  // process.rs:146-147,231-250
+        k = make_osck4<OSC>(splat(p.sr) / f_osc);                // units.rs:32-42
+    }
 }
 
 // The recurrence step of a frame: phase accumulation, oscillator, LPF, gain.
@@ -228,6 +393,12 @@ __device__ __forceinline__ float bcast_sub(float v) {
     constexpr int ctrl = (L == 4) ? (K * 0x55) : ((K) | (K << 2) | ((2 + K) << 4) | ((2 + K) << 6));
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false));
 }
+template <int L, int K>
+__device__ __forceinline__ f4 bcast_sub4(f4 v) {
+    f4 r;
+    r.x = bcast_sub<L, K>(v.x); r.y = bcast_sub<L, K>(v.y); r.z = bcast_sub<L, K>(v.z); r.w = bcast_sub<L, K>(v.w);
+    return r;
+}
 
 // wave64 sum where every voice's value is replicated over L consecutive lanes: the first
 // log2(L) butterfly steps are skipped, leaving the balanced tree over the wave's 64/L voices.
@@ -241,6 +412,24 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
     v = v + dpp_mov<0x143, 0xc>(v);               // row_bcast31 -> rows 2,3 : total in lane 63
     return v;
 }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ f4 dpp_mov4(f4 v) {
+    f4 r;
+    r.x = dpp_mov<CTRL, ROW_MASK>(v.x); r.y = dpp_mov<CTRL, ROW_MASK>(v.y);
+    r.z = dpp_mov<CTRL, ROW_MASK>(v.z); r.w = dpp_mov<CTRL, ROW_MASK>(v.w);
+    return r;
+}
+// four frames' reductions side by side (four independent dependency chains)
+template <int L>
+__device__ __forceinline__ f4 wave_sum_lane63_x4(f4 v) {
+    if (L == 1) v = v + dpp_mov4<0xB1, 0xf>(v);
+    if (L <= 2) v = v + dpp_mov4<0x4E, 0xf>(v);
+    v = v + dpp_mov4<0x141, 0xf>(v);
+    v = v + dpp_mov4<0x140, 0xf>(v);
+    v = v + dpp_mov4<0x142, 0xa>(v);
+    v = v + dpp_mov4<0x143, 0xc>(v);
+    return v;
+}
 
 // lane 63's wave total of frame `i` goes to lane (i & 63) of the row buffer
 __device__ __forceinline__ float park_total(float rowbuf, float tot, uint32_t i, uint32_t lane) {
@@ -249,12 +438,14 @@ __device__ __forceinline__ float park_total(float rowbuf, float tot, uint32_t i,
 }
 
 // ---------------------------------------------------------------------------------------
-// render kernel.  L lanes per voice (1, 2 or 4): the closed-form work of L consecutive
-// frames is spread over the voice's L lanes (each lane does ONE of the L frames), the
-// results are exchanged with quad_perm DPP moves and every lane then runs the short
-// recurrence for all L frames redundantly.  This multiplies the number of waves by L for
-// the same voice count (64k voices are only one wave per SIMD at L = 1) at the price of
-// L x the recurrence work, which is ~10% of a frame.
+// render kernel.
+//   * one voice per lane-group of L lanes (L = 1, 2 or 4);
+//   * the x16 path walks the fill in groups of 4*L frames: each lane evaluates the closed-form
+//     part of FOUR consecutive frames on 4-wide vectors (ILP), the L lanes of a voice take
+//     consecutive quadruples, exchange results with quad_perm DPP moves, and every lane then
+//     runs the short recurrence (phase, oscillator, LPF) for all 4*L frames;
+//   * L > 1 multiplies the number of waves for the same voice count (64k voices are only one
+//     wave per SIMD at L = 1) at the price of L x the recurrence work (~10% of a frame).
 //   grid = ceil(n_voices / block_voices), blockDim.x = block_voices * L.
 // ---------------------------------------------------------------------------------------
 template <int OSC, bool FM, bool FASTDIV, int L>
@@ -265,7 +456,7 @@ __global__ void __launch_bounds__(1024) s2r_render_kernel(const S2rRenderParams 
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6, n_waves = blockDim.x >> 6;
-    const uint32_t sub = tid & (L - 1);                          // which of the L frames this lane prepares
+    const uint32_t sub = tid & (L - 1);                          // which quadruple of the group this lane prepares
     const uint32_t block_voices = blockDim.x / L;
     const uint32_t vi = blockIdx.x * block_voices + tid / L;
 
@@ -293,7 +484,12 @@ __global__ void __launch_bounds__(1024) s2r_render_kernel(const S2rRenderParams 
 
     // mod_env_to_osc_freq == 0: pow(2, mod*0) == 1 exactly, so freq == 1.0 * pitch and the
     // period (and everything derived from it by correctly rounded divisions) is constant.
-    OscK k_const = make_osck<OSC>(p.sr / (1.0f * r.pitch));
+    const OscK k_const = make_osck<OSC>(p.sr / (1.0f * r.pitch));
+
+    // envelope stage registers; a threshold of -inf forces the cascade on this lane's first frame
+    EnvRun ea = env_make(0, p.amp, r.ro_a, r.end_a);
+    EnvRun em = env_make(0, p.mod, r.ro_m, r.end_m);
+    float thr_min = -__builtin_inff();
 
     __syncthreads();
 
@@ -303,42 +499,56 @@ __global__ void __launch_bounds__(1024) s2r_render_kernel(const S2rRenderParams 
     const bool pv_lane = in_range && sub == 0;
     float *bp = p.block_partials + (size_t)blockIdx.x * p.frames_stride;
     uint32_t buf = 0;
+    constexpr uint32_t G = kP * L;                                       // frames per group
 
     // Frames are walked in super-chunks of 64: the wave total of frame i is parked in lane
-    // (i & 63) of `rowbuf` (v_readlane + v_writelane, no exec juggling, no LDS), and once per
+    // (i & 63) of `rowbuf` (v_readlane + select, no exec juggling, no LDS), and once per
     // super-chunk the 64 totals go to LDS in one coalesced write for the cross-wave combine.
     for (uint32_t sc0 = 0; sc0 < p.frames; sc0 += kSuper) {
         const uint32_t n_sc = (p.frames - sc0 < kSuper) ? (p.frames - sc0) : kSuper;
         const uint32_t n_x16 = (x16_frames > sc0) ? ((x16_frames - sc0 < n_sc) ? (x16_frames - sc0) : n_sc) : 0u;
         float rowbuf = 0.0f;
         if (wave_live) {
-            for (uint32_t g = 0; g < n_x16; g += L) {
-                // closed-form work of frame sc0+g+sub on this lane
-                FrameCF cf; OscK kf = k_const;
-                closed_form_x16<OSC, FM, FASTDIV>(p, r, r.offset + sc0 + g + sub, sT, cf, kf);
-                // recurrence for the L frames of the group, every lane of the voice alike
-#define S2R_STEP(K)                                                                              \
-                if constexpr (K < L) {                                                           \
-                    FrameCF c2; OscK k2 = k_const;                                               \
-                    if constexpr (L == 1) { c2 = cf; k2 = kf; }                                  \
+            for (uint32_t g = 0; g < n_x16; g += G) {
+                // closed-form work of frames sc0+g+4*sub .. +3 on this lane
+                FrameCF4 cf; OscK4 kf;
+                closed_form_x4<OSC, FM, FASTDIV>(p, r, ea, em, thr_min, r.offset + sc0 + g + kP * sub, sT, cf, kf);
+                // recurrence for the 4*L frames of the group, every lane of the voice alike
+#define S2R_QUAD(Q)                                                                              \
+                if constexpr (Q < L) {                                                           \
+                    FrameCF4 c4; OscK4 k4;                                                       \
+                    if constexpr (L == 1) { c4 = cf; if (FM) k4 = kf; }                          \
                     else {                                                                       \
-                        c2.amp = bcast_sub<L, K>(cf.amp); c2.xc = bcast_sub<L, K>(cf.xc);        \
-                        c2.nz = bcast_sub<L, K>(cf.nz);                                          \
+                        c4.amp = bcast_sub4<L, Q>(cf.amp); c4.xc = bcast_sub4<L, Q>(cf.xc);      \
+                        c4.nz = bcast_sub4<L, Q>(cf.nz);                                         \
                         if (FM) {                                                                \
-                            k2.period = bcast_sub<L, K>(kf.period);                              \
-                            k2.inv_period = bcast_sub<L, K>(kf.inv_period);                      \
-                            if (OSC != S2R_OSC_SINE) k2.a = bcast_sub<L, K>(kf.a);               \
-                            if (OSC == S2R_OSC_TRIANGLE) { k2.b = bcast_sub<L, K>(kf.b); k2.c = bcast_sub<L, K>(kf.c); } \
+                            k4.period = bcast_sub4<L, Q>(kf.period);                             \
+                            k4.inv_period = bcast_sub4<L, Q>(kf.inv_period);                     \
+                            if (OSC != S2R_OSC_SINE) k4.a = bcast_sub4<L, Q>(kf.a);              \
+                            if (OSC == S2R_OSC_TRIANGLE) { k4.b = bcast_sub4<L, Q>(kf.b); k4.c = bcast_sub4<L, Q>(kf.c); } \
                         }                                                                        \
                     }                                                                            \
-                    float out = recur_x16<OSC>(p, r, c2, k2, sSin);                              \
-                    out = live ? out : 0.0f;                                                     \
-                    if (p.per_voice) { if (pv_lane) p.per_voice[pv_base + sc0 + g + K] = out; }  \
-                    const float tot = wave_sum_lane63<L>(out);                                   \
-                    rowbuf = park_total(rowbuf, tot, g + K, lane);                               \
+                    f4 out4;                                                                     \
+                    _Pragma("unroll")                                                            \
+                    for (int j = 0; j < kP; ++j) {                                               \
+                        FrameCF c1; c1.amp = c4.amp[j]; c1.xc = c4.xc[j]; c1.nz = c4.nz[j];      \
+                        OscK k1 = k_const;                                                       \
+                        if (FM) { k1.period = k4.period[j]; k1.inv_period = k4.inv_period[j];    \
+                                  k1.a = k4.a[j]; k1.b = k4.b[j]; k1.c = k4.c[j]; }              \
+                        const float o = recur_x16<OSC>(p, r, c1, k1, sSin);                      \
+                        out4[j] = live ? o : 0.0f;                                               \
+                    }                                                                            \
+                    if (p.per_voice) { if (pv_lane) {                                            \
+                        float *dst = p.per_voice + pv_base + sc0 + g + kP * Q;                   \
+                        dst[0] = out4.x; dst[1] = out4.y; dst[2] = out4.z; dst[3] = out4.w; } }  \
+                    const f4 tot4 = wave_sum_lane63_x4<L>(out4);                                 \
+                    rowbuf = park_total(rowbuf, tot4.x, g + kP * Q + 0, lane);                   \
+                    rowbuf = park_total(rowbuf, tot4.y, g + kP * Q + 1, lane);                   \
+                    rowbuf = park_total(rowbuf, tot4.z, g + kP * Q + 2, lane);                   \
+                    rowbuf = park_total(rowbuf, tot4.w, g + kP * Q + 3, lane);                   \
                 }
-                S2R_STEP(0) S2R_STEP(1) S2R_STEP(2) S2R_STEP(3)
-#undef S2R_STEP
+                S2R_QUAD(0) S2R_QUAD(1) S2R_QUAD(2) S2R_QUAD(3)
+#undef S2R_QUAD
             }
             for (uint32_t i = n_x16; i < n_sc; ++i) {                    // scalar tail (< 16 frames, last super-chunk)
                 float out = frame_sisd<OSC>(p, r, r.offset + sc0 + i, sT, sSin);
