@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--churn", type=int, default=128, help="note-ons (and note-offs) per step per 65536 voices")
     ap.add_argument("--block-voices", type=int, default=0)
     ap.add_argument("--lanes", type=int, default=0, help="GPU lanes per voice (1/2/4, 0 = auto)")
+    ap.add_argument("--no-overlap", action="store_true", help="do not overlap the all-gather with the next render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-voices", type=int, default=4096)
     ap.add_argument("--cpu-buffers", type=int, default=0, help="0 = sized for ~15 s")
@@ -115,38 +116,33 @@ def main():
 
     vpg = args.voices_per_gpu
     total = vpg * world
-    synth = s2.Synth(total, max_frames=FRAMES, device=local_rank, shard_begin=rank * vpg, shard_voices=vpg,
-                     block_voices=args.block_voices, lanes_per_voice=args.lanes)
-    synth.load_patch("synth mySynth {\n\n}\n")       # example.synth2: empty body == default patch
+    from synth2_amd.sharded import ShardedSynth
+    sh = ShardedSynth(vpg, max_frames=FRAMES, rank=rank, world=world, device=dev,
+                      block_voices=args.block_voices, lanes_per_voice=args.lanes, overlap=not args.no_overlap)
+    synth = sh.renderer
+    sh.load_patch("synth mySynth {\n\n}\n")       # example.synth2: empty body == default patch
 
     # initial population: every voice of the pool gets a note (all ranks see the same stream)
     init = np.zeros(total, dtype=s2.NOTE_EVENT_DTYPE)
     init["kind"] = 1
     init["note"] = 36 + (np.arange(total) % 61)
     init["velocity"] = 1.0
-    synth.note_events(init)
+    sh.note_events(init)
 
     n_steps = args.warmup + args.steps
     events = [make_events(total, args.churn, k) for k in range(n_steps)]
 
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
-    partial = [torch.zeros(FRAMES, dtype=torch.float32, device=dev) for _ in range(2)]
-    gathered = [torch.zeros((world, FRAMES), dtype=torch.float32, device=dev) for _ in range(2)]
-    mix = torch.zeros(FRAMES, dtype=torch.float32, device=dev)
+    partial = sh.partial
+    mix = sh.mix
 
     def step(k):
-        b = k & 1
-        synth.note_events(events[k])
-        synth.fill_device(partial[b].data_ptr(), FRAMES, SR, sptr)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered[b], partial[b])
-            if rank == 0:
-                s2.sum_partials_device(gathered[b].data_ptr(), world, FRAMES, mix.data_ptr(), sptr)
-        else:
-            s2.sum_partials_device(partial[b].data_ptr(), 1, FRAMES, mix.data_ptr(), sptr)
+        sh.note_events(events[k])
+        sh.fill(FRAMES, SR)
 
     def fence():
+        sh.flush()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -155,18 +151,11 @@ def main():
         step(k)
     fence()
     # ---- timed region: exactly K steps ----
-    synth.set_timing(True)
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record(stream)
     for k in range(args.warmup, n_steps):
         step(k)
-    ev1.record(stream)
     fence()
     dt = time.perf_counter() - t0
-    render_ms_last = synth.last_render_ms()
-    synth.set_timing(False)
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:

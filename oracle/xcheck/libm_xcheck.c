@@ -10,6 +10,9 @@
  *
  * usage: libm_xcheck expf|powf2|sleef2 <lo> <hi>     (every float in [lo,hi])
  *        libm_xcheck expf all | powf2 all            (every one of the 2^32 bit patterns)
+ *        libm_xcheck div <c> <stride>                s2r_div_const(x, c) vs x / c for every
+ *                                                    stride-th float with 2^-60 < |x| < 2^60
+ *        libm_xcheck div65535                        all integers 0..65535 (the noise quotient)
  */
 #include <math.h>
 #include <stdint.h>
@@ -37,7 +40,38 @@ static inline void one(uint32_t u) {
     }
 }
 
+static int div_mode(float c, uint32_t stride) {
+    const float rc = 1.0f / c;
+    uint64_t n = 0, bad = 0;
+    for (int sign = 0; sign < 2; sign++)
+        for (uint32_t u = s2r_f2u(0x1p-60f) + 1; u < s2r_f2u(0x1p60f); u += stride) {
+            float x = s2r_u2f(u | (sign ? 0x80000000u : 0u));
+            float a = s2r_div_const_nocheck(x, c, rc), b = x / c, g = s2r_div_const(x, c, rc);
+            n++;
+            if (s2r_f2u(a) != s2r_f2u(b) || s2r_f2u(g) != s2r_f2u(b)) { bad++; if (shown < 10) { shown++; fprintf(stderr, "MISMATCH %a / %a: %a vs %a\n", x, c, a, b); } }
+        }
+    /* the guarded form must also be right outside the window */
+    const float edge[] = {0.0f, -0.0f, 0x1p-149f, -0x1p-140f, 0x1p-126f, 0x1p-61f, 0x1p61f, 0x1.fffffep127f, -0x1.fffffep127f, INFINITY, -INFINITY, NAN};
+    for (unsigned i = 0; i < sizeof edge / sizeof *edge; i++) {
+        float g = s2r_div_const(edge[i], c, rc), b = edge[i] / c;
+        n++;
+        if (!(g != g && b != b) && s2r_f2u(g) != s2r_f2u(b)) { bad++; fprintf(stderr, "EDGE MISMATCH %a / %a: %a vs %a\n", edge[i], c, g, b); }
+    }
+    printf("checked=%llu mismatches=%llu\n", (unsigned long long)n, (unsigned long long)bad);
+    return bad ? 1 : 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc >= 2 && !strcmp(argv[1], "div65535")) {
+        uint64_t bad = 0;
+        for (uint32_t v = 0; v <= 65535; v++) {
+            float a = s2r_div_const_nocheck((float)v, 65535.0f, 0x1.0001p-16f), b = (float)v / 65535.0f;
+            if (s2r_f2u(a) != s2r_f2u(b)) bad++;
+        }
+        printf("checked=65536 mismatches=%llu\n", (unsigned long long)bad);
+        return bad ? 1 : 0;
+    }
+    if (argc >= 4 && !strcmp(argv[1], "div")) return div_mode(strtof(argv[2], 0), (uint32_t)strtoul(argv[3], 0, 10));
     if (argc < 3) return 2;
     mode = !strcmp(argv[1], "expf") ? 0 : !strcmp(argv[1], "powf2") ? 1 : 2;
     if (!strcmp(argv[2], "all")) {

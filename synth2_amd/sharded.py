@@ -1,0 +1,104 @@
+"""Voice-pool sharding over the GPUs of one node: one process per GPU, torch.distributed for the
+single small exchange per buffer.
+
+Voices never interact before the mix (the reference adds each voice's 16-frame buffer into an
+accumulator, synth.rs:177-195), so the pool is cut into contiguous ranges, one per rank.  Every
+rank sees the SAME note-event stream and runs the same voice-allocation policy over the whole
+pool (host-side, cheap); only events that land in its own range reach its GPU.  Per buffer each
+rank renders a partial mix (frames x 4 B = 4 KiB at 1024 frames), the partials are all-gathered
+(RCCL over xGMI; latency-bound, not bandwidth-bound) and rank 0 adds them in RANK ORDER, rooted
+at +0.0 — the same association a single GPU produces with ``mix_groups = world``.
+
+The renderer and the row-combine are injectable so the exchange logic can be exercised on CPU
+with gloo (tests/test_sharded_gloo.py feeds it partial rows made by the CPU oracle); the
+defaults are the HIP path and nothing else — there is no CPU fallback here.
+"""
+import torch
+import torch.distributed as dist
+
+from . import synth as _synth
+
+
+class ShardedSynth:
+    def __init__(self, voices_per_rank, max_frames=1024, rank=0, world=1, device=None, renderer=None,
+                 combine=None, block_voices=0, lanes_per_voice=0, overlap=True):
+        self.rank, self.world = rank, world
+        self.voices_per_rank = voices_per_rank
+        self.total_voices = voices_per_rank * world
+        self.max_frames = max_frames
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if renderer is None:
+            renderer = _synth.Synth(self.total_voices, max_frames=max_frames,
+                                    device=self.device.index if self.device.index is not None else -1,
+                                    shard_begin=rank * voices_per_rank, shard_voices=voices_per_rank,
+                                    block_voices=block_voices, lanes_per_voice=lanes_per_voice)
+        self.renderer = renderer
+        self.combine = combine if combine is not None else self._combine_hip
+        self.overlap = overlap and world > 1
+        self.partial = [torch.zeros(max_frames, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.gathered = [torch.zeros((world, max_frames), dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.mix = torch.zeros(max_frames, dtype=torch.float32, device=self.device)
+        self._pending = None      # (work, slot, frames) of the all-gather still in flight
+        self._k = 0
+
+    # ---- events: identical stream on every rank ----
+    def note_events(self, events):
+        self.renderer.note_events(events)
+
+    def note_on(self, note, velocity=1.0):
+        return self.renderer.note_on(note, velocity)
+
+    def note_off(self, note):
+        self.renderer.note_off(note)
+
+    def load_patch(self, text):
+        self.renderer.load_patch(text)
+
+    # ---- one buffer ----
+    def _stream_ptr(self):
+        return torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else None
+
+    def _combine_hip(self, rows, n_rows, frames, out):
+        _synth.sum_partials_device(rows.data_ptr(), n_rows, frames, out.data_ptr(), self._stream_ptr())
+
+    def _finish(self, pending):
+        work, slot, frames = pending
+        if work is not None:
+            work.wait()                      # current stream waits for the collective
+        if self.rank == 0:
+            # rows are [world][max_frames]; combine wants them packed [world][frames]
+            rows = self.gathered[slot] if frames == self.max_frames else self.gathered[slot][:, :frames].contiguous()
+            self.combine(rows, self.world, frames, self.mix)
+
+    def fill(self, frames, sample_rate=48000):
+        """Render one buffer.  With overlap on, the all-gather of buffer k runs on RCCL's own
+        stream while buffer k+1 renders; call flush() before reading ``mix``."""
+        slot = self._k & 1
+        self._k += 1
+        part = self.partial[slot]
+        self.renderer.fill_device(part.data_ptr(), frames, sample_rate, self._stream_ptr())
+        if self.world == 1:
+            self.combine(part, 1, frames, self.mix)
+            return
+        if self._pending is not None:
+            self._finish(self._pending)
+            self._pending = None
+        if frames == self.max_frames:
+            work = dist.all_gather_into_tensor(self.gathered[slot].view(-1), part, async_op=self.overlap)
+        else:
+            tmp = torch.zeros((self.world, frames), dtype=torch.float32, device=self.device)
+            work = dist.all_gather_into_tensor(tmp.view(-1), part[:frames].contiguous(), async_op=self.overlap)
+            if work is not None:
+                work.wait()
+                work = None
+            self.gathered[slot][:, :frames] = tmp
+        pending = (work if self.overlap else None, slot, frames)
+        if self.overlap:
+            self._pending = pending
+        else:
+            self._finish(pending)
+
+    def flush(self):
+        if self._pending is not None:
+            self._finish(self._pending)
+            self._pending = None

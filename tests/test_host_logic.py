@@ -1,0 +1,146 @@
+"""CPU-only tests of the product's host logic through the C ABI (no device needed): the
+voice-allocation policy against the oracle's restatement of synth.rs:61-120, the .synth2
+loader, and that libs2r.so loads and exports every symbol include/s2r.h declares."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import s2o
+import synth2_amd as s2
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = s2.load_library()
+    assert L.s2r_abi_version() == 1
+    hdr = open(os.path.join(ROOT, "include", "s2r.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(s2r_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 30
+    raw = C.CDLL(s2.synth.lib_path())
+    missing = [n for n in names if not hasattr(raw, n)]
+    assert not missing, "declared in include/s2r.h but not exported: %s" % missing
+
+
+def test_no_cpu_fallback_without_a_device(has_gpu):
+    if has_gpu:
+        pytest.skip("GPU present")
+    with pytest.raises(s2.S2rError) as e:
+        s2.Synth(8)
+    assert e.value.status == -2      # S2R_ERR_NO_DEVICE
+
+
+def test_status_strings():
+    L = s2.load_library()
+    assert L.s2r_status_string(0) == b"ok"
+    assert b"overflow" in L.s2r_status_string(-7)
+
+
+# ---------------------------------------------------------------- .synth2 loader
+
+def test_example_synth2_is_the_default_patch():
+    """example.synth2:1-3 (`synth mySynth {` / blank / `}`) == Synth::default_config (synth.rs:125-152)"""
+    p = s2.parse_patch("synth mySynth {\n\n}\n")
+    d = s2.default_patch()
+    assert bytes(p) == bytes(d)
+    assert (p.osc_kind, p.osc_gain, p.noise, p.lpf_freq) == (s2.OSC_SAW, 1.0, 0.0, 200.0)
+    assert (p.amp_env.attack_ms, p.amp_env.decay_ms, p.amp_env.sustain, p.amp_env.release_ms) == (100.0, 100.0, 0.5, 100.0)
+    assert (p.mod_env.attack_ms, p.mod_env.decay_ms, p.mod_env.sustain, p.mod_env.release_ms) == (0.0, 200.0, 0.0, 0.0)
+    assert (p.mod_env_to_osc_freq, p.mod_env_to_lpf_freq) == (0.0, 10.0)
+    # and equals the oracle's restatement of default_config
+    o = s2o.lib().s2o_default_config()
+    assert bytes(o) == bytes(p)
+
+
+def test_patch_full_grammar():
+    p = s2.parse_patch("""
+        # a comment
+        synth lead {
+            osc.kind = sine;  osc.gain = 0.25
+            noise = 0.125,
+            lpf.freq = 1234.5      // Hz
+            amp_env.attack = 1; amp_env.decay = 2; amp_env.sustain = 0.75; amp_env.release = 3
+            mod_env.attack = 4; mod_env.decay = 5; mod_env.sustain = 0.5; mod_env.release = 6
+            mod_env_to_osc_freq = -2.5
+            mod_env_to_lpf_freq = 7
+        }""")
+    assert p.osc_kind == s2.OSC_SINE and p.osc_gain == 0.25 and p.noise == 0.125 and p.lpf_freq == 1234.5
+    assert (p.amp_env.attack_ms, p.amp_env.decay_ms, p.amp_env.sustain, p.amp_env.release_ms) == (1, 2, 0.75, 3)
+    assert (p.mod_env.attack_ms, p.mod_env.decay_ms, p.mod_env.sustain, p.mod_env.release_ms) == (4, 5, 0.5, 6)
+    assert (p.mod_env_to_osc_freq, p.mod_env_to_lpf_freq) == (-2.5, 7.0)
+    for kind, code in (("square", 0), ("saw", 1), ("triangle", 2), ("sine", 3)):
+        assert s2.parse_patch("synth x { osc.kind = %s }" % kind).osc_kind == code
+
+
+@pytest.mark.parametrize("text,status", [
+    ("", -4), ("synth", -4), ("synth x", -4), ("synth x {", -4), ("synth x { } trailing", -4),
+    ("synth x { bogus = 1 }", -4), ("synth x { osc.kind = sawtooth }", -4), ("synth x { osc.gain 1 }", -4),
+    ("synth x { osc.gain = }", -4),
+    ("synth x { osc.gain = 1.5 }", -5),               # Unipolar<1>, units.rs:55-65
+    ("synth x { noise = -0.1 }", -5),
+    ("synth x { amp_env.sustain = 2 }", -5),
+    ("synth x { mod_env_to_lpf_freq = 10.5 }", -5),   # Bipolar<10>
+    ("synth x { mod_env_to_osc_freq = -11 }", -5),
+    ("synth x { amp_env.attack = -1 }", -5),
+    ("synth x { lpf.freq = nan }", -5),
+    ("synth x { osc.kind = 7 }", -5),
+])
+def test_patch_errors(text, status):
+    with pytest.raises(s2.S2rError) as e:
+        s2.parse_patch(text)
+    assert e.value.status == status
+
+
+# ---------------------------------------------------------------- voice pool policy
+
+@pytest.mark.parametrize("voices,seed", [(1, 0), (2, 1), (8, 2), (8, 3), (64, 4), (300, 5)])
+def test_voice_pool_matches_reference_policy(voices, seed):
+    """random note_on/note_off/advance streams: the O(log V) pool picks exactly the voices the
+    reference's O(V) scans pick (synth.rs:82-120)."""
+    rng = np.random.RandomState(seed)
+    pool = s2.VoicePool(voices)
+    ora = s2o.OracleSynth(voices)
+    for step in range(3000):
+        r = rng.randint(0, 10)
+        note = int(rng.randint(50, 50 + max(2, voices // 2)))
+        if r < 5:
+            want = ora.next_voice_index()
+            assert pool.next_voice() == want
+            ora.note_on(note)
+            assert pool.note_on(note) == want
+        elif r < 8:
+            before = [(ora.voice(i).has_current, ora.voice(i).has_release) for i in range(voices)]
+            ora.note_off(note)
+            after = [(ora.voice(i).has_current, ora.voice(i).has_release) for i in range(voices)]
+            changed = [i for i in range(voices) if before[i] != after[i]]
+            got = pool.note_off(note)
+            assert got == (changed[0] if changed else -1)
+        else:
+            n = int(rng.choice([16, 16, 16, 64, 1024, 1]))
+            pool.advance(n)
+            for i in range(voices):      # what Synth::sample does to every started voice (synth.rs:197)
+                v = ora.voice(i)
+                if v.has_current:
+                    v.current_frame_offset = min(0xFFFFFFFF, v.current_frame_offset + n)
+    for i in range(voices):
+        q = pool.query(i)
+        v = ora.voice(i)
+        assert bool(q.started) == bool(v.has_current)
+        if v.has_current:
+            assert q.note == v.note and q.current_frame_offset == v.current_frame_offset
+            assert bool(q.released) == bool(v.has_release)
+            if v.has_release:
+                assert q.release_frame_offset == v.release_frame_offset
+
+
+def test_voice_pool_many_steals_of_a_held_note_stays_bounded():
+    """a note that is re-triggered forever without note_off must not grow the lazy heaps without bound"""
+    pool = s2.VoicePool(4)
+    for _ in range(20000):
+        pool.note_on(60)
+        pool.advance(16)
+    assert pool.note_off(60) in (0, 1, 2, 3)
