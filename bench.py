@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="GPU lanes per voice (1/2/4, 0 = auto)")
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap the all-gather with the next render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-voices", type=int, default=4096)
+    ap.add_argument("--cpu-voices", type=int, default=16384)
     ap.add_argument("--cpu-buffers", type=int, default=0, help="0 = sized for ~15 s")
     args = ap.parse_args()
 
@@ -227,7 +227,7 @@ def main():
                 nb = args.cpu_buffers
             else:
                 probe, _ = cpu_baseline(args.cpu_voices, 1, threads)
-                nb = int(max(2, min(200, 15.0 * probe / (args.cpu_voices * FRAMES))))
+                nb = int(max(2, min(400, 15.0 * probe / (args.cpu_voices * FRAMES))))
             v, secs = cpu_baseline(args.cpu_voices, nb, threads)
             out["cpu_baseline"] = {"value": v, "unit": "samples/s", "cores": threads, "kind": "port",
                                    "sample": "%d voices x %d frames x %d buffers, default patch, same note map; "

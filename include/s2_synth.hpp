@@ -1,0 +1,69 @@
+// s2_synth.hpp — header-only C++ mirror of `s2_lib::try3::synth` over the C ABI (s2r.h).
+//
+// Same names, argument meaning and call pattern as the reference
+// (/root/reference/components/s2_lib/src/try3/synth.rs:9-21,53-80,154-156; units.rs:11-14), so a
+// C++ caller — or a test — reads like the reference's own call sites
+// (components/s2_bin/src/main.rs:132-147,198-205):
+//
+//     s2::Synth synth;                                   // Synth::new()
+//     synth.note_on(s2::Note{69}, s2::Velocity{{1.0f}});
+//     synth.sample(buffer, n, s2::SampleRateKhz{48000}); // overwrites buffer
+//     synth.note_off(s2::Note{69});
+//
+// Where the reference panics (offset overflow, process.rs:36) this throws s2::Error.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include "s2r.h"
+
+namespace s2 {
+
+template <unsigned N> struct Unipolar { float v; };   // units.rs:11
+struct Note { uint8_t v; };                           // synth.rs:16  Note(pub u8)
+struct Velocity { Unipolar<1> v; };                   // synth.rs:18  Velocity(pub Unipolar<1>)
+struct SampleRateKhz { uint32_t v; };                 // units.rs:14  (holds Hz, units.rs:21)
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int st, const std::string &msg) : std::runtime_error(msg), status(st) {}
+};
+
+class Synth {
+  public:
+    // Synth::new(): NUM_VOICES = 8 in the reference (synth.rs:7); here a run-time size.
+    explicit Synth(uint32_t num_voices = 8, uint32_t max_frames = 2048, int device = -1) {
+        s2r_config cfg{};
+        cfg.struct_size = sizeof cfg;
+        cfg.total_voices = num_voices;
+        cfg.max_frames = max_frames;
+        cfg.device = device;
+        const int rc = s2r_create(&cfg, &h_);
+        if (rc != S2R_OK) throw Error(rc, s2r_status_string(rc));
+    }
+    explicit Synth(const s2r_config &cfg) {
+        const int rc = s2r_create(&cfg, &h_);
+        if (rc != S2R_OK) throw Error(rc, s2r_status_string(rc));
+    }
+    ~Synth() { s2r_destroy(h_); }
+    Synth(const Synth &) = delete;
+    Synth &operator=(const Synth &) = delete;
+    Synth(Synth &&o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+
+    void load_patch(const std::string &synth2_text) { check(s2r_load_patch(h_, synth2_text.data(), synth2_text.size())); }
+    void note_on(Note note, Velocity velocity) { check(s2r_note_on(h_, note.v, velocity.v.v)); }     // synth.rs:61-70
+    void note_off(Note note) { check(s2r_note_off(h_, note.v)); }                                    // synth.rs:72-80
+    // Synth::sample(&mut [f32], SampleRateKhz), synth.rs:154-169
+    void sample(float *buffer, size_t len, SampleRateKhz sample_rate) { check(s2r_fill(h_, buffer, len, sample_rate.v)); }
+
+    s2r_synth *handle() { return h_; }
+
+  private:
+    void check(int rc) {
+        if (rc != S2R_OK) throw Error(rc, s2r_last_error(h_));
+    }
+    s2r_synth *h_ = nullptr;
+};
+
+}  // namespace s2

@@ -320,10 +320,11 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
     s->padded_voices = s->n_blocks * bv;
     s->mix_groups = cfg->mix_groups ? cfg->mix_groups : 1u;
     {
-        // lanes per voice: enough waves to give every SIMD of the 256 CUs a few (64 k voices at
-        // one lane per voice are exactly one wave per SIMD)
+        // lanes per voice: below one wave per SIMD (64 k voices at one lane per voice are exactly
+        // one wave on each of the 1024 SIMDs) spread a voice over 2 or 4 lanes to fill the chip;
+        // above that the 4-frame ILP of a single lane is the faster way (measured)
         uint32_t l = cfg->lanes_per_voice;
-        if (l == 0) l = shard_voices <= 65536u ? 4u : (shard_voices <= 131072u ? 2u : 1u);
+        if (l == 0) l = shard_voices >= 65536u ? 1u : (shard_voices >= 32768u ? 2u : 4u);
         while (l > 1 && bv * l > 1024u) l >>= 1;
         if (l != 1 && l != 2 && l != 4) { delete s; return S2R_ERR_INVALID; }
         s->lanes = l;
