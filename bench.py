@@ -164,15 +164,29 @@ def main():
     mix_host = mix.cpu().numpy()
 
     # ---- per-launch duration of the render kernel, HIP events on the launch stream ----
-    # (separate short loop so the events do not perturb the timed region)
-    kms = []
-    synth.set_timing(True)
-    for k in range(min(args.steps, 16)):
-        synth.fill_device(partial[0].data_ptr(), FRAMES, SR, sptr)
-        kms.append(synth.last_render_ms())
-    synth.set_timing(False)
+    # (separate short loops so the events do not perturb the timed region)
+    def kernel_ms_loop():
+        kms = []
+        synth.set_timing(True)
+        for k in range(min(args.steps, 16)):
+            synth.fill_device(partial[0].data_ptr(), FRAMES, SR, sptr)
+            kms.append(synth.last_render_ms())
+        synth.set_timing(False)
+        fence()
+        return float(np.mean(kms)) if kms else float("nan")
+
+    kernel_ms = kernel_ms_loop()
+    # the same workload with the flat-envelope coefficient reuse switched off: every frame of
+    # every voice pays the full pow/exp chain (what the kernel costs when all voices modulate)
+    synth.set_flat_shortcut(False)
+    kernel_ms_full = kernel_ms_loop()
+    t2 = time.perf_counter()
+    n_full = min(args.steps, 32)
+    for k in range(n_full):
+        sh.fill(FRAMES, SR)
     fence()
-    kernel_ms = float(np.mean(kms)) if kms else float("nan")
+    dt_full = time.perf_counter() - t2
+    synth.set_flat_shortcut(True)
 
     # ---- synchronous host-buffer API (s2r_fill): D2H + sync per buffer ----
     sync_rate = None
@@ -188,7 +202,7 @@ def main():
         value = total * FRAMES * args.steps / dt_max
         kernel_s = kernel_ms * 1e-3
         hbm_gbs = BYTES_PER_VOICE_FILL * vpg / kernel_s / 1e9
-        valu_tf = FLOPS_PER_VOICE_SAMPLE * vpg * FRAMES / kernel_s / 1e12
+        valu_tf = FLOPS_PER_VOICE_SAMPLE * vpg * FRAMES / (kernel_ms_full * 1e-3) / 1e12
         out = {
             "metric": "voice-samples/sec (mono) at 64k voices per GPU, 48 kHz, 1024-frame buffers",
             "value": value,
@@ -215,7 +229,9 @@ def main():
                          "note": "algorithmic bytes = %d B per voice per fill; the path is VALU-bound, see roofline_valu" % BYTES_PER_VOICE_FILL},
             "roofline_valu": {"bound": "valu-fp32", "achieved": valu_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": valu_tf / VALU_PEAK_TFLOPS,
-                              "flops_per_voice_sample": FLOPS_PER_VOICE_SAMPLE},
+                              "flops_per_voice_sample": FLOPS_PER_VOICE_SAMPLE, "kernel_ms": kernel_ms_full,
+                              "note": "launch time with the flat-envelope coefficient reuse OFF, i.e. all 250 flop-eq per voice-sample executed"},
+            "value_all_voices_modulating": total * FRAMES * n_full / dt_full if world == 1 else None,
             "mix_checksum": float(np.abs(mix_host).sum()),
         }
         if sync_rate is not None:

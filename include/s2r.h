@@ -165,6 +165,11 @@ uint64_t s2r_double_release_count(const s2r_synth *s);      /* synth.rs:77 warn 
  * on the library's stream around the launch); < 0 if timing is off.  Enable with
  * s2r_set_timing(s, 1): adds two event records per fill. */
 int s2r_set_timing(s2r_synth *s, int enabled);
+/* Measurement knob (default on): while the mod envelope of every voice of a wavefront is in a
+ * flat stage the LPF coefficient is reused instead of recomputed — same bits either way.
+ * Turning it off makes every frame pay the full pow/exp chain (bench.py's
+ * `value_all_voices_modulating` leg). */
+int s2r_set_flat_shortcut(s2r_synth *s, int enabled);
 float s2r_last_render_ms(s2r_synth *s);
 const char *s2r_last_error(const s2r_synth *s);             /* never NULL */
 const char *s2r_status_string(int status);

@@ -579,18 +579,18 @@ void s2o_sample(s2o_synth *s, float *buffer, size_t frames, uint32_t sr) {
 
 /* ------------------------------------------------------------------ GPU mix tree */
 
-static float wave_tree64(const float *per_voice, uint32_t voices, size_t frames, uint32_t v0, size_t i) {
-    float t[64];
-    for (uint32_t l = 0; l < 64; l++) t[l] = (v0 + l < voices) ? per_voice[(size_t)(v0 + l) * frames + i] : 0.0f;
-    for (uint32_t w = 64; w > 1; w >>= 1)
-        for (uint32_t k = 0; k < w / 2; k++) t[k] = t[2 * k] + t[2 * k + 1];
-    return t[0];
+/* 16 consecutive voices added in index order (the reference's own order inside the group) */
+static float group16(const float *per_voice, uint32_t voices, size_t frames, uint32_t v0, size_t i) {
+    float acc = (v0 < voices) ? per_voice[(size_t)v0 * frames + i] : 0.0f;
+    for (uint32_t k = 1; k < 16; k++) acc += (v0 + k < voices) ? per_voice[(size_t)(v0 + k) * frames + i] : 0.0f;
+    return acc;
 }
 
+/* a workgroup's `block_voices` voices: its 16-voice group sums added in group order */
 static float block_partial(const float *per_voice, uint32_t voices, size_t frames, uint32_t b, uint32_t block_voices, size_t i) {
     uint32_t v0 = b * block_voices;
-    float acc = wave_tree64(per_voice, voices, frames, v0, i);
-    for (uint32_t w = 1; w < block_voices / 64; w++) acc += wave_tree64(per_voice, voices, frames, v0 + 64 * w, i);
+    float acc = group16(per_voice, voices, frames, v0, i);
+    for (uint32_t g = 1; g < block_voices / 16; g++) acc += group16(per_voice, voices, frames, v0 + 16 * g, i);
     return acc;
 }
 

@@ -73,10 +73,11 @@ typedef struct {
     uint64_t double_release; /* synth.rs:77 warn counter */
 } s2o_synth;
 
-/* GPU mix-tree description (DESIGN.md §Mix tree): voices are reduced pairwise inside
- * 64-voice waves, waves sequentially inside a block of `block_voices`, blocks sequentially
- * inside each of `groups` contiguous groups, groups sequentially, and the root is
- * (+0.0f) + total (the `accum = splat(0.0)` of synth.rs:176). */
+/* GPU mix-tree description: every 16 consecutive voices are added in index
+ * order (the reference's order, synth.rs:177-195), the 16-voice sums of a block of
+ * `block_voices` in order, blocks sequentially inside each of `groups` contiguous groups,
+ * groups sequentially, and the root is (+0.0f) + total (the `accum = splat(0.0)` of
+ * synth.rs:176).  For pools of <= 16 voices this IS the reference's summation order. */
 typedef struct { uint32_t block_voices; uint32_t groups; } s2o_tree;
 
 s2o_layer_cfg s2o_default_config(void);                     /* synth.rs:125-152 */

@@ -48,6 +48,7 @@ struct S2rRenderParams {
     float sr;             // sample_rate as f32 (units.rs:21)
     float rcp_sr;         // RN(1/sr)
     int32_t fast_div_sr;  // 1 => x/sr may use the 3-op exact quotient (rate verified exhaustively)
+    int32_t no_flat_shortcut;  // 1 => always recompute the LPF coefficient (measurement knob)
     uint32_t frames;      // this fill
     uint32_t n_voices;    // shard voices
     uint32_t frames_stride; // row stride of block_partials / per_voice (== max_frames or frames)

@@ -118,7 +118,7 @@ struct s2r_synth {
     float *per_voice_dev = nullptr; size_t per_voice_cap = 0;
     float pitch_table[256];
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    bool timing = false, timed = false;
+    bool timing = false, timed = false, no_flat_shortcut = false;
     uint64_t double_release = 0;
     std::string err = "";
 };
@@ -197,6 +197,7 @@ S2rRenderParams make_params(s2r_synth *s, size_t frames, uint32_t sample_rate) {
     // 2^-10 <= pow2 <= 2^10 (|mod * amount| <= 10), so lpf_freq in [2^-30, 2^30] keeps the
     // dividend inside the window the 3-op quotient was verified for
     p.fast_div_sr = (fast_div_rate(sample_rate) && s->patch.lpf_freq >= 0x1p-30f && s->patch.lpf_freq <= 0x1p30f) ? 1 : 0;
+    p.no_flat_shortcut = s->no_flat_shortcut ? 1 : 0;
     p.frames = (uint32_t)frames;
     p.n_voices = s->shard_voices;
     p.frames_stride = s->cfg.max_frames;
@@ -567,6 +568,12 @@ uint32_t s2r_shard_voices(const s2r_synth *s) { return s ? s->shard_voices : 0; 
 uint32_t s2r_block_voices(const s2r_synth *s) { return s ? s->block_voices : 0; }
 uint32_t s2r_lanes_per_voice(const s2r_synth *s) { return s ? s->lanes : 0; }
 uint64_t s2r_double_release_count(const s2r_synth *s) { return s ? s->double_release : 0; }
+
+int s2r_set_flat_shortcut(s2r_synth *s, int enabled) {
+    if (!s) return S2R_ERR_INVALID;
+    s->no_flat_shortcut = enabled == 0;
+    return S2R_OK;
+}
 
 int s2r_set_timing(s2r_synth *s, int enabled) {
     if (!s) return S2R_ERR_INVALID;

@@ -14,11 +14,24 @@
 #include "s2r_device.h"
 #include "s2r_math.h"
 
+#if defined(S2R_ABLATE_RECUR)
+#define S2R_RECUR(OSC, p, r, c1, k1, sSin) ((c1.amp + c1.xc) + c1.nz)
+#else
+#define S2R_RECUR(OSC, p, r, c1, k1, sSin) recur_x16<OSC>(p, r, c1, k1, sSin)
+#endif
+// development-only ablation switches (tools/ablate.sh); never defined in the product build
+#if defined(S2R_ABLATE_MIX)
+#define S2R_ABLATE_MIX_BEGIN { asm volatile("" :: "v"(out4.x), "v"(out4.y), "v"(out4.z), "v"(out4.w)); } if (false) {
+#define S2R_ABLATE_MIX_END }
+#else
+#define S2R_ABLATE_MIX_BEGIN
+#define S2R_ABLATE_MIX_END
+#endif
+
 namespace {
 
 __constant__ uint64_t c_exp2f_table[S2R_EXP2F_N] = S2R_EXP2F_TABLE_INIT;
 
-constexpr int kMaxWaves = 16;      // 1024-thread workgroup
 constexpr int kChunk = 16;         // the reference's x16 chunk (synth.rs:158, process.rs:25)
 constexpr uint32_t kSuper = 64;    // frames between two cross-wave combines (one lane of the row buffer each)
 constexpr int kP = 4;              // frames whose closed-form work one lane carries at once (ILP)
@@ -119,12 +132,7 @@ __device__ __forceinline__ f4 expf4(f4 x, const uint64_t *T) {
     return res;
 }
 
-// ---------------------------------------------------------------------------------------
-// wave64 sum by DPP.  After the six steps lane 63 holds
-//   (((v0+v1)+(v2+v3)) + ...)   — a balanced pairwise tree over the lanes in index order,
-// which is the tree oracle/s2_oracle.c:wave_tree64 spells out.  Must run with all 64 lanes
-// enabled.
-// ---------------------------------------------------------------------------------------
+// DPP move (the quad_perm exchanges between the L lanes of a voice)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_mov(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
@@ -145,37 +153,31 @@ struct VoiceRegs {
 };
 
 // The x16 ADSR (old/simdtest.rs:270-331) is a cascade of four `t < threshold` tests selecting one
-// of five expressions.  Within a fill t only grows, so a voice's stage only ever moves forward
-// (at most four times in its life): keep the ACTIVE stage's line  slope * (t - base) + y0  and
-// its end threshold in registers and re-run the cascade only when t reaches that threshold.
+// of five expressions.  A stage, once entered, lasts until t reaches its end threshold: keep the
+// ACTIVE stage's line  slope * (t - base) + y0  and that threshold in registers and re-run the
+// cascade only when t reaches it.  (t only grows within a fill; thresholds never precede the
+// stage they end, so "t < thr of the stage found at an earlier t" implies the same stage now.)
 // The value produced is the reference's selected expression, operation for operation.
 struct EnvRun {
     float slope, base, y0, thr;
-    int stage;                  // 0 attack, 1 decay, 2 sustain, 3 release, 4 end
 };
 
-// registers of stage `stage` (branch-free selects so the struct stays in registers)
-__device__ __forceinline__ EnvRun env_make(int stage, const S2rEnv &e, float ro, float end) {
+// the cascade of simdtest.rs:288-292 for one frame offset t, from scratch: the first stage whose
+// `t < threshold` test holds (0 attack, 1 decay, 2 sustain, 3 release, 4 end), returned as that
+// stage's line and end threshold.  Straight-line selects only, so everything stays in registers.
+__device__ __forceinline__ EnvRun env_stage_at(const S2rEnv &e, float ro, float end, float t) {
+    const bool s0 = t < e.A;
+    const bool s1 = !s0 && t < e.sus_off;
+    const bool s2 = !s0 && !s1 && t < ro;
+    const bool s3 = !s0 && !s1 && !s2 && t < end;
     EnvRun s;
-    s.stage = stage;
-    s.slope = stage == 0 ? e.slope_att : stage == 1 ? e.slope_dec : stage == 3 ? e.slope_rel : 0.0f;
-    s.base  = stage == 1 ? e.A : stage == 3 ? ro : 0.0f;
-    s.y0    = stage == 1 ? 1.0f : (stage == 2 || stage == 3) ? e.S : 0.0f;
-    s.thr   = stage == 0 ? e.A : stage == 1 ? e.sus_off : stage == 2 ? ro : stage == 3 ? end : __builtin_inff();
     //  0: (1/A) * t + 0        1: ((S-1)/D) * (t-A) + 1     2: S  (0*t + S == S)
     //  3: (-S/R) * (t-ro) + S  4: 0
+    s.slope = s0 ? e.slope_att : s1 ? e.slope_dec : s3 ? e.slope_rel : 0.0f;
+    s.base  = s1 ? e.A : s3 ? ro : 0.0f;
+    s.y0    = s1 ? 1.0f : (s2 || s3) ? e.S : 0.0f;
+    s.thr   = s0 ? e.A : s1 ? e.sus_off : s2 ? ro : s3 ? end : __builtin_inff();
     return s;
-}
-
-// the cascade: leave every stage whose `t < threshold` test fails (simdtest.rs:288-292)
-__device__ __forceinline__ EnvRun env_advance(EnvRun s, const S2rEnv &e, float ro, float end, float t) {
-    int stage = s.stage;
-    float thr = s.thr;
-    while (stage < 4 && !(t < thr)) {
-        stage++;
-        thr = stage == 1 ? e.sus_off : stage == 2 ? ro : stage == 3 ? end : __builtin_inff();
-    }
-    return env_make(stage, e, ro, end);
 }
 
 __device__ __forceinline__ float env_value(const EnvRun &s, float t) {
@@ -239,7 +241,11 @@ __device__ __forceinline__ OscK make_osck(float period) {
 // oscillators.rs basic::{Square,Saw,Triangle,Table}Oscillator[X16]::sample given the phased offset
 template <int OSC>
 __device__ __forceinline__ float osc_value(const OscK &k, float off, const float *sSin) {
-    const float x = s2r_fmod_period(off, k.period);             // offset % period
+    // offset % period: `off` itself while 0 <= off < period (one unsigned compare on the bit
+    // patterns, see s2r_fmod_period); the exact library fmodf only if some lane of the wave needs it
+    float x = off;
+    const bool slow = !(s2r_f2u(off) < s2r_f2u(k.period) && k.period > 0.0f);
+    if (__builtin_expect(__ballot(slow) != 0ull, 0)) { if (slow) x = ::fmodf(off, k.period); }
     if (OSC == S2R_OSC_SAW) {
         return __builtin_fmaf(k.a, x, 1.0f);
     } else if (OSC == S2R_OSC_SQUARE) {
@@ -312,39 +318,78 @@ __device__ __forceinline__ f4 hash_noise4(uint32_t seed_rot, f4 t) {
     return vfma(q, splat(2.0f), splat(-1.0f));
 }
 
+// While the mod envelope sits in a stage whose slope is zero (sustain, end, or a degenerate
+// decay/release) its value is the constant y0, so everything derived from it alone — the LPF
+// coefficient exp(-2 pi f / sr) and, under FM, the oscillator period constants — is the same
+// number frame after frame.  It is computed once when the stage is entered (scalar routines,
+// bit-identical to the vector ones) and reused while EVERY voice of the wave is in such a stage.
+struct FlatCache {
+    float xc;
+    OscK k;
+};
+
+template <int OSC, bool FM, bool FASTDIV>
+__device__ __forceinline__ FlatCache refresh_flat(const S2rRenderParams &p, const VoiceRegs &r, const EnvRun em,
+                                                  const uint64_t *sT, FlatCache fc) {
+    if (em.slope == 0.0f) {
+        const float mod = em.y0;                                          // 0 * (t - base) + y0 == y0
+        const float f_lpf = s2r_pow2_sleef_core(mod * p.amt_lpf) * p.lpf_freq;
+        fc.xc = s2r_expf(lpf_arg<FASTDIV>(p, f_lpf), sT);
+        if (FM) fc.k = make_osck<OSC>(p.sr / (s2r_pow2_sleef_core(mod * p.amt_osc) * r.pitch));
+    }
+    return fc;
+}
+
 // frames oi .. oi+3 of one voice
 template <int OSC, bool FM, bool FASTDIV>
 __device__ __forceinline__ void closed_form_x4(const S2rRenderParams &p, const VoiceRegs &r, EnvRun &ea, EnvRun &em,
-                                               float &thr_min, uint32_t oi, const uint64_t *sT,
+                                               float &thr_min, FlatCache &fc, uint32_t oi, const uint64_t *sT,
                                                FrameCF4 &cf, OscK4 &k) {
     const u4 ou = (u4)(oi) + (u4){0u, 1u, 2u, 3u};               // offsets_x16: wrapping u32 add (process.rs:213-219)
     const f4 t = __builtin_convertvector(ou, f4);                // offsets as f32 (simdtest.rs:277-279, process.rs:348)
-    f4 amp, mod;
-    if (__builtin_expect(!(t.w < thr_min), 0)) {
-        // an envelope stage ends inside these four frames: walk them one by one
+    // fast path first: the active stages' lines for all four frames
+    f4 amp = splat(ea.slope) * (t - splat(ea.base)) + splat(ea.y0);           // process.rs:144
+    f4 mod = splat(em.slope) * (t - splat(em.base)) + splat(em.y0);           // process.rs:145
+    bool moving = p.no_flat_shortcut != 0;
+    const bool cold = !(t.w < thr_min);
+    if (__builtin_expect(__ballot(cold) != 0ull, 0)) {      // wave-uniform branch: no exec juggling when nobody is cold
+        if (cold) {
+            // an envelope stage ends inside these four frames: walk them one by one
+            moving = true;
 #define S2R_ENV_STEP(C)                                                                   \
-        {                                                                                 \
-            const float tj = t.C;                                                         \
-            if (!(tj < thr_min)) {                                                        \
-                ea = env_advance(ea, p.amp, r.ro_a, r.end_a, tj);                         \
-                em = env_advance(em, p.mod, r.ro_m, r.end_m, tj);                         \
-                thr_min = __builtin_fminf(ea.thr, em.thr);                                \
-            }                                                                             \
-            amp.C = env_value(ea, tj);                                                    \
-            mod.C = env_value(em, tj);                                                    \
-        }
-        S2R_ENV_STEP(x) S2R_ENV_STEP(y) S2R_ENV_STEP(z) S2R_ENV_STEP(w)
+            {                                                                             \
+                const float tj = t.C;                                                     \
+                if (!(tj < thr_min)) {                                                    \
+                    ea = env_stage_at(p.amp, r.ro_a, r.end_a, tj);                        \
+                    em = env_stage_at(p.mod, r.ro_m, r.end_m, tj);                        \
+                    thr_min = __builtin_fminf(ea.thr, em.thr);                            \
+                }                                                                         \
+                amp.C = env_value(ea, tj);                                                \
+                mod.C = env_value(em, tj);                                                \
+            }
+            S2R_ENV_STEP(x) S2R_ENV_STEP(y) S2R_ENV_STEP(z) S2R_ENV_STEP(w)
 #undef S2R_ENV_STEP
-    } else {
-        amp = splat(ea.slope) * (t - splat(ea.base)) + splat(ea.y0);          // process.rs:144
-        mod = splat(em.slope) * (t - splat(em.base)) + splat(em.y0);          // process.rs:145
+            fc = refresh_flat<OSC, FM, FASTDIV>(p, r, em, sT, fc);
+        }
     }
     cf.amp = amp;
+#if defined(S2R_ABLATE_NOISE)
+    cf.nz = t;
+#else
+    cf.nz = hash_noise4(r.seed_rot, t) + splat(p.noise_level);   // process.rs:347-356 (ADD)
+#endif
+    moving = moving || em.slope != 0.0f;
+    if (__ballot(moving) == 0ull) {
+        // every voice of this wave has a flat mod envelope over these four frames
+        cf.xc = splat(fc.xc);
+        if (FM) { k.period = splat(fc.k.period); k.inv_period = splat(fc.k.inv_period);
+                  k.a = splat(fc.k.a); k.b = splat(fc.k.b); k.c = splat(fc.k.c); }
+        return;
+    }
     const f4 f_lpf = pow2_sleef_core4(mod * splat(p.amt_lpf)) * splat(p.lpf_freq);   // process.rs:148-152
     const f4 num = splat(-2.0f * 3.14159274101257324f) * f_lpf;  // -2.0 * pi * freq   (filters.rs:21)
     const f4 arg = FASTDIV ? div_const_nocheck4(num, p.sr, p.rcp_sr) : (num / splat(p.sr));
     cf.xc = expf4(arg, sT);
-    cf.nz = hash_noise4(r.seed_rot, t) + splat(p.noise_level);   // process.rs:347-356 (ADD)
     if (FM) {
         const f4 f_osc = pow2_sleef_core4(mod * splat(p.amt_osc)) * splat(r.pitch);  // process.rs:146-147,231-250
         k = make_osck4<OSC>(splat(p.sr) / f_osc);                // units.rs:32-42
@@ -400,43 +445,6 @@ __device__ __forceinline__ f4 bcast_sub4(f4 v) {
     return r;
 }
 
-// wave64 sum where every voice's value is replicated over L consecutive lanes: the first
-// log2(L) butterfly steps are skipped, leaving the balanced tree over the wave's 64/L voices.
-template <int L>
-__device__ __forceinline__ float wave_sum_lane63(float v) {
-    if (L == 1) v = v + dpp_mov<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]  : pairs
-    if (L <= 2) v = v + dpp_mov<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]  : quads
-    v = v + dpp_mov<0x141, 0xf>(v);               // row_half_mirror      : 8
-    v = v + dpp_mov<0x140, 0xf>(v);               // row_mirror           : 16 (row totals in every lane)
-    v = v + dpp_mov<0x142, 0xa>(v);               // row_bcast15 -> rows 1,3 : (r0+r1), (r2+r3)
-    v = v + dpp_mov<0x143, 0xc>(v);               // row_bcast31 -> rows 2,3 : total in lane 63
-    return v;
-}
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ f4 dpp_mov4(f4 v) {
-    f4 r;
-    r.x = dpp_mov<CTRL, ROW_MASK>(v.x); r.y = dpp_mov<CTRL, ROW_MASK>(v.y);
-    r.z = dpp_mov<CTRL, ROW_MASK>(v.z); r.w = dpp_mov<CTRL, ROW_MASK>(v.w);
-    return r;
-}
-// four frames' reductions side by side (four independent dependency chains)
-template <int L>
-__device__ __forceinline__ f4 wave_sum_lane63_x4(f4 v) {
-    if (L == 1) v = v + dpp_mov4<0xB1, 0xf>(v);
-    if (L <= 2) v = v + dpp_mov4<0x4E, 0xf>(v);
-    v = v + dpp_mov4<0x141, 0xf>(v);
-    v = v + dpp_mov4<0x140, 0xf>(v);
-    v = v + dpp_mov4<0x142, 0xa>(v);
-    v = v + dpp_mov4<0x143, 0xc>(v);
-    return v;
-}
-
-// lane 63's wave total of frame `i` goes to lane (i & 63) of the row buffer
-__device__ __forceinline__ float park_total(float rowbuf, float tot, uint32_t i, uint32_t lane) {
-    const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), 63));
-    return lane == (i & 63u) ? s : rowbuf;
-}
-
 // ---------------------------------------------------------------------------------------
 // render kernel.
 //   * one voice per lane-group of L lanes (L = 1, 2 or 4);
@@ -448,14 +456,22 @@ __device__ __forceinline__ float park_total(float rowbuf, float tot, uint32_t i,
 //     wave per SIMD at L = 1) at the price of L x the recurrence work (~10% of a frame).
 //   grid = ceil(n_voices / block_voices), blockDim.x = block_voices * L.
 // ---------------------------------------------------------------------------------------
-template <int OSC, bool FM, bool FASTDIV, int L>
-__global__ void __launch_bounds__(1024) s2r_render_kernel(const S2rRenderParams p) {
+template <int OSC, bool FM, bool FASTDIV, int L, int MAXT>
+__global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams p) {
     __shared__ uint64_t sT[S2R_EXP2F_N];
-    __shared__ float sW[2][kMaxWaves][kSuper];
     __shared__ float sSin[OSC == S2R_OSC_SINE ? 1024 : 1];
+    extern __shared__ float s_dyn[];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6, n_waves = blockDim.x >> 6;
+    // mixdown staging: per wave a [16 frames][VW voices + 1] tile that is written
+    // voice-per-lane and read frame-per-lane, and per block the 16-voice group sums
+    // sW[2][n_groups][64 frames] for the cross-wave combine
+    constexpr uint32_t VW = 64 / L;                              // voices per wave
+    constexpr uint32_t GW = VW / 16;                             // 16-voice groups per wave
+    const uint32_t n_groups = n_waves * GW;
+    float *const sW = s_dyn;                                     // [2][n_groups][kSuper]
+    float *const tile = s_dyn + 2 * n_groups * kSuper + wave * (kChunk * (VW + 1));
     const uint32_t sub = tid & (L - 1);                          // which quadruple of the group this lane prepares
     const uint32_t block_voices = blockDim.x / L;
     const uint32_t vi = blockIdx.x * block_voices + tid / L;
@@ -487,9 +503,11 @@ __global__ void __launch_bounds__(1024) s2r_render_kernel(const S2rRenderParams 
     const OscK k_const = make_osck<OSC>(p.sr / (1.0f * r.pitch));
 
     // envelope stage registers; a threshold of -inf forces the cascade on this lane's first frame
-    EnvRun ea = env_make(0, p.amp, r.ro_a, r.end_a);
-    EnvRun em = env_make(0, p.mod, r.ro_m, r.end_m);
+    EnvRun ea = env_stage_at(p.amp, r.ro_a, r.end_a, 0.0f);
+    EnvRun em = env_stage_at(p.mod, r.ro_m, r.end_m, 0.0f);
     float thr_min = -__builtin_inff();
+    FlatCache fc;
+    fc.xc = 0.0f; fc.k = k_const;
 
     __syncthreads();
 
@@ -501,78 +519,94 @@ __global__ void __launch_bounds__(1024) s2r_render_kernel(const S2rRenderParams 
     uint32_t buf = 0;
     constexpr uint32_t G = kP * L;                                       // frames per group
 
-    // Frames are walked in super-chunks of 64: the wave total of frame i is parked in lane
-    // (i & 63) of `rowbuf` (v_readlane + select, no exec juggling, no LDS), and once per
-    // super-chunk the 64 totals go to LDS in one coalesced write for the cross-wave combine.
+    const uint32_t col = lane / L;                                       // this voice's column in the wave's tile
+    // after each 16-frame chunk lane j adds, for frame (j & 15), the 16 voices of group (j >> 4) in
+    // index order (the reference's own order within the group, synth.rs:177-195) and files the
+    // group sum for the cross-wave combine
+    auto reduce_chunk = [&](uint32_t f_base, uint32_t n_frames) {
+        const uint32_t f = lane & 15u, grp = lane >> 4;
+        if (grp < GW && f < n_frames) {
+            const float *src = tile + f * (VW + 1) + grp * 16u;
+            float acc = src[0];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) acc += src[k];
+            sW[(buf * n_groups + wave * GW + grp) * kSuper + f_base + f] = acc;
+        }
+    };
+
+    // Frames are walked in super-chunks of 64 (one barrier and one cross-wave combine each), each
+    // made of 16-frame chunks (one wave-local transpose-and-add each).
     for (uint32_t sc0 = 0; sc0 < p.frames; sc0 += kSuper) {
         const uint32_t n_sc = (p.frames - sc0 < kSuper) ? (p.frames - sc0) : kSuper;
         const uint32_t n_x16 = (x16_frames > sc0) ? ((x16_frames - sc0 < n_sc) ? (x16_frames - sc0) : n_sc) : 0u;
-        float rowbuf = 0.0f;
         if (wave_live) {
-            for (uint32_t g = 0; g < n_x16; g += G) {
-                // closed-form work of frames sc0+g+4*sub .. +3 on this lane
-                FrameCF4 cf; OscK4 kf;
-                closed_form_x4<OSC, FM, FASTDIV>(p, r, ea, em, thr_min, r.offset + sc0 + g + kP * sub, sT, cf, kf);
-                // recurrence for the 4*L frames of the group, every lane of the voice alike
+            for (uint32_t c16 = 0; c16 < n_x16; c16 += kChunk) {
+                for (uint32_t g = c16; g < c16 + kChunk; g += G) {
+                    // closed-form work of frames sc0+g+4*sub .. +3 on this lane
+                    FrameCF4 cf; OscK4 kf;
+                    closed_form_x4<OSC, FM, FASTDIV>(p, r, ea, em, thr_min, fc, r.offset + sc0 + g + kP * sub, sT, cf, kf);
+                    // recurrence for the 4*L frames of the group, every lane of the voice alike
 #define S2R_QUAD(Q)                                                                              \
-                if constexpr (Q < L) {                                                           \
-                    FrameCF4 c4; OscK4 k4;                                                       \
-                    if constexpr (L == 1) { c4 = cf; if (FM) k4 = kf; }                          \
-                    else {                                                                       \
-                        c4.amp = bcast_sub4<L, Q>(cf.amp); c4.xc = bcast_sub4<L, Q>(cf.xc);      \
-                        c4.nz = bcast_sub4<L, Q>(cf.nz);                                         \
-                        if (FM) {                                                                \
-                            k4.period = bcast_sub4<L, Q>(kf.period);                             \
-                            k4.inv_period = bcast_sub4<L, Q>(kf.inv_period);                     \
-                            if (OSC != S2R_OSC_SINE) k4.a = bcast_sub4<L, Q>(kf.a);              \
-                            if (OSC == S2R_OSC_TRIANGLE) { k4.b = bcast_sub4<L, Q>(kf.b); k4.c = bcast_sub4<L, Q>(kf.c); } \
+                    if constexpr (Q < L) {                                                       \
+                        FrameCF4 c4; OscK4 k4;                                                   \
+                        if constexpr (L == 1) { c4 = cf; if (FM) k4 = kf; }                      \
+                        else {                                                                   \
+                            c4.amp = bcast_sub4<L, Q>(cf.amp); c4.xc = bcast_sub4<L, Q>(cf.xc);  \
+                            c4.nz = bcast_sub4<L, Q>(cf.nz);                                     \
+                            if (FM) {                                                            \
+                                k4.period = bcast_sub4<L, Q>(kf.period);                         \
+                                k4.inv_period = bcast_sub4<L, Q>(kf.inv_period);                 \
+                                if (OSC != S2R_OSC_SINE) k4.a = bcast_sub4<L, Q>(kf.a);          \
+                                if (OSC == S2R_OSC_TRIANGLE) { k4.b = bcast_sub4<L, Q>(kf.b); k4.c = bcast_sub4<L, Q>(kf.c); } \
+                            }                                                                    \
                         }                                                                        \
-                    }                                                                            \
-                    f4 out4;                                                                     \
-                    _Pragma("unroll")                                                            \
-                    for (int j = 0; j < kP; ++j) {                                               \
-                        FrameCF c1; c1.amp = c4.amp[j]; c1.xc = c4.xc[j]; c1.nz = c4.nz[j];      \
-                        OscK k1 = k_const;                                                       \
-                        if (FM) { k1.period = k4.period[j]; k1.inv_period = k4.inv_period[j];    \
-                                  k1.a = k4.a[j]; k1.b = k4.b[j]; k1.c = k4.c[j]; }              \
-                        const float o = recur_x16<OSC>(p, r, c1, k1, sSin);                      \
-                        out4[j] = live ? o : 0.0f;                                               \
-                    }                                                                            \
-                    if (p.per_voice) { if (pv_lane) {                                            \
-                        float *dst = p.per_voice + pv_base + sc0 + g + kP * Q;                   \
-                        dst[0] = out4.x; dst[1] = out4.y; dst[2] = out4.z; dst[3] = out4.w; } }  \
-                    const f4 tot4 = wave_sum_lane63_x4<L>(out4);                                 \
-                    rowbuf = park_total(rowbuf, tot4.x, g + kP * Q + 0, lane);                   \
-                    rowbuf = park_total(rowbuf, tot4.y, g + kP * Q + 1, lane);                   \
-                    rowbuf = park_total(rowbuf, tot4.z, g + kP * Q + 2, lane);                   \
-                    rowbuf = park_total(rowbuf, tot4.w, g + kP * Q + 3, lane);                   \
-                }
-                S2R_QUAD(0) S2R_QUAD(1) S2R_QUAD(2) S2R_QUAD(3)
+                        f4 out4;                                                                 \
+                        _Pragma("unroll")                                                        \
+                        for (int j = 0; j < kP; ++j) {                                           \
+                            FrameCF c1; c1.amp = c4.amp[j]; c1.xc = c4.xc[j]; c1.nz = c4.nz[j];  \
+                            OscK k1 = k_const;                                                   \
+                            if (FM) { k1.period = k4.period[j]; k1.inv_period = k4.inv_period[j]; \
+                                      k1.a = k4.a[j]; k1.b = k4.b[j]; k1.c = k4.c[j]; }          \
+                            const float o = S2R_RECUR(OSC, p, r, c1, k1, sSin);                  \
+                            out4[j] = live ? o : 0.0f;                                           \
+                        }                                                                        \
+                        if (p.per_voice) { if (pv_lane) {                                        \
+                            float *dst = p.per_voice + pv_base + sc0 + g + kP * Q;               \
+                            dst[0] = out4.x; dst[1] = out4.y; dst[2] = out4.z; dst[3] = out4.w; } } \
+                        S2R_ABLATE_MIX_BEGIN                                                     \
+                        float *trow = tile + ((g + kP * Q) & 15u) * (VW + 1) + col;              \
+                        trow[0 * (VW + 1)] = out4.x; trow[1 * (VW + 1)] = out4.y;                \
+                        trow[2 * (VW + 1)] = out4.z; trow[3 * (VW + 1)] = out4.w;                \
+                        S2R_ABLATE_MIX_END                                                       \
+                    }
+                    S2R_QUAD(0) S2R_QUAD(1) S2R_QUAD(2) S2R_QUAD(3)
 #undef S2R_QUAD
+                }
+                reduce_chunk(c16, kChunk);
             }
-            for (uint32_t i = n_x16; i < n_sc; ++i) {                    // scalar tail (< 16 frames, last super-chunk)
-                float out = frame_sisd<OSC>(p, r, r.offset + sc0 + i, sT, sSin);
-                out = live ? out : 0.0f;
-                if (p.per_voice) { if (pv_lane) p.per_voice[pv_base + sc0 + i] = out; }
-                const float tot = wave_sum_lane63<L>(out);
-                rowbuf = park_total(rowbuf, tot, i, lane);
+            if (n_x16 < n_sc) {                                          // scalar tail (< 16 frames, last super-chunk)
+                for (uint32_t i = n_x16; i < n_sc; ++i) {
+                    float out = frame_sisd<OSC>(p, r, r.offset + sc0 + i, sT, sSin);
+                    out = live ? out : 0.0f;
+                    if (p.per_voice) { if (pv_lane) p.per_voice[pv_base + sc0 + i] = out; }
+                    tile[(i - n_x16) * (VW + 1) + col] = out;
+                }
+                reduce_chunk(n_x16, n_sc - n_x16);
             }
-        } else if (p.per_voice) {
-            if (pv_lane) for (uint32_t i = 0; i < n_sc; ++i) p.per_voice[pv_base + sc0 + i] = 0.0f;
+        } else {
+            for (uint32_t i = lane; i < GW * kSuper; i += 64u)
+                sW[(buf * n_groups + wave * GW + i / kSuper) * kSuper + (i % kSuper)] = 0.0f;
+            if (p.per_voice) { if (pv_lane) for (uint32_t i = 0; i < n_sc; ++i) p.per_voice[pv_base + sc0 + i] = 0.0f; }
         }
-        sW[buf][wave][lane] = rowbuf;
+#if defined(S2R_ABLATE_BARRIER)
+        if (false) {
+#else
         __syncthreads();
         if (tid < n_sc) {
-            // 64-voice sums first (L waves each, pairwise), then those in order: the same tree
-            // for every L (oracle/s2_oracle.c: block_partial)
-            float acc = 0.0f;
-            for (uint32_t w = 0; w < n_waves; w += L) {
-                float s64;
-                if (L == 1) s64 = sW[buf][w][tid];
-                else if (L == 2) s64 = sW[buf][w][tid] + sW[buf][w + 1][tid];
-                else s64 = (sW[buf][w][tid] + sW[buf][w + 1][tid]) + (sW[buf][w + 2][tid] + sW[buf][w + 3][tid]);
-                acc = (w == 0) ? s64 : acc + s64;
-            }
+#endif
+            // the block's 16-voice group sums, in group (= voice index) order
+            float acc = sW[(buf * n_groups + 0) * kSuper + tid];
+            for (uint32_t gq = 1; gq < n_groups; ++gq) acc += sW[(buf * n_groups + gq) * kSuper + tid];
             bp[sc0 + tid] = acc;
         }
         buf ^= 1u;
@@ -651,10 +685,21 @@ template <int OSC, bool FM, bool FASTDIV>
 hipError_t launch_l(const S2rRenderParams &p, uint32_t block_voices, uint32_t lanes, hipStream_t stream) {
     const uint32_t grid = (p.n_voices + block_voices - 1) / block_voices;
     const dim3 block(block_voices * lanes);
+    const uint32_t n_waves = block_voices * lanes / 64, vw = 64 / lanes, n_groups = n_waves * (vw / 16);
+    const size_t lds = sizeof(float) * ((size_t)2 * n_groups * kSuper + (size_t)n_waves * kChunk * (vw + 1));
+    // the launch bound is the register budget: 256-thread workgroups (one wave per SIMD) may use
+    // the whole file, which the 4-frame vector code wants; bigger workgroups get what is left
+    const uint32_t threads = block_voices * lanes;
     switch (lanes) {
-    case 1: hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, FASTDIV, 1>), dim3(grid), block, 0, stream, p); break;
-    case 2: hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, FASTDIV, 2>), dim3(grid), block, 0, stream, p); break;
-    case 4: hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, FASTDIV, 4>), dim3(grid), block, 0, stream, p); break;
+    case 1:
+        if (threads <= 256) hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, FASTDIV, 1, 256>), dim3(grid), block, lds, stream, p);
+        else hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, FASTDIV, 1, 1024>), dim3(grid), block, lds, stream, p);
+        break;
+    case 2:
+        if (threads <= 512) hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, FASTDIV, 2, 512>), dim3(grid), block, lds, stream, p);
+        else hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, FASTDIV, 2, 1024>), dim3(grid), block, lds, stream, p);
+        break;
+    case 4: hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, FASTDIV, 4, 1024>), dim3(grid), block, lds, stream, p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -42,10 +42,12 @@ def lcg(seed):
 class Pair:
     """An oracle synth and a GPU synth driven in lockstep."""
 
-    def __init__(self, num_voices, patch=None, max_frames=2048, block_voices=0, mix_groups=0, seeds=None, lanes=0):
+    def __init__(self, num_voices, patch=None, max_frames=2048, block_voices=0, mix_groups=0, seeds=None, lanes=0, flat_shortcut=True):
         self.gpu = s2.Synth(num_voices, max_frames=max_frames, block_voices=block_voices, mix_groups=mix_groups,
                             lanes_per_voice=lanes)
         self.cpu = s2o.OracleSynth(num_voices)
+        if not flat_shortcut:
+            self.gpu.set_flat_shortcut(False)
         self.block_voices = self.gpu.block_voices
         self.groups = mix_groups or 1
         self.seeds = seeds

@@ -75,6 +75,28 @@ def test_c2_1024_voices_blocks_of_256(lanes):
     _run_c2(block_voices=256, lanes=lanes)
 
 
+@pytest.mark.parametrize("fm", [0.0, -2.0])
+@pytest.mark.parametrize("flat", [True, False])
+def test_flat_envelope_shortcut_is_bit_neutral(flat, fm):
+    """the LPF-coefficient reuse while the mod envelope is flat (sustain / end stage) must not
+    change a bit; exercised with voices entering and leaving flat stages at different times,
+    a non-zero sustain, and FM so the cached oscillator constants are used too"""
+    patch = make_patch(mod_env_to_osc_freq=fm)
+    patch.mod_env.attack_ms = 2.0
+    patch.mod_env.decay_ms = 10.0
+    patch.mod_env.sustain = 0.25
+    patch.mod_env.release_ms = 15.0
+    pr = Pair(256, patch, flat_shortcut=flat)
+    for b in range(12):
+        for v in range(16):
+            pr.note_on(36 + (b * 16 + v) % 61)
+        if b >= 3:
+            for n in range(36, 97, 5):
+                pr.note_off(n + b % 5)
+        g, o, _pv = pr.sample(512)
+        assert_bits_equal(g, o, "flat=%s fm=%g buffer %d" % (flat, fm, b))
+
+
 def test_sample_rate_without_fast_division():
     """a rate outside the verified whitelist takes the true-division kernel variant"""
     pr = Pair(64)
