@@ -56,6 +56,16 @@ struct S2rRenderParams {
     float *block_partials;   // [n_blocks][frames_stride]
     float *per_voice;        // [n_voices][frames] or nullptr (mix-disabled debug/parity path)
     const float *sin_table;  // 1024 floats (tables.rs)
+    // coefficient stream: LPF coefficients of the 64-voice groups whose mod
+    // envelope moves during this fill, computed ahead of the render kernel by s2r_coeff_kernel
+    int32_t use_coeff;          // 0: never look at the stream
+    const int32_t *group_slot;  // [n_groups64] stream slot of each 64-voice group, -1 = none
+    int32_t *group_slot_w;      // same array, writable (classify kernel)
+    uint32_t *slot_group;       // [coeff_capacity] inverse map
+    uint32_t *coeff_count;      // [2] slots handed out this fill (index = coeff_parity), next fill's is zeroed
+    uint32_t coeff_parity;
+    uint32_t coeff_capacity;    // slots the stream buffer holds; more moving groups => in-lane path
+    float *coeff;               // [slot][quad][64][4]
 };
 
 // Coalesced note events, one record per touched voice per fill (host folds the event
@@ -81,6 +91,7 @@ struct S2rMixParams {
     float *out;
 };
 
+hipError_t s2r_launch_coeff(const S2rRenderParams &p, hipStream_t stream);   // classify + coefficient pass
 hipError_t s2r_launch_render(const S2rRenderParams &p, uint32_t block_voices, uint32_t lanes_per_voice, hipStream_t stream);
 hipError_t s2r_launch_mix(const S2rMixParams &p, hipStream_t stream);
 hipError_t s2r_launch_events(const S2rVoiceArrays &v, const S2rVoiceEvent *dev_events, uint32_t n, hipStream_t stream);

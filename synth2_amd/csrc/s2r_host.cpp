@@ -116,6 +116,9 @@ struct s2r_synth {
     float *out_host = nullptr;                   // pinned, 2*max_frames
     float *sin_dev = nullptr;
     float *per_voice_dev = nullptr; size_t per_voice_cap = 0;
+    // coefficient stream (s2r_kernels.hip)
+    int32_t *group_slot = nullptr; uint32_t *slot_group = nullptr; uint32_t *coeff_count = nullptr; float *coeff = nullptr;
+    uint32_t coeff_capacity = 0, coeff_parity = 0; bool use_coeff = true;
     float pitch_table[256];
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool timing = false, timed = false, no_flat_shortcut = false;
@@ -205,6 +208,11 @@ S2rRenderParams make_params(s2r_synth *s, size_t frames, uint32_t sample_rate) {
     p.block_partials = s->block_partials;
     p.per_voice = nullptr;
     p.sin_table = s->sin_dev;
+    // stream only where it is defined: no oscillator FM, the flat-envelope logic enabled
+    p.use_coeff = (s->use_coeff && !s->no_flat_shortcut && s->patch.mod_env_to_osc_freq == 0.0f && s->coeff != nullptr) ? 1 : 0;
+    p.group_slot = s->group_slot; p.group_slot_w = s->group_slot; p.slot_group = s->slot_group;
+    p.coeff_count = s->coeff_count; p.coeff_parity = s->coeff_parity; p.coeff_capacity = s->coeff_capacity;
+    p.coeff = s->coeff;
     return p;
 }
 
@@ -216,6 +224,12 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
     S2rRenderParams p = make_params(s, frames, sample_rate);
     p.per_voice = per_voice_dev;
     if (s->timing) S2R_HIP(s, hipEventRecord(s->t0, stream));
+    if (p.use_coeff && frames >= 16) {
+        S2R_HIP(s, s2r_launch_coeff(p, stream));
+        s->coeff_parity ^= 1u;
+    } else {
+        p.use_coeff = 0;       // nothing was prepared for this fill
+    }
     S2R_HIP(s, s2r_launch_render(p, s->block_voices, s->lanes, stream));
     if (s->timing) { S2R_HIP(s, hipEventRecord(s->t1, stream)); s->timed = true; }
     if (dev_out) {
@@ -265,6 +279,10 @@ void release_all(s2r_synth *s) {
     if (s->out_host) (void)hipHostFree(s->out_host);
     if (s->sin_dev) (void)hipFree(s->sin_dev);
     if (s->per_voice_dev) (void)hipFree(s->per_voice_dev);
+    if (s->group_slot) (void)hipFree(s->group_slot);
+    if (s->slot_group) (void)hipFree(s->slot_group);
+    if (s->coeff_count) (void)hipFree(s->coeff_count);
+    if (s->coeff) (void)hipFree(s->coeff);
     if (s->t0) (void)hipEventDestroy(s->t0);
     if (s->t1) (void)hipEventDestroy(s->t1);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -366,6 +384,21 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
         CREATE_HIP(hipHostMalloc((void **)&sl.host, (size_t)shard_voices * sizeof(S2rVoiceEvent), hipHostMallocDefault));
         CREATE_HIP(hipMalloc((void **)&sl.dev, (size_t)shard_voices * sizeof(S2rVoiceEvent)));
         CREATE_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    }
+    {
+        // coefficient stream: room for half of the 64-voice groups (beyond that the in-lane path is
+        // at least as good); [slot][max_frames/4][64] float4
+        const uint32_t n_groups64 = (shard_voices + 63u) / 64u;
+        s->coeff_capacity = n_groups64 > 1 ? n_groups64 / 2 : 1;
+        // one entry per 64 lanes of the PADDED voice range: the render kernel's padding waves look
+        // their (non-existent) group up too and must find -1
+        const size_t n_slots_padded = s->padded_voices / 64u + 1u;
+        CREATE_HIP(hipMalloc((void **)&s->group_slot, n_slots_padded * sizeof(int32_t)));
+        CREATE_HIP(hipMemsetAsync(s->group_slot, 0xff, n_slots_padded * sizeof(int32_t), s->stream));
+        CREATE_HIP(hipMalloc((void **)&s->slot_group, s->coeff_capacity * sizeof(uint32_t)));
+        CREATE_HIP(hipMalloc((void **)&s->coeff_count, 2 * sizeof(uint32_t)));
+        CREATE_HIP(hipMemsetAsync(s->coeff_count, 0, 2 * sizeof(uint32_t), s->stream));
+        CREATE_HIP(hipMalloc((void **)&s->coeff, (size_t)s->coeff_capacity * cfg->max_frames * 64 * sizeof(float)));
     }
     CREATE_HIP(hipEventCreate(&s->t0));
     CREATE_HIP(hipEventCreate(&s->t1));
@@ -572,6 +605,12 @@ uint64_t s2r_double_release_count(const s2r_synth *s) { return s ? s->double_rel
 int s2r_set_flat_shortcut(s2r_synth *s, int enabled) {
     if (!s) return S2R_ERR_INVALID;
     s->no_flat_shortcut = enabled == 0;
+    return S2R_OK;
+}
+
+int s2r_set_coeff_stream(s2r_synth *s, int enabled) {
+    if (!s) return S2R_ERR_INVALID;
+    s->use_coeff = enabled != 0;
     return S2R_OK;
 }
 

@@ -344,7 +344,7 @@ __device__ __forceinline__ FlatCache refresh_flat(const S2rRenderParams &p, cons
 template <int OSC, bool FM, bool FASTDIV>
 __device__ __forceinline__ void closed_form_x4(const S2rRenderParams &p, const VoiceRegs &r, EnvRun &ea, EnvRun &em,
                                                float &thr_min, FlatCache &fc, uint32_t oi, const uint64_t *sT,
-                                               FrameCF4 &cf, OscK4 &k) {
+                                               bool have_stream, f4 stream_xc, FrameCF4 &cf, OscK4 &k) {
     const u4 ou = (u4)(oi) + (u4){0u, 1u, 2u, 3u};               // offsets_x16: wrapping u32 add (process.rs:213-219)
     const f4 t = __builtin_convertvector(ou, f4);                // offsets as f32 (simdtest.rs:277-279, process.rs:348)
     // fast path first: the active stages' lines for all four frames
@@ -378,6 +378,10 @@ __device__ __forceinline__ void closed_form_x4(const S2rRenderParams &p, const V
 #else
     cf.nz = hash_noise4(r.seed_rot, t) + splat(p.noise_level);   // process.rs:347-356 (ADD)
 #endif
+    if (have_stream) {             // wave-uniform: this 64-voice group's coefficients were computed ahead
+        cf.xc = stream_xc;
+        return;
+    }
     moving = moving || em.slope != 0.0f;
     if (__ballot(moving) == 0ull) {
         // every voice of this wave has a flat mod envelope over these four frames
@@ -443,6 +447,88 @@ __device__ __forceinline__ f4 bcast_sub4(f4 v) {
     f4 r;
     r.x = bcast_sub<L, K>(v.x); r.y = bcast_sub<L, K>(v.y); r.z = bcast_sub<L, K>(v.z); r.w = bcast_sub<L, K>(v.w);
     return r;
+}
+
+// ---------------------------------------------------------------------------------------
+// Coefficient stream.  The render kernel is one wave per SIMD at 64 k voices, so its duration is
+// that of its SLOWEST wave: a few 64-voice groups whose mod envelope is moving (full pow/exp
+// chain every frame) hold back a chip of waves that only reuse a constant.  The LPF coefficient
+// is closed-form in the frame offset, so for exactly those groups it is computed ahead of time,
+// spread over the whole GPU ((group, 16-quad chunk) work items, four frames per lane as in the
+// render kernel), into an HBM/L2-resident stream that the render kernel then just reads.
+//   s2r_classify_kernel: one wave per 64-voice group; a group gets a slot iff some live voice's
+//     mod envelope is not provably flat for the whole fill.
+//   s2r_coeff_kernel:    persistent-style grid over (slot, chunk of 16 quads).
+// If more groups move than the buffer holds (count > capacity) nobody uses the stream and the
+// render kernel computes in-lane as before.  Not used under oscillator FM.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) s2r_classify_kernel(const S2rRenderParams p) {
+    const uint32_t group = blockIdx.x, lane = threadIdx.x;
+    const uint32_t vi = group * 64u + lane;
+    if (group == 0 && lane == 0) p.coeff_count[p.coeff_parity ^ 1u] = 0u;       // ready for the next fill
+    bool moving = false;
+    if (vi < p.n_voices) {
+        const uint32_t flags = p.v.flags[vi];
+        if (flags & S2R_VF_STARTED) {
+            const uint32_t offset = p.v.offset[vi];
+            const float rel_f = (flags & S2R_VF_RELEASED) ? (float)p.v.release[vi] : 4294967296.0f;
+            const float ro_m = __builtin_fmaxf(rel_f, p.mod.sus_off), end_m = ro_m + p.mod.R;
+            const EnvRun e0 = env_stage_at(p.mod, ro_m, end_m, (float)offset);
+            const float t_last = (float)(offset + (p.frames - 1u));
+            moving = !(e0.slope == 0.0f && t_last < e0.thr);
+        }
+    }
+    const bool any = __ballot(moving) != 0ull;
+    if (lane == 0) {
+        int32_t slot = -1;
+        if (any) {
+            const uint32_t s = atomicAdd(&p.coeff_count[p.coeff_parity], 1u);
+            if (s < p.coeff_capacity) { slot = (int32_t)s; p.slot_group[s] = group; }
+        }
+        p.group_slot_w[group] = slot;
+    }
+}
+
+template <bool FASTDIV>
+__global__ void __launch_bounds__(256) s2r_coeff_kernel(const S2rRenderParams p) {
+    __shared__ uint64_t sT[S2R_EXP2F_N];
+    if (threadIdx.x < S2R_EXP2F_N) sT[threadIdx.x] = c_exp2f_table[threadIdx.x];
+    __syncthreads();
+    const uint32_t count = p.coeff_count[p.coeff_parity];
+    if (count == 0u || count > p.coeff_capacity) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t n_quads = (p.frames & ~15u) / kP;
+    constexpr uint32_t kQuadsPerItem = 16;
+    const uint32_t chunks = (n_quads + kQuadsPerItem - 1) / kQuadsPerItem;
+    const uint32_t n_items = count * chunks;
+    for (uint32_t it = blockIdx.x * 4u + wave; it < n_items; it += gridDim.x * 4u) {
+        const uint32_t slot = it / chunks, chunk = it % chunks;
+        const uint32_t vi = p.slot_group[slot] * 64u + lane;
+        const bool in_range = vi < p.n_voices;
+        const uint32_t flags = in_range ? p.v.flags[vi] : 0u;
+        const uint32_t offset = in_range ? p.v.offset[vi] : 0u;
+        const float rel_f = (flags & S2R_VF_RELEASED) ? (float)p.v.release[vi] : 4294967296.0f;
+        const float ro_m = __builtin_fmaxf(rel_f, p.mod.sus_off), end_m = ro_m + p.mod.R;
+        EnvRun em = env_stage_at(p.mod, ro_m, end_m, 0.0f);
+        float thr = -__builtin_inff();
+        f4 *dst = (f4 *)p.coeff + ((size_t)slot * n_quads + (size_t)chunk * kQuadsPerItem) * 64u + lane;
+        const uint32_t q1 = (chunk + 1) * kQuadsPerItem < n_quads ? kQuadsPerItem : n_quads - chunk * kQuadsPerItem;
+        for (uint32_t q = 0; q < q1; ++q) {
+            const uint32_t oi = offset + (chunk * kQuadsPerItem + q) * kP;
+            const u4 ou = (u4)(oi) + (u4){0u, 1u, 2u, 3u};
+            const f4 t = __builtin_convertvector(ou, f4);
+            f4 mod = splat(em.slope) * (t - splat(em.base)) + splat(em.y0);
+            if (!(t.w < thr)) {          // a stage boundary inside (or before) these frames: frame by frame
+#define S2R_STEP(C) { if (!(t.C < thr)) { em = env_stage_at(p.mod, ro_m, end_m, t.C); thr = em.thr; } mod.C = env_value(em, t.C); }
+                S2R_STEP(x) S2R_STEP(y) S2R_STEP(z) S2R_STEP(w)
+#undef S2R_STEP
+            }
+            const f4 f_lpf = pow2_sleef_core4(mod * splat(p.amt_lpf)) * splat(p.lpf_freq);
+            const f4 num = splat(-2.0f * 3.14159274101257324f) * f_lpf;
+            const f4 arg = FASTDIV ? div_const_nocheck4(num, p.sr, p.rcp_sr) : (num / splat(p.sr));
+            dst[(size_t)q * 64u] = expf4(arg, sT);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -513,6 +599,14 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
 
     const bool wave_live = __ballot(live) != 0ull;
     const uint32_t x16_frames = p.frames & ~(uint32_t)(kChunk - 1);      // frames in full 16-chunks
+    // coefficient stream for this wave's 64-voice group, if one was prepared (wave-uniform)
+    int32_t slot = -1;
+    if (!FM && p.use_coeff && p.coeff_count[p.coeff_parity] <= p.coeff_capacity)
+        slot = p.group_slot[__builtin_amdgcn_readfirstlane((blockIdx.x * block_voices + tid / L) / 64u)];
+    const bool have_stream = slot >= 0;
+    const f4 *stream = (const f4 *)p.coeff + ((size_t)(have_stream ? slot : 0) * (x16_frames / kP)) * 64u + ((tid / L) & 63u);
+    f4 xc_next = splat(0.0f);
+    if (have_stream && x16_frames) xc_next = stream[(size_t)sub * 64u];
     const size_t pv_base = (size_t)vi * p.frames;
     const bool pv_lane = in_range && sub == 0;
     float *bp = p.block_partials + (size_t)blockIdx.x * p.frames_stride;
@@ -544,7 +638,13 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
                 for (uint32_t g = c16; g < c16 + kChunk; g += G) {
                     // closed-form work of frames sc0+g+4*sub .. +3 on this lane
                     FrameCF4 cf; OscK4 kf;
-                    closed_form_x4<OSC, FM, FASTDIV>(p, r, ea, em, thr_min, fc, r.offset + sc0 + g + kP * sub, sT, cf, kf);
+                    const f4 xc_now = xc_next;
+                    if (have_stream) {       // prefetch the next group's quadruple while this one is consumed
+                        const uint32_t qn = (sc0 + g + G) / kP + sub;
+                        if (qn < x16_frames / kP) xc_next = stream[(size_t)qn * 64u];
+                    }
+                    closed_form_x4<OSC, FM, FASTDIV>(p, r, ea, em, thr_min, fc, r.offset + sc0 + g + kP * sub, sT,
+                                                     have_stream, xc_now, cf, kf);
                     // recurrence for the 4*L frames of the group, every lane of the voice alike
 #define S2R_QUAD(Q)                                                                              \
                     if constexpr (Q < L) {                                                       \
@@ -715,6 +815,15 @@ hipError_t launch_osc(const S2rRenderParams &p, uint32_t block_voices, uint32_t 
 }
 
 }  // namespace
+
+hipError_t s2r_launch_coeff(const S2rRenderParams &p, hipStream_t stream) {
+    if (!p.use_coeff || p.n_voices == 0 || p.frames < 16u) return hipSuccess;
+    const uint32_t n_groups64 = (p.n_voices + 63u) / 64u;
+    hipLaunchKernelGGL(s2r_classify_kernel, dim3(n_groups64), dim3(64), 0, stream, p);
+    if (p.fast_div_sr) hipLaunchKernelGGL(s2r_coeff_kernel<true>, dim3(2048), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(s2r_coeff_kernel<false>, dim3(2048), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
 
 hipError_t s2r_launch_render(const S2rRenderParams &p, uint32_t block_voices, uint32_t lanes_per_voice, hipStream_t stream) {
     if (p.n_voices == 0 || p.frames == 0) return hipSuccess;

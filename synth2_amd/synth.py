@@ -139,6 +139,7 @@ def load_library():
         "s2r_double_release_count": (C.c_uint64, [H]),
         "s2r_set_timing": (C.c_int, [H, C.c_int]),
         "s2r_set_flat_shortcut": (C.c_int, [H, C.c_int]),
+        "s2r_set_coeff_stream": (C.c_int, [H, C.c_int]),
         "s2r_last_render_ms": (C.c_float, [H]),
         "s2r_last_error": (C.c_char_p, [H]),
         "s2r_parse_patch_text": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(Patch), C.c_char_p, C.c_size_t]),
@@ -321,6 +322,9 @@ class Synth:
 
     def set_flat_shortcut(self, enabled=True):
         self._check(self.L.s2r_set_flat_shortcut(self.h, 1 if enabled else 0))
+
+    def set_coeff_stream(self, enabled=True):
+        self._check(self.L.s2r_set_coeff_stream(self.h, 1 if enabled else 0))
 
     def set_timing(self, enabled=True):
         self._check(self.L.s2r_set_timing(self.h, 1 if enabled else 0))

@@ -75,6 +75,41 @@ def test_c2_1024_voices_blocks_of_256(lanes):
     _run_c2(block_voices=256, lanes=lanes)
 
 
+@pytest.mark.parametrize("lanes", [1, 2, 4])
+@pytest.mark.parametrize("stream", [True, False])
+def test_coefficient_stream_is_bit_neutral(stream, lanes):
+    """64-voice groups with a moving mod envelope get their LPF coefficients from the ahead-of-time
+    pass; with it off they are computed in-lane.  Mixed population: some groups fully flat, some
+    partly moving, some restarted mid-run, ragged fills (tail frames bypass the stream)."""
+    V = 1024
+    pr = Pair(V, lanes=lanes, max_frames=1024)
+    if not stream:
+        pr.gpu.set_coeff_stream(False)
+    for v in range(V):
+        pr.note_on(36 + v % 61)
+    for b, n in enumerate([1024, 1024, 512, 1000, 1024, 16, 1024, 1024, 1024, 1024, 1024, 1024]):
+        if b in (3, 5, 8, 10):
+            for k in range(40):              # restart the 40 oldest voices: their groups start moving again
+                pr.note_on(40 + (k + b) % 50)
+        if b == 6:
+            for note in range(36, 97, 3):
+                pr.note_off(note)
+        g, o, _pv = pr.sample(n)
+        assert_bits_equal(g, o, "stream=%s lanes=%d buffer %d" % (stream, lanes, b))
+
+
+def test_coefficient_stream_overflow_falls_back():
+    """more moving groups than the stream holds (capacity = half the groups): everything is
+    computed in-lane, same bits"""
+    V = 512
+    pr = Pair(V)
+    for v in range(V):
+        pr.note_on(36 + v % 61)          # all 8 groups moving for the first 9600 frames
+    for b in range(3):
+        g, o, _pv = pr.sample(1024)
+        assert_bits_equal(g, o, "overflow buffer %d" % b)
+
+
 @pytest.mark.parametrize("fm", [0.0, -2.0])
 @pytest.mark.parametrize("flat", [True, False])
 def test_flat_envelope_shortcut_is_bit_neutral(flat, fm):
