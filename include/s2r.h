@@ -141,6 +141,9 @@ int s2r_fill_stereo(s2r_synth *s, float *interleaved_lr_out, size_t frames, uint
  * be NULL) without synchronising.  Partials of all shards are then combined in rank order
  * by s2r_sum_partials_device. */
 int s2r_fill_device(s2r_synth *s, float *dev_partial_out, size_t frames, uint32_t sample_rate_hz, void *hip_stream);
+/* Single-shard form of the above: the FINAL mix (root-added, exactly what s2r_fill returns)
+ * left in device memory on `hip_stream`, no synchronisation. */
+int s2r_fill_device_root(s2r_synth *s, float *dev_out, size_t frames, uint32_t sample_rate_hz, void *hip_stream);
 /* out[i] = ((+0.0 + rows[0][i]) + rows[1][i]) + ...   rows is [n_rows][frames] on device. */
 int s2r_sum_partials_device(const float *dev_rows, uint32_t n_rows, size_t frames, float *dev_out, void *hip_stream);
 

@@ -165,7 +165,8 @@ int flush_events(s2r_synth *s, hipStream_t stream) {
     if (sl.in_flight) { S2R_HIP(s, hipEventSynchronize(sl.done)); sl.in_flight = false; }
     const uint32_t n = (uint32_t)s->pending.size();
     std::memcpy(sl.host, s->pending.data(), n * sizeof(S2rVoiceEvent));
-    S2R_HIP(s, hipMemcpyAsync(sl.dev, sl.host, n * sizeof(S2rVoiceEvent), hipMemcpyHostToDevice, stream));
+    // the kernel reads the pinned (device-mapped) host buffer directly: a few KB over PCIe inside
+    // the kernel instead of a separate copy node in front of it
     S2R_HIP(s, s2r_launch_events(s->v, sl.dev, n, stream));
     S2R_HIP(s, hipEventRecord(sl.done, stream));
     sl.in_flight = true;
@@ -270,7 +271,6 @@ void release_all(s2r_synth *s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (EventSlot &sl : s->slots) {
         if (sl.host) (void)hipHostFree(sl.host);
-        if (sl.dev) (void)hipFree(sl.dev);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     if (s->voice_mem) (void)hipFree(s->voice_mem);
@@ -381,8 +381,8 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
     CREATE_HIP(hipMalloc((void **)&s->out_dev, (size_t)2 * cfg->max_frames * sizeof(float)));
     CREATE_HIP(hipHostMalloc((void **)&s->out_host, (size_t)2 * cfg->max_frames * sizeof(float), hipHostMallocDefault));
     for (EventSlot &sl : s->slots) {
-        CREATE_HIP(hipHostMalloc((void **)&sl.host, (size_t)shard_voices * sizeof(S2rVoiceEvent), hipHostMallocDefault));
-        CREATE_HIP(hipMalloc((void **)&sl.dev, (size_t)shard_voices * sizeof(S2rVoiceEvent)));
+        CREATE_HIP(hipHostMalloc((void **)&sl.host, (size_t)shard_voices * sizeof(S2rVoiceEvent), hipHostMallocMapped));
+        CREATE_HIP(hipHostGetDevicePointer((void **)&sl.dev, sl.host, 0));
         CREATE_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     }
     {
@@ -503,6 +503,15 @@ int s2r_fill_device(s2r_synth *s, float *dev_partial_out, size_t frames, uint32_
     if (!dev_partial_out) return set_err(s, S2R_ERR_INVALID, "null device output buffer");
     S2R_HIP(s, hipSetDevice(s->device));
     return enqueue_fill(s, frames, sample_rate_hz, (hipStream_t)hip_stream, dev_partial_out, false, false, nullptr);
+}
+
+int s2r_fill_device_root(s2r_synth *s, float *dev_out, size_t frames, uint32_t sample_rate_hz, void *hip_stream) {
+    int rc = check_fill(s, frames, sample_rate_hz);
+    if (rc != S2R_OK) return rc;
+    if (frames == 0) return S2R_OK;
+    if (!dev_out) return set_err(s, S2R_ERR_INVALID, "null device output buffer");
+    S2R_HIP(s, hipSetDevice(s->device));
+    return enqueue_fill(s, frames, sample_rate_hz, (hipStream_t)hip_stream, dev_out, true, false, nullptr);
 }
 
 int s2r_sum_partials_device(const float *dev_rows, uint32_t n_rows, size_t frames, float *dev_out, void *hip_stream) {

@@ -244,7 +244,11 @@ __device__ __forceinline__ float osc_value(const OscK &k, float off, const float
     // offset % period: `off` itself while 0 <= off < period (one unsigned compare on the bit
     // patterns, see s2r_fmod_period); the exact library fmodf only if some lane of the wave needs it
     float x = off;
+#if defined(S2R_ABLATE_COLD)
+    const bool slow = false;
+#else
     const bool slow = !(s2r_f2u(off) < s2r_f2u(k.period) && k.period > 0.0f);
+#endif
     if (__builtin_expect(__ballot(slow) != 0ull, 0)) { if (slow) x = ::fmodf(off, k.period); }
     if (OSC == S2R_OSC_SAW) {
         return __builtin_fmaf(k.a, x, 1.0f);
@@ -351,7 +355,11 @@ __device__ __forceinline__ void closed_form_x4(const S2rRenderParams &p, const V
     f4 amp = splat(ea.slope) * (t - splat(ea.base)) + splat(ea.y0);           // process.rs:144
     f4 mod = splat(em.slope) * (t - splat(em.base)) + splat(em.y0);           // process.rs:145
     bool moving = p.no_flat_shortcut != 0;
+#if defined(S2R_ABLATE_COLD)
+    const bool cold = false;
+#else
     const bool cold = !(t.w < thr_min);
+#endif
     if (__builtin_expect(__ballot(cold) != 0ull, 0)) {      // wave-uniform branch: no exec juggling when nobody is cold
         if (cold) {
             // an envelope stage ends inside these four frames: walk them one by one
@@ -734,14 +742,14 @@ __global__ void s2r_mix_kernel(const S2rMixParams m) {
         uint32_t b1 = b0 + m.blocks_per_group;
         if (b1 > m.n_blocks) b1 = m.n_blocks;
         if (b0 >= b1) continue;
-        // the adds are sequential by specification; the loads are not, so fetch 16 rows at a time
+        // the adds are sequential by specification; the loads are not, so fetch 64 rows at a time
         float acc = 0.0f;
-        for (uint32_t b = b0; b < b1; b += 16) {
-            float v[16];
+        for (uint32_t b = b0; b < b1; b += 64) {
+            float v[64];
 #pragma unroll
-            for (uint32_t j = 0; j < 16; ++j) v[j] = (b + j < b1) ? m.block_partials[(size_t)(b + j) * m.frames_stride + f] : 0.0f;
+            for (uint32_t j = 0; j < 64; ++j) v[j] = (b + j < b1) ? m.block_partials[(size_t)(b + j) * m.frames_stride + f] : 0.0f;
 #pragma unroll
-            for (uint32_t j = 0; j < 16; ++j) if (b + j < b1) acc = (b + j == b0) ? v[j] : acc + v[j];
+            for (uint32_t j = 0; j < 64; ++j) if (b + j < b1) acc = (b + j == b0) ? v[j] : acc + v[j];
         }
         total = (m.root_add || g > 0) ? total + acc : acc;
     }
@@ -840,7 +848,7 @@ hipError_t s2r_launch_render(const S2rRenderParams &p, uint32_t block_voices, ui
 
 hipError_t s2r_launch_mix(const S2rMixParams &m, hipStream_t stream) {
     if (m.frames == 0) return hipSuccess;
-    hipLaunchKernelGGL(s2r_mix_kernel, dim3((m.frames + 255) / 256), dim3(256), 0, stream, m);
+    hipLaunchKernelGGL(s2r_mix_kernel, dim3((m.frames + 63) / 64), dim3(64), 0, stream, m);
     return hipGetLastError();
 }
 

@@ -76,6 +76,10 @@ class ShardedSynth:
         slot = self._k & 1
         self._k += 1
         part = self.partial[slot]
+        if self.world == 1 and hasattr(self.renderer, "fill_device_root") and self.combine == self._combine_hip:
+            # one shard: its mix kernel roots the sum itself ((+0.0) + total), no combine pass
+            self.renderer.fill_device_root(self.mix.data_ptr(), frames, sample_rate, self._stream_ptr())
+            return
         self.renderer.fill_device(part.data_ptr(), frames, sample_rate, self._stream_ptr())
         if self.world == 1:
             self.combine(part, 1, frames, self.mix)

@@ -128,6 +128,7 @@ def load_library():
         "s2r_fill": (C.c_int, [H, _f32p, C.c_size_t, C.c_uint32]),
         "s2r_fill_stereo": (C.c_int, [H, _f32p, C.c_size_t, C.c_uint32]),
         "s2r_fill_device": (C.c_int, [H, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
+        "s2r_fill_device_root": (C.c_int, [H, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
         "s2r_sum_partials_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_size_t, C.c_void_p, C.c_void_p]),
         "s2r_render_voices": (C.c_int, [H, _f32p, C.c_size_t, C.c_uint32]),
         "s2r_export_state": (C.c_int, [H, C.c_void_p]),
@@ -305,6 +306,11 @@ class Synth:
         """Partial mix of this shard into device memory at ``dev_ptr`` on ``stream`` (async)."""
         self._check(self.L.s2r_fill_device(self.h, C.c_void_p(dev_ptr), frames, int(sample_rate),
                                            C.c_void_p(stream) if stream else None))
+
+    def fill_device_root(self, dev_ptr, frames, sample_rate=SampleRateKhz(48000), stream=None):
+        """Final (root-added) mix of a single-shard synth into device memory (async)."""
+        self._check(self.L.s2r_fill_device_root(self.h, C.c_void_p(dev_ptr), frames, int(sample_rate),
+                                                C.c_void_p(stream) if stream else None))
 
     # --- state ---
     def export_state(self):
