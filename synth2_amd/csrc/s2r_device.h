@@ -52,6 +52,7 @@ struct S2rRenderParams {
     uint32_t frames;      // this fill
     uint32_t n_voices;    // shard voices
     uint32_t frames_stride; // row stride of block_partials / per_voice (== max_frames or frames)
+    uint32_t super_frames;  // frames between two cross-wave combines (set by the launcher)
     S2rVoiceArrays v;
     float *block_partials;   // [n_blocks][frames_stride]
     float *per_voice;        // [n_voices][frames] or nullptr (mix-disabled debug/parity path)

@@ -33,7 +33,7 @@ namespace {
 __constant__ uint64_t c_exp2f_table[S2R_EXP2F_N] = S2R_EXP2F_TABLE_INIT;
 
 constexpr int kChunk = 16;         // the reference's x16 chunk (synth.rs:158, process.rs:25)
-constexpr uint32_t kSuper = 64;    // frames between two cross-wave combines (one lane of the row buffer each)
+constexpr uint32_t kSuperMax = 256; // frames between two cross-wave combines: 256 (small workgroups) or 64
 constexpr int kP = 4;              // frames whose closed-form work one lane carries at once (ILP)
 
 // The closed-form part of kP = 4 consecutive frames is evaluated together on 4-wide vectors.
@@ -332,20 +332,20 @@ struct FlatCache {
     OscK k;
 };
 
-template <int OSC, bool FM, bool FASTDIV>
+template <int OSC, bool FM>
 __device__ __forceinline__ FlatCache refresh_flat(const S2rRenderParams &p, const VoiceRegs &r, const EnvRun em,
                                                   const uint64_t *sT, FlatCache fc) {
     if (em.slope == 0.0f) {
         const float mod = em.y0;                                          // 0 * (t - base) + y0 == y0
         const float f_lpf = s2r_pow2_sleef_core(mod * p.amt_lpf) * p.lpf_freq;
-        fc.xc = s2r_expf(lpf_arg<FASTDIV>(p, f_lpf), sT);
+        fc.xc = s2r_expf(p.fast_div_sr ? lpf_arg<true>(p, f_lpf) : lpf_arg<false>(p, f_lpf), sT);
         if (FM) fc.k = make_osck<OSC>(p.sr / (s2r_pow2_sleef_core(mod * p.amt_osc) * r.pitch));
     }
     return fc;
 }
 
 // frames oi .. oi+3 of one voice
-template <int OSC, bool FM, bool FASTDIV>
+template <int OSC, bool FM>
 __device__ __forceinline__ void closed_form_x4(const S2rRenderParams &p, const VoiceRegs &r, EnvRun &ea, EnvRun &em,
                                                float &thr_min, FlatCache &fc, uint32_t oi, const uint64_t *sT,
                                                bool have_stream, f4 stream_xc, FrameCF4 &cf, OscK4 &k) {
@@ -377,7 +377,7 @@ __device__ __forceinline__ void closed_form_x4(const S2rRenderParams &p, const V
             }
             S2R_ENV_STEP(x) S2R_ENV_STEP(y) S2R_ENV_STEP(z) S2R_ENV_STEP(w)
 #undef S2R_ENV_STEP
-            fc = refresh_flat<OSC, FM, FASTDIV>(p, r, em, sT, fc);
+            fc = refresh_flat<OSC, FM>(p, r, em, sT, fc);
         }
     }
     cf.amp = amp;
@@ -400,7 +400,7 @@ __device__ __forceinline__ void closed_form_x4(const S2rRenderParams &p, const V
     }
     const f4 f_lpf = pow2_sleef_core4(mod * splat(p.amt_lpf)) * splat(p.lpf_freq);   // process.rs:148-152
     const f4 num = splat(-2.0f * 3.14159274101257324f) * f_lpf;  // -2.0 * pi * freq   (filters.rs:21)
-    const f4 arg = FASTDIV ? div_const_nocheck4(num, p.sr, p.rcp_sr) : (num / splat(p.sr));
+    const f4 arg = p.fast_div_sr ? div_const_nocheck4(num, p.sr, p.rcp_sr) : (num / splat(p.sr));   // wave-uniform choice
     cf.xc = expf4(arg, sT);
     if (FM) {
         const f4 f_osc = pow2_sleef_core4(mod * splat(p.amt_osc)) * splat(r.pitch);  // process.rs:146-147,231-250
@@ -550,8 +550,9 @@ __global__ void __launch_bounds__(256) s2r_coeff_kernel(const S2rRenderParams p)
 //     wave per SIMD at L = 1) at the price of L x the recurrence work (~10% of a frame).
 //   grid = ceil(n_voices / block_voices), blockDim.x = block_voices * L.
 // ---------------------------------------------------------------------------------------
-template <int OSC, bool FM, bool FASTDIV, int L, int MAXT>
+template <int OSC, bool FM, bool PV, int L, int MAXT>
 __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams p) {
+    const uint32_t kSuper = p.super_frames;                      // 64 or 256, wave-uniform
     __shared__ uint64_t sT[S2R_EXP2F_N];
     __shared__ float sSin[OSC == S2R_OSC_SINE ? 1024 : 1];
     extern __shared__ float s_dyn[];
@@ -651,7 +652,7 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
                         const uint32_t qn = (sc0 + g + G) / kP + sub;
                         if (qn < x16_frames / kP) xc_next = stream[(size_t)qn * 64u];
                     }
-                    closed_form_x4<OSC, FM, FASTDIV>(p, r, ea, em, thr_min, fc, r.offset + sc0 + g + kP * sub, sT,
+                    closed_form_x4<OSC, FM>(p, r, ea, em, thr_min, fc, r.offset + sc0 + g + kP * sub, sT,
                                                      have_stream, xc_now, cf, kf);
                     // recurrence for the 4*L frames of the group, every lane of the voice alike
 #define S2R_QUAD(Q)                                                                              \
@@ -678,7 +679,7 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
                             const float o = S2R_RECUR(OSC, p, r, c1, k1, sSin);                  \
                             out4[j] = live ? o : 0.0f;                                           \
                         }                                                                        \
-                        if (p.per_voice) { if (pv_lane) {                                        \
+                        if (PV) { if (pv_lane) {                                        \
                             float *dst = p.per_voice + pv_base + sc0 + g + kP * Q;               \
                             dst[0] = out4.x; dst[1] = out4.y; dst[2] = out4.z; dst[3] = out4.w; } } \
                         S2R_ABLATE_MIX_BEGIN                                                     \
@@ -696,7 +697,7 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
                 for (uint32_t i = n_x16; i < n_sc; ++i) {
                     float out = frame_sisd<OSC>(p, r, r.offset + sc0 + i, sT, sSin);
                     out = live ? out : 0.0f;
-                    if (p.per_voice) { if (pv_lane) p.per_voice[pv_base + sc0 + i] = out; }
+                    if (PV) { if (pv_lane) p.per_voice[pv_base + sc0 + i] = out; }
                     tile[(i - n_x16) * (VW + 1) + col] = out;
                 }
                 reduce_chunk(n_x16, n_sc - n_x16);
@@ -704,18 +705,18 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
         } else {
             for (uint32_t i = lane; i < GW * kSuper; i += 64u)
                 sW[(buf * n_groups + wave * GW + i / kSuper) * kSuper + (i % kSuper)] = 0.0f;
-            if (p.per_voice) { if (pv_lane) for (uint32_t i = 0; i < n_sc; ++i) p.per_voice[pv_base + sc0 + i] = 0.0f; }
+            if (PV) { if (pv_lane) for (uint32_t i = 0; i < n_sc; ++i) p.per_voice[pv_base + sc0 + i] = 0.0f; }
         }
 #if defined(S2R_ABLATE_BARRIER)
         if (false) {
 #else
         __syncthreads();
-        if (tid < n_sc) {
+        for (uint32_t f = tid; f < n_sc; f += blockDim.x) {
 #endif
             // the block's 16-voice group sums, in group (= voice index) order
-            float acc = sW[(buf * n_groups + 0) * kSuper + tid];
-            for (uint32_t gq = 1; gq < n_groups; ++gq) acc += sW[(buf * n_groups + gq) * kSuper + tid];
-            bp[sc0 + tid] = acc;
+            float acc = sW[(buf * n_groups + 0) * kSuper + f];
+            for (uint32_t gq = 1; gq < n_groups; ++gq) acc += sW[(buf * n_groups + gq) * kSuper + f];
+            bp[sc0 + f] = acc;
         }
         buf ^= 1u;
     }
@@ -789,25 +790,27 @@ __global__ void s2r_events_kernel(const S2rVoiceArrays v, const S2rVoiceEvent *e
     }
 }
 
-template <int OSC, bool FM, bool FASTDIV>
-hipError_t launch_l(const S2rRenderParams &p, uint32_t block_voices, uint32_t lanes, hipStream_t stream) {
+template <int OSC, bool FM, bool PV>
+hipError_t launch_l(const S2rRenderParams &p0, uint32_t block_voices, uint32_t lanes, hipStream_t stream) {
+    S2rRenderParams p = p0;
     const uint32_t grid = (p.n_voices + block_voices - 1) / block_voices;
     const dim3 block(block_voices * lanes);
     const uint32_t n_waves = block_voices * lanes / 64, vw = 64 / lanes, n_groups = n_waves * (vw / 16);
-    const size_t lds = sizeof(float) * ((size_t)2 * n_groups * kSuper + (size_t)n_waves * kChunk * (vw + 1));
+    p.super_frames = n_groups <= 16 ? kSuperMax : 64u;           // keeps the staging under ~100 KiB of LDS
+    const size_t lds = sizeof(float) * ((size_t)2 * n_groups * p.super_frames + (size_t)n_waves * kChunk * (vw + 1));
     // the launch bound is the register budget: 256-thread workgroups (one wave per SIMD) may use
     // the whole file, which the 4-frame vector code wants; bigger workgroups get what is left
     const uint32_t threads = block_voices * lanes;
     switch (lanes) {
     case 1:
-        if (threads <= 256) hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, FASTDIV, 1, 256>), dim3(grid), block, lds, stream, p);
-        else hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, FASTDIV, 1, 1024>), dim3(grid), block, lds, stream, p);
+        if (threads <= 256) hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, PV, 1, 256>), dim3(grid), block, lds, stream, p);
+        else hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, PV, 1, 1024>), dim3(grid), block, lds, stream, p);
         break;
     case 2:
-        if (threads <= 512) hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, FASTDIV, 2, 512>), dim3(grid), block, lds, stream, p);
-        else hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, FASTDIV, 2, 1024>), dim3(grid), block, lds, stream, p);
+        if (threads <= 512) hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, PV, 2, 512>), dim3(grid), block, lds, stream, p);
+        else hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, PV, 2, 1024>), dim3(grid), block, lds, stream, p);
         break;
-    case 4: hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, FASTDIV, 4, 1024>), dim3(grid), block, lds, stream, p); break;
+    case 4: hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, PV, 4, 1024>), dim3(grid), block, lds, stream, p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -817,9 +820,9 @@ template <int OSC>
 hipError_t launch_osc(const S2rRenderParams &p, uint32_t block_voices, uint32_t lanes, hipStream_t stream) {
     // pow(2, mod * amount) == 1 exactly iff amount is +-0 (mod is always finite and >= 0)
     const bool fm = p.amt_osc != 0.0f;
-    const bool fd = p.fast_div_sr != 0;
-    if (fm) return fd ? launch_l<OSC, true, true>(p, block_voices, lanes, stream) : launch_l<OSC, true, false>(p, block_voices, lanes, stream);
-    return fd ? launch_l<OSC, false, true>(p, block_voices, lanes, stream) : launch_l<OSC, false, false>(p, block_voices, lanes, stream);
+    const bool pv = p.per_voice != nullptr;       // mix-disabled debug/parity variant
+    if (fm) return pv ? launch_l<OSC, true, true>(p, block_voices, lanes, stream) : launch_l<OSC, true, false>(p, block_voices, lanes, stream);
+    return pv ? launch_l<OSC, false, true>(p, block_voices, lanes, stream) : launch_l<OSC, false, false>(p, block_voices, lanes, stream);
 }
 
 }  // namespace
