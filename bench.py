@@ -199,6 +199,16 @@ def main():
         sync_rate = vpg * FRAMES * min(args.steps, 32) / (time.perf_counter() - t1)
 
     if rank == 0:
+        # HBM bytes per launch of the render kernel from the committed rocprofv3 PMC passes
+        # (FETCH_SIZE and WRITE_SIZE in separate passes, KiB units); dword-per-lane accesses, for
+        # which the guide's x2 FETCH_SIZE correction (16 B/lane streams) is not calibrated
+        traffic = None
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01", "steady_state_summary.json")))
+            pm = prof["pmc_avg_per_dispatch"]
+            traffic = (pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
+        except Exception:
+            pass
         value = total * FRAMES * args.steps / dt_max
         kernel_s = kernel_ms * 1e-3
         hbm_gbs = BYTES_PER_VOICE_FILL * vpg / kernel_s / 1e9
@@ -224,7 +234,7 @@ def main():
             "msamples_per_s": value / 1e6,
             "realtime_factor_64k_voices": value / (65536.0 * SR),
             "roofline": {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "s2r_render_kernel", "kernel_ms": kernel_ms,
                          "note": "algorithmic bytes = %d B per voice per fill; the path is VALU-bound, see roofline_valu" % BYTES_PER_VOICE_FILL},
             "roofline_valu": {"bound": "valu-fp32", "achieved": valu_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",

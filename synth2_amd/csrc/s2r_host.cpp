@@ -224,13 +224,13 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
     if (rc != S2R_OK) return rc;
     S2rRenderParams p = make_params(s, frames, sample_rate);
     p.per_voice = per_voice_dev;
-    if (s->timing) S2R_HIP(s, hipEventRecord(s->t0, stream));
     if (p.use_coeff && frames >= 16) {
         S2R_HIP(s, s2r_launch_coeff(p, stream));
         s->coeff_parity ^= 1u;
     } else {
         p.use_coeff = 0;       // nothing was prepared for this fill
     }
+    if (s->timing) S2R_HIP(s, hipEventRecord(s->t0, stream));      // brackets the render kernel alone
     S2R_HIP(s, s2r_launch_render(p, s->block_voices, s->lanes, stream));
     if (s->timing) { S2R_HIP(s, hipEventRecord(s->t1, stream)); s->timed = true; }
     if (dev_out) {

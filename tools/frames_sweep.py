@@ -19,10 +19,12 @@ def run(voices, frames, flat=True, lanes=0, reps=12):
         ms.append(s.last_render_ms())
     return float(np.median(ms)), s.lanes_per_voice
 
-for voices in (65536, 131072, 16384):
+import itertools
+cases = [(65536, 0), (131072, 0), (16384, 0)] if len(sys.argv) < 2 else [(int(a.split(":")[0]), int(a.split(":")[1])) for a in sys.argv[1:]]
+for voices, lanes in cases:
     for flat in (True, False):
         row = []
         for frames in (64, 256, 1024, 4096):
-            t, L = run(voices, frames, flat)
+            t, L = run(voices, frames, flat, lanes)
             row.append("%d:%.4f" % (frames, t))
         print("voices %6d L=%d flat=%-5s  ms by frames  %s" % (voices, L, flat, "  ".join(row)))
