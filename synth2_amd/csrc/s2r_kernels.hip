@@ -386,6 +386,9 @@ __device__ __forceinline__ void closed_form_x4(const S2rRenderParams &p, const V
 #else
     cf.nz = hash_noise4(r.seed_rot, t) + splat(p.noise_level);   // process.rs:347-356 (ADD)
 #endif
+#if defined(S2R_ABLATE_FORCEFLAT)
+    cf.xc = splat(fc.xc); return;
+#endif
     if (have_stream) {             // wave-uniform: this 64-voice group's coefficients were computed ahead
         cf.xc = stream_xc;
         return;
@@ -540,6 +543,78 @@ __global__ void __launch_bounds__(256) s2r_coeff_kernel(const S2rRenderParams p)
 }
 
 // ---------------------------------------------------------------------------------------
+// The branch-free 16-frame chunk.  Measured (tools/ablate.sh): with the rare branches (envelope
+// stage change, fmodf slow path, coefficient-source selection) inside the per-quad loop the
+// SAME executed work takes almost twice as long — every one is a basic-block boundary the
+// scheduler cannot move work across, and a taken branch is an instruction-fetch bubble for the
+// single wave a SIMD holds.  So the decision is taken once per chunk, wave-uniformly, and the
+// common case runs this straight-line code: 4 quads, closed-form part on 4-vectors, then the
+// recurrence, all in one basic block.
+//   Preconditions (checked by the caller for the whole wave): no envelope threshold inside the
+//   chunk; period > 0 and 0 <= phase < 1 (then fmodf(period*phase, period) is `off` itself unless
+//   off == period, where it is +0); no oscillator FM.
+//   SRC: 0 = every voice flat (constant coefficient), 1 = coefficient stream, 2 = compute in-lane.
+// ---------------------------------------------------------------------------------------
+template <int OSC, int SRC>
+__device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &r, const EnvRun &ea, const EnvRun &em,
+                                           const FlatCache &fc, const OscK &k, uint32_t o_chunk, const f4 *stream_q,
+                                           const uint64_t *sT, const float *sSin, bool live, float *tile_col,
+                                           uint32_t tile_stride, float *pv_dst) {
+    f4 xq[4];
+    if (SRC == 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xq[q] = stream_q[(size_t)q * 64u];      // 4 coalesced 16-byte loads, used last
+    }
+    f4 amp[4], nz[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const u4 ou = (u4)(o_chunk + 4u * q) + (u4){0u, 1u, 2u, 3u};
+        const f4 t = __builtin_convertvector(ou, f4);
+        amp[q] = splat(ea.slope) * (t - splat(ea.base)) + splat(ea.y0);
+        nz[q] = hash_noise4(r.seed_rot, t) + splat(p.noise_level);
+        if (SRC == 0) xq[q] = splat(fc.xc);
+        if (SRC == 2) {
+            const f4 mod = splat(em.slope) * (t - splat(em.base)) + splat(em.y0);
+            const f4 f_lpf = pow2_sleef_core4(mod * splat(p.amt_lpf)) * splat(p.lpf_freq);
+            const f4 num = splat(-2.0f * 3.14159274101257324f) * f_lpf;
+            const f4 arg = p.fast_div_sr ? div_const_nocheck4(num, p.sr, p.rcp_sr) : (num / splat(p.sr));
+            xq[q] = expf4(arg, sT);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f4 a0 = splat(1.0f) - xq[q];                       // filters.rs:23
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float ph = r.phase;
+            const float nx = ph + k.inv_period;                  // oscillators.rs:377-381; nx >= 0
+            r.phase = nx - __builtin_truncf(nx);                 //   fmodf(nx, 1) for nx >= 0
+            const float off = k.period * ph;                     // fma(period, ph, +0) with a product >= +0
+            const float x = (off == k.period) ? 0.0f : off;      // fmodf(off, period) on [0, period]
+            float osc;
+            if (OSC == S2R_OSC_SAW) osc = __builtin_fmaf(k.a, x, 1.0f);
+            else if (OSC == S2R_OSC_SQUARE) osc = x < k.a ? 1.0f : -1.0f;
+            else if (OSC == S2R_OSC_TRIANGLE) {
+                const float first = __builtin_fmaf(k.b, x, 1.0f), second = __builtin_fmaf(k.c, x - k.a, -1.0f);
+                osc = x < k.a ? first : second;
+            } else {
+                const float tv = x * 1024.0f / k.period;
+                const uint32_t i1 = s2r_f32_as_u32(tv), i2 = (i1 + 1u) & 1023u;
+                const float s1 = i1 < 1024u ? sSin[i1] : 0.0f, s2 = sSin[i2];
+                osc = __builtin_fmaf((s2 - s1) / 1.0f, tv - (float)i1, s1);
+            }
+            const float s = (osc + p.osc_gain) + nz[q][j];
+            const float y = __builtin_fmaf(a0[j], s, xq[q][j] * r.last);
+            r.last = y;
+            float out = y * amp[q][j];
+            out = live ? out : 0.0f;
+            tile_col[(4 * q + j) * tile_stride] = out;
+            if (pv_dst) pv_dst[4 * q + j] = out;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // render kernel.
 //   * one voice per lane-group of L lanes (L = 1, 2 or 4);
 //   * the x16 path walks the fill in groups of 4*L frames: each lane evaluates the closed-form
@@ -608,6 +683,10 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
 
     const bool wave_live = __ballot(live) != 0ull;
     const uint32_t x16_frames = p.frames & ~(uint32_t)(kChunk - 1);      // frames in full 16-chunks
+    // preconditions of the branch-free chunk that hold for the whole fill once they hold at its start
+    // (phase' = fmodf(phase + 1/period, 1) stays in [0,1) for a positive period)
+    const bool fast_ok = L == 1 && !FM &&
+        __ballot(!(k_const.period > 0.0f && k_const.period < __builtin_inff() && r.phase >= 0.0f && r.phase < 1.0f)) == 0ull;
     // coefficient stream for this wave's 64-voice group, if one was prepared (wave-uniform)
     int32_t slot = -1;
     if (!FM && p.use_coeff && p.coeff_count[p.coeff_parity] <= p.coeff_capacity)
@@ -644,6 +723,23 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
         const uint32_t n_x16 = (x16_frames > sc0) ? ((x16_frames - sc0 < n_sc) ? (x16_frames - sc0) : n_sc) : 0u;
         if (wave_live) {
             for (uint32_t c16 = 0; c16 < n_x16; c16 += kChunk) {
+                const uint32_t o_chunk = r.offset + sc0 + c16;
+                // one wave-uniform decision per 16 frames: nobody reaches an envelope threshold in here
+                if (fast_ok && __ballot(!((float)(o_chunk + (kChunk - 1)) < thr_min)) == 0ull) {
+                    float *tcol = tile + col;
+                    float *pvd = (PV && pv_lane) ? p.per_voice + pv_base + sc0 + c16 : nullptr;
+                    const f4 *sq = stream + (size_t)((sc0 + c16) / kP) * 64u;
+                    if (have_stream) chunk_fast<OSC, 1>(p, r, ea, em, fc, k_const, o_chunk, sq, sT, sSin, live, tcol, VW + 1, pvd);
+                    else if (!p.no_flat_shortcut && __ballot(live && em.slope != 0.0f) == 0ull)
+                        chunk_fast<OSC, 0>(p, r, ea, em, fc, k_const, o_chunk, sq, sT, sSin, live, tcol, VW + 1, pvd);
+                    else chunk_fast<OSC, 2>(p, r, ea, em, fc, k_const, o_chunk, sq, sT, sSin, live, tcol, VW + 1, pvd);
+                    if (have_stream) {                       // keep the general path's one-ahead prefetch coherent
+                        const uint32_t qn = (sc0 + c16 + kChunk) / kP + sub;
+                        if (qn < x16_frames / kP) xc_next = stream[(size_t)qn * 64u];
+                    }
+                    reduce_chunk(c16, kChunk);
+                    continue;
+                }
                 for (uint32_t g = c16; g < c16 + kChunk; g += G) {
                     // closed-form work of frames sc0+g+4*sub .. +3 on this lane
                     FrameCF4 cf; OscK4 kf;
