@@ -594,13 +594,21 @@ static float block_partial(const float *per_voice, uint32_t voices, size_t frame
     return acc;
 }
 
+/* blocks [b0, b1): runs of 16 consecutive blocks added sequentially, then the run sums */
+static float blocks_sum(const float *per_voice, uint32_t voices, size_t frames, uint32_t b0, uint32_t b1, uint32_t block_voices, size_t i) {
+    float total = 0.0f;
+    for (uint32_t r0 = b0; r0 < b1; r0 += 16) {
+        uint32_t r1 = r0 + 16 < b1 ? r0 + 16 : b1;
+        float acc = block_partial(per_voice, voices, frames, r0, block_voices, i);
+        for (uint32_t b = r0 + 1; b < r1; b++) acc += block_partial(per_voice, voices, frames, b, block_voices, i);
+        total = (r0 == b0) ? acc : total + acc;
+    }
+    return total;
+}
+
 void s2o_mix_tree_partial(const float *per_voice, uint32_t voices, size_t frames, uint32_t block_voices, float *out) {
     uint32_t nblocks = (voices + block_voices - 1) / block_voices;
-    for (size_t i = 0; i < frames; i++) {
-        float acc = block_partial(per_voice, voices, frames, 0, block_voices, i);
-        for (uint32_t b = 1; b < nblocks; b++) acc += block_partial(per_voice, voices, frames, b, block_voices, i);
-        out[i] = acc;
-    }
+    for (size_t i = 0; i < frames; i++) out[i] = blocks_sum(per_voice, voices, frames, 0, nblocks, block_voices, i);
 }
 
 void s2o_mix_tree(const float *per_voice, uint32_t voices, size_t frames, s2o_tree tree, float *out) {
@@ -612,9 +620,7 @@ void s2o_mix_tree(const float *per_voice, uint32_t voices, size_t frames, s2o_tr
         for (uint32_t g = 0; g < groups; g++) {
             uint32_t b0 = g * per_group, b1 = b0 + per_group < nblocks ? b0 + per_group : nblocks;
             if (b0 >= b1) continue;
-            float acc = block_partial(per_voice, voices, frames, b0, tree.block_voices, i);
-            for (uint32_t b = b0 + 1; b < b1; b++) acc += block_partial(per_voice, voices, frames, b, tree.block_voices, i);
-            total += acc;
+            total += blocks_sum(per_voice, voices, frames, b0, b1, tree.block_voices, i);
         }
         out[i] = total;
     }

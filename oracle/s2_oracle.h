@@ -75,9 +75,10 @@ typedef struct {
 
 /* GPU mix-tree description: every 16 consecutive voices are added in index
  * order (the reference's order, synth.rs:177-195), the 16-voice sums of a block of
- * `block_voices` in order, blocks sequentially inside each of `groups` contiguous groups,
- * groups sequentially, and the root is (+0.0f) + total (the `accum = splat(0.0)` of
- * synth.rs:176).  For pools of <= 16 voices this IS the reference's summation order. */
+ * `block_voices` in order, blocks in runs of 16 (sequential inside a run, run sums
+ * sequential) inside each of `groups` contiguous groups, groups sequentially, and the root is
+ * (+0.0f) + total (the `accum = splat(0.0)` of synth.rs:176).  For pools of <= 16 voices
+ * this IS the reference's summation order. */
 typedef struct { uint32_t block_voices; uint32_t groups; } s2o_tree;
 
 s2o_layer_cfg s2o_default_config(void);                     /* synth.rs:125-152 */

@@ -509,7 +509,7 @@ __global__ void __launch_bounds__(256) s2r_coeff_kernel(const S2rRenderParams p)
     if (count == 0u || count > p.coeff_capacity) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t n_quads = (p.frames & ~15u) / kP;
-    constexpr uint32_t kQuadsPerItem = 16;
+    constexpr uint32_t kQuadsPerItem = 4;
     const uint32_t chunks = (n_quads + kQuadsPerItem - 1) / kQuadsPerItem;
     const uint32_t n_items = count * chunks;
     for (uint32_t it = blockIdx.x * 4u + wave; it < n_items; it += gridDim.x * 4u) {
@@ -827,31 +827,50 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
 }
 
 // ---------------------------------------------------------------------------------------
-// mix kernel: one thread per frame adds the workgroup partial rows in a fixed order:
-// blocks sequentially inside each group, groups sequentially, root (+0.0) + total.
+// mix kernel: adds the workgroup partial rows in the fixed order of DESIGN.md 4.3:
+//   runs of 16 consecutive workgroups sequentially -> the run sums of a mix group sequentially
+//   -> the mix groups sequentially -> root (+0.0) + total.
+// One workgroup handles 16 frames: thread (slot, f) adds whole runs (16 independent loads in
+// flight each), the run sums meet in LDS, 16 threads finish.  Runs never straddle a mix group.
 // ---------------------------------------------------------------------------------------
-__global__ void s2r_mix_kernel(const S2rMixParams m) {
-    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= m.frames) return;
-    float total = 0.0f;                                          // accum = splat(0.0), synth.rs:176
-    for (uint32_t g = 0; g < m.n_groups; ++g) {
-        const uint32_t b0 = g * m.blocks_per_group;
-        uint32_t b1 = b0 + m.blocks_per_group;
-        if (b1 > m.n_blocks) b1 = m.n_blocks;
-        if (b0 >= b1) continue;
-        // the adds are sequential by specification; the loads are not, so fetch 64 rows at a time
-        float acc = 0.0f;
-        for (uint32_t b = b0; b < b1; b += 64) {
-            float v[64];
+constexpr uint32_t kMixRun = 16;
+
+__global__ void __launch_bounds__(256) s2r_mix_kernel(const S2rMixParams m) {
+    extern __shared__ float s_run[];                             // [total runs][16 frames]
+    const uint32_t f_local = threadIdx.x & 15u, slot = threadIdx.x >> 4;
+    const uint32_t f = blockIdx.x * 16u + f_local;
+    const uint32_t runs_per_group = (m.blocks_per_group + kMixRun - 1) / kMixRun;
+    const uint32_t total_runs = runs_per_group * m.n_groups;
+    if (f < m.frames) {
+        for (uint32_t run = slot; run < total_runs; run += 16u) {
+            const uint32_t g = run / runs_per_group, rg = run % runs_per_group;
+            const uint32_t gb0 = g * m.blocks_per_group;
+            uint32_t gb1 = gb0 + m.blocks_per_group; if (gb1 > m.n_blocks) gb1 = m.n_blocks;
+            const uint32_t b0 = gb0 + rg * kMixRun;
+            float v[kMixRun];
 #pragma unroll
-            for (uint32_t j = 0; j < 64; ++j) v[j] = (b + j < b1) ? m.block_partials[(size_t)(b + j) * m.frames_stride + f] : 0.0f;
+            for (uint32_t j = 0; j < kMixRun; ++j) v[j] = (b0 + j < gb1) ? m.block_partials[(size_t)(b0 + j) * m.frames_stride + f] : 0.0f;
+            float acc = v[0];
 #pragma unroll
-            for (uint32_t j = 0; j < 64; ++j) if (b + j < b1) acc = (b + j == b0) ? v[j] : acc + v[j];
+            for (uint32_t j = 1; j < kMixRun; ++j) if (b0 + j < gb1) acc += v[j];
+            s_run[run * 16u + f_local] = (b0 < gb1) ? acc : 0.0f;
         }
-        total = (m.root_add || g > 0) ? total + acc : acc;
     }
-    if (m.stereo) { m.out[2 * f] = total; m.out[2 * f + 1] = total; }
-    else m.out[f] = total;
+    __syncthreads();
+    if (threadIdx.x < 16u && f < m.frames) {
+        float total = 0.0f;                                      // accum = splat(0.0), synth.rs:176
+        for (uint32_t g = 0; g < m.n_groups; ++g) {
+            const uint32_t gb0 = g * m.blocks_per_group;
+            uint32_t gb1 = gb0 + m.blocks_per_group; if (gb1 > m.n_blocks) gb1 = m.n_blocks;
+            if (gb0 >= gb1) continue;
+            const uint32_t n_runs = (gb1 - gb0 + kMixRun - 1) / kMixRun;
+            float acc = s_run[(g * runs_per_group) * 16u + f_local];
+            for (uint32_t r = 1; r < n_runs; ++r) acc += s_run[(g * runs_per_group + r) * 16u + f_local];
+            total = (m.root_add || g > 0) ? total + acc : acc;
+        }
+        if (m.stereo) { m.out[2 * f] = total; m.out[2 * f + 1] = total; }
+        else m.out[f] = total;
+    }
 }
 
 // out[i] = ((+0.0 + rows[0][i]) + rows[1][i]) + ...   (rank-order combine of shard partials)
@@ -947,7 +966,10 @@ hipError_t s2r_launch_render(const S2rRenderParams &p, uint32_t block_voices, ui
 
 hipError_t s2r_launch_mix(const S2rMixParams &m, hipStream_t stream) {
     if (m.frames == 0) return hipSuccess;
-    hipLaunchKernelGGL(s2r_mix_kernel, dim3((m.frames + 63) / 64), dim3(64), 0, stream, m);
+    const uint32_t runs_per_group = (m.blocks_per_group + kMixRun - 1) / kMixRun;
+    const size_t lds = (size_t)runs_per_group * m.n_groups * 16u * sizeof(float);
+    if (lds > 64u * 1024u) return hipErrorInvalidValue;          // > 16 k workgroups in one shard
+    hipLaunchKernelGGL(s2r_mix_kernel, dim3((m.frames + 15) / 16), dim3(256), lds, stream, m);
     return hipGetLastError();
 }
 
