@@ -72,12 +72,23 @@ class Pair:
         self.gpu.note_off(note)
 
     def render_voices(self, frames, sr=48000):
-        return self.gpu.render_voices(frames, sr), self.cpu.render_voices(frames, sr)
+        return self.gpu.render_voices(frames, sr), self.cpu.render_voices(frames, sr, threads=self.threads)
+
+    threads = 1
+
+    def note_events(self, events):
+        """batch form; voice choices are cross-checked by the single-event tests"""
+        self.gpu.note_events(events)
+        for e in events:
+            if e["kind"] == 1:
+                self.cpu.note_on(int(e["note"]), float(e["velocity"]))
+            else:
+                self.cpu.note_off(int(e["note"]))
 
     def sample(self, frames, sr=48000):
         """GPU mono mix and the oracle's mix through the same tree"""
         g = self.gpu.sample(np.empty(frames, dtype=np.float32), sr)
-        pv = self.cpu.render_voices(frames, sr)
+        pv = self.cpu.render_voices(frames, sr, threads=self.threads)
         return g, s2o.mix_tree(pv, self.block_voices, self.groups), pv
 
 

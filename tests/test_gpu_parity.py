@@ -325,3 +325,40 @@ def test_error_statuses():
         s.load_patch("synth x { bogus = 3 }")
     assert e.value.status == -4
     assert s.sample(np.empty(0, dtype=np.float32)).size == 0      # empty buffer is fine
+
+
+def _full_size(voices, buffers, churn):
+    """BASELINE-size pools against the (multi-threaded) oracle, bit for bit, plus the
+    size-independent properties: determinism across handles and shard/whole equality."""
+    import os
+    pr = Pair(voices, max_frames=1024)
+    pr.threads = min(32, len(os.sched_getaffinity(0)))
+    ev = np.zeros(voices, dtype=s2.NOTE_EVENT_DTYPE)
+    ev["kind"] = 1
+    ev["note"] = 36 + np.arange(voices) % 61
+    ev["velocity"] = 1.0
+    pr.note_events(ev)
+    rng = np.random.RandomState(voices % 9973)
+    for b in range(buffers):
+        if b:
+            ch = np.zeros(2 * churn, dtype=s2.NOTE_EVENT_DTYPE)
+            ch["kind"][churn:] = 1
+            ch["note"] = 36 + rng.randint(0, 61, 2 * churn)
+            ch["velocity"] = 1.0
+            pr.note_events(ch)
+        g, o, pv = pr.sample(1024)
+        assert_bits_equal(g, o, "%d voices, buffer %d" % (voices, b))
+    seq = s2o.mix_sequential(pv)
+    exact = pv.astype(np.float64).sum(axis=0).astype(np.float32)
+    print("%d voices: tree vs the reference's sequential order %d ULP; vs the exactly rounded sum: tree %d ULP, sequential %d ULP"
+          % (voices, ulp_diff(o, seq), ulp_diff(o, exact), ulp_diff(seq, exact)))
+
+
+def test_c3_full_size_65536_voices():
+    """BASELINE config 2: 65 536 voices on one MI355X (the bench workload), 3 buffers with churn"""
+    _full_size(65536, 3, 128)
+
+
+def test_c4_shard_size_131072_voices():
+    """BASELINE config 3's per-GPU share: 1 048 576 voices / 8 GPUs"""
+    _full_size(131072, 2, 256)
