@@ -121,9 +121,15 @@ int s2r_note_off(s2r_synth *s, uint8_t note);
 
 /* A batch of note_on / note_off calls applied in order — what s2_bin's
  * apply_all_midi_messages loop does between two sample() calls (main.rs:170-187), in one
- * crossing of the boundary. */
+ * crossing of the boundary.
+ *
+ * `frame` = 0: the event takes effect before the next fill (like s2r_note_on/off).
+ * `frame` = a multiple of 16 below the next fill's length: the event takes effect INSIDE the
+ * next fill at that frame, exactly as if the caller had split the fill there — s2_bin's
+ * apply-MIDI-every-16-frames loop (main.rs:138-143) reproduced inside one launch.  Events
+ * must be submitted in non-decreasing frame order. */
 typedef enum { S2R_NOTE_OFF = 0, S2R_NOTE_ON = 1 } s2r_note_kind;
-typedef struct { uint8_t kind; uint8_t note; uint8_t _pad[2]; float velocity; } s2r_note_event;
+typedef struct { uint8_t kind; uint8_t note; uint16_t frame; float velocity; } s2r_note_event;
 int s2r_note_events(s2r_synth *s, const s2r_note_event *events, size_t n);
 
 /* Synth::sample(&mut [f32], SampleRateKhz) (synth.rs:154-169).  `sample_rate_hz` is what

@@ -35,6 +35,8 @@ struct S2rVoiceArrays {
     uint32_t *seed;       // NoiseState.seed                 state.rs:17-21
 };
 
+struct S2rTimedEvent;
+
 struct S2rRenderParams {
     // patch (static_config.rs:4-44), shared by every voice
     int32_t osc_kind;
@@ -67,6 +69,9 @@ struct S2rRenderParams {
     uint32_t coeff_parity;
     uint32_t coeff_capacity;    // slots the stream buffer holds; more moving groups => in-lane path
     float *coeff;               // [slot][quad][64][4]
+    // timed events of this fill (nullptr: none)
+    const S2rTimedEvent *tev;
+    int32_t *voice_ev_head;     // [padded voices] index of the voice's first timed event, -1 = none
 };
 
 // Coalesced note events, one record per touched voice per fill (host folds the event
@@ -79,6 +84,21 @@ struct S2rVoiceEvent {
 };
 #define S2R_EV_RESTART 1u
 #define S2R_EV_RELEASE 2u
+
+// A note event that takes effect INSIDE a fill, at a 16-frame boundary — what s2_bin does by
+// calling sample() 16 frames at a time with MIDI applied in between (main.rs:138-143), here
+// inside one launch.  Records live in mapped host memory; a voice's events of one fill form a
+// chain (next), its first one is published through voice_ev_head[voice].
+struct S2rTimedEvent {
+    uint32_t voice;       // shard-local index
+    uint32_t frame;       // frame offset inside the fill, multiple of 16
+    uint32_t flags;       // S2R_EV_RESTART / S2R_EV_RELEASE, S2R_TEV_FIRST
+    float pitch;          // valid when restart
+    uint32_t seed;
+    int32_t next;         // index of the voice's next event in this fill, -1 = none
+    uint32_t _pad[2];
+};
+#define S2R_TEV_FIRST 0x100u
 
 struct S2rMixParams {
     const float *block_partials;  // [n_blocks][frames_stride]
@@ -96,4 +116,5 @@ hipError_t s2r_launch_coeff(const S2rRenderParams &p, hipStream_t stream);   // 
 hipError_t s2r_launch_render(const S2rRenderParams &p, uint32_t block_voices, uint32_t lanes_per_voice, hipStream_t stream);
 hipError_t s2r_launch_mix(const S2rMixParams &p, hipStream_t stream);
 hipError_t s2r_launch_events(const S2rVoiceArrays &v, const S2rVoiceEvent *dev_events, uint32_t n, hipStream_t stream);
+hipError_t s2r_launch_tev_heads(int32_t *heads, const S2rTimedEvent *tev, uint32_t n, hipStream_t stream);
 hipError_t s2r_launch_sum_rows(const float *rows, uint32_t n_rows, uint32_t frames, float *out, hipStream_t stream);

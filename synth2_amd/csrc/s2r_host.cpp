@@ -89,6 +89,8 @@ bool fast_div_rate(uint32_t sr) {
 struct EventSlot {
     S2rVoiceEvent *host = nullptr;   // pinned
     S2rVoiceEvent *dev = nullptr;
+    S2rTimedEvent *thost = nullptr;  // pinned, mapped: timed events of one fill
+    S2rTimedEvent *tdev = nullptr;
     hipEvent_t done = nullptr;
     bool in_flight = false;
 };
@@ -107,6 +109,12 @@ struct s2r_synth {
     std::vector<int32_t> pending_slot;           // shard-local voice -> index in pending, -1
     EventSlot slots[kEventSlots];
     int next_slot = 0;
+    // timed events (take effect inside the next fill at a 16-frame boundary)
+    std::vector<S2rTimedEvent> tpending;
+    std::vector<int32_t> tlast;                  // shard-local voice -> its last timed event this fill, -1
+    uint32_t fill_time = 0;                      // frames of the next fill the pool clock has already moved
+    uint32_t tev_capacity = 0;
+    int32_t *voice_ev_head = nullptr;
     // device
     hipStream_t stream = nullptr;
     S2rVoiceArrays v{};
@@ -157,19 +165,33 @@ void push_event(s2r_synth *s, uint32_t pool_index, uint32_t flags, float pitch, 
     if (flags & S2R_EV_RELEASE) e.flags |= S2R_EV_RELEASE;
 }
 
-// upload the folded events and apply them on `stream`
-int flush_events(s2r_synth *s, hipStream_t stream) {
-    if (s->pending.empty()) return S2R_OK;
+// upload the folded events and apply them on `stream`; publish the timed ones.  Returns the slot
+// whose `done` event the caller must record AFTER the render kernel when timed events exist
+// (the kernel reads them from the slot's mapped memory), or nullptr.
+int flush_events(s2r_synth *s, hipStream_t stream, EventSlot **timed_slot, const S2rTimedEvent **tev_dev) {
+    *timed_slot = nullptr; *tev_dev = nullptr;
+    if (s->pending.empty() && s->tpending.empty()) return S2R_OK;
     EventSlot &sl = s->slots[s->next_slot];
     s->next_slot = (s->next_slot + 1) % kEventSlots;
     if (sl.in_flight) { S2R_HIP(s, hipEventSynchronize(sl.done)); sl.in_flight = false; }
     const uint32_t n = (uint32_t)s->pending.size();
-    std::memcpy(sl.host, s->pending.data(), n * sizeof(S2rVoiceEvent));
-    // the kernel reads the pinned (device-mapped) host buffer directly: a few KB over PCIe inside
-    // the kernel instead of a separate copy node in front of it
-    S2R_HIP(s, s2r_launch_events(s->v, sl.dev, n, stream));
-    S2R_HIP(s, hipEventRecord(sl.done, stream));
-    sl.in_flight = true;
+    if (n) {
+        std::memcpy(sl.host, s->pending.data(), n * sizeof(S2rVoiceEvent));
+        // the kernel reads the pinned (device-mapped) host buffer directly: a few KB over PCIe inside
+        // the kernel instead of a separate copy node in front of it
+        S2R_HIP(s, s2r_launch_events(s->v, sl.dev, n, stream));
+    }
+    const uint32_t nt = (uint32_t)s->tpending.size();
+    if (nt) {
+        std::memcpy(sl.thost, s->tpending.data(), nt * sizeof(S2rTimedEvent));
+        S2R_HIP(s, s2r_launch_tev_heads(s->voice_ev_head, sl.tdev, nt, stream));
+        *timed_slot = &sl; *tev_dev = sl.tdev;
+        for (const S2rTimedEvent &e : s->tpending) s->tlast[e.voice] = -1;
+        s->tpending.clear();
+    } else {
+        S2R_HIP(s, hipEventRecord(sl.done, stream));
+        sl.in_flight = true;
+    }
     for (const S2rVoiceEvent &e : s->pending) s->pending_slot[e.voice] = -1;
     s->pending.clear();
     return S2R_OK;
@@ -181,7 +203,9 @@ int check_fill(s2r_synth *s, size_t frames, uint32_t sample_rate) {
     if (sample_rate == 0) return set_err(s, S2R_ERR_INVALID, "sample_rate_hz must be > 0");
     // process.rs:36,71: offset.checked_add(..).expect("overflow") — the reference panics once a
     // voice's offset would pass u32::MAX; report it instead of rendering garbage.
-    if (s->pool->oldest_offset() + frames > 0xffffffffull)
+    if (s->fill_time && s->fill_time >= frames)
+        return set_err(s, S2R_ERR_INVALID, "a timed event at frame %u does not fall inside this %zu-frame fill", s->fill_time, frames);
+    if (s->pool->oldest_offset() + (frames - s->fill_time) > 0xffffffffull)
         return set_err(s, S2R_ERR_OFFSET_OVERFLOW, "a voice's frame offset would overflow u32 (the reference panics here)");
     return S2R_OK;
 }
@@ -220,10 +244,14 @@ S2rRenderParams make_params(s2r_synth *s, size_t frames, uint32_t sample_rate) {
 // events -> render -> (mix) on `stream`; the partial or final mix lands in `dev_out`
 int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t stream, float *dev_out,
                  bool root_add, bool stereo, float *per_voice_dev) {
-    int rc = flush_events(s, stream);
+    EventSlot *timed_slot = nullptr;
+    const S2rTimedEvent *tev_dev = nullptr;
+    int rc = flush_events(s, stream, &timed_slot, &tev_dev);
     if (rc != S2R_OK) return rc;
     S2rRenderParams p = make_params(s, frames, sample_rate);
     p.per_voice = per_voice_dev;
+    p.tev = tev_dev;
+    p.voice_ev_head = s->voice_ev_head;
     if (p.use_coeff && frames >= 16) {
         S2R_HIP(s, s2r_launch_coeff(p, stream));
         s->coeff_parity ^= 1u;
@@ -233,6 +261,10 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
     if (s->timing) S2R_HIP(s, hipEventRecord(s->t0, stream));      // brackets the render kernel alone
     S2R_HIP(s, s2r_launch_render(p, s->block_voices, s->lanes, stream));
     if (s->timing) { S2R_HIP(s, hipEventRecord(s->t1, stream)); s->timed = true; }
+    if (timed_slot) {                     // the render kernel was the last reader of the slot's records
+        S2R_HIP(s, hipEventRecord(timed_slot->done, stream));
+        timed_slot->in_flight = true;
+    }
     if (dev_out) {
         S2rMixParams m{};
         m.block_partials = s->block_partials;
@@ -246,7 +278,8 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
         m.out = dev_out;
         S2R_HIP(s, s2r_launch_mix(m, stream));
     }
-    s->pool->advance(frames);
+    s->pool->advance(frames - s->fill_time);
+    s->fill_time = 0;
     return S2R_OK;
 }
 
@@ -271,6 +304,7 @@ void release_all(s2r_synth *s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (EventSlot &sl : s->slots) {
         if (sl.host) (void)hipHostFree(sl.host);
+        if (sl.thost) (void)hipHostFree(sl.thost);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     if (s->voice_mem) (void)hipFree(s->voice_mem);
@@ -279,6 +313,7 @@ void release_all(s2r_synth *s) {
     if (s->out_host) (void)hipHostFree(s->out_host);
     if (s->sin_dev) (void)hipFree(s->sin_dev);
     if (s->per_voice_dev) (void)hipFree(s->per_voice_dev);
+    if (s->voice_ev_head) (void)hipFree(s->voice_ev_head);
     if (s->group_slot) (void)hipFree(s->group_slot);
     if (s->slot_group) (void)hipFree(s->slot_group);
     if (s->coeff_count) (void)hipFree(s->coeff_count);
@@ -344,7 +379,7 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
         // above that the 4-frame ILP of a single lane is the faster way (measured)
         uint32_t l = cfg->lanes_per_voice;
         if (l == 0) l = shard_voices >= 65536u ? 1u : (shard_voices >= 32768u ? 2u : 4u);
-        while (l > 1 && bv * l > 1024u) l >>= 1;
+        while (l > 1 && (bv * l > 1024u || (l == 2 && bv > 256u))) l >>= 1;
         if (l != 1 && l != 2 && l != 4) { delete s; return S2R_ERR_INVALID; }
         s->lanes = l;
     }
@@ -380,11 +415,17 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
     CREATE_HIP(hipMalloc((void **)&s->block_partials, (size_t)s->n_blocks * cfg->max_frames * sizeof(float)));
     CREATE_HIP(hipMalloc((void **)&s->out_dev, (size_t)2 * cfg->max_frames * sizeof(float)));
     CREATE_HIP(hipHostMalloc((void **)&s->out_host, (size_t)2 * cfg->max_frames * sizeof(float), hipHostMallocDefault));
+    s->tev_capacity = shard_voices < 4096u ? 4096u : shard_voices;
+    s->tlast.assign(shard_voices, -1);
     for (EventSlot &sl : s->slots) {
         CREATE_HIP(hipHostMalloc((void **)&sl.host, (size_t)shard_voices * sizeof(S2rVoiceEvent), hipHostMallocMapped));
         CREATE_HIP(hipHostGetDevicePointer((void **)&sl.dev, sl.host, 0));
         CREATE_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        CREATE_HIP(hipHostMalloc((void **)&sl.thost, (size_t)s->tev_capacity * sizeof(S2rTimedEvent), hipHostMallocMapped));
+        CREATE_HIP(hipHostGetDevicePointer((void **)&sl.tdev, sl.thost, 0));
     }
+    CREATE_HIP(hipMalloc((void **)&s->voice_ev_head, pv * sizeof(int32_t)));
+    CREATE_HIP(hipMemsetAsync(s->voice_ev_head, 0xff, pv * sizeof(int32_t), s->stream));
     {
         // coefficient stream: room for half of the 64-voice groups (beyond that the in-lane path is
         // at least as good); [slot][max_frames/4][64] float4
@@ -456,6 +497,7 @@ int s2r_parse_patch_text(const char *text, size_t len, s2r_patch *out, char *err
 
 int s2r_note_on_ex(s2r_synth *s, uint8_t note, float velocity, uint32_t *voice_index_out) {
     if (!s) return S2R_ERR_INVALID;
+    if (s->fill_time) return set_err(s, S2R_ERR_INVALID, "untimed note_on after timed events: fill first or give it a frame");
     const uint32_t i = s->pool->note_on(note, velocity);
     if (voice_index_out) *voice_index_out = i;
     push_event(s, i, S2R_EV_RESTART, s->pitch_table[note], s->seed_override[i]);
@@ -466,6 +508,7 @@ int s2r_note_on(s2r_synth *s, uint8_t note, float velocity) { return s2r_note_on
 
 int s2r_note_off(s2r_synth *s, uint8_t note) {
     if (!s) return S2R_ERR_INVALID;
+    if (s->fill_time) return set_err(s, S2R_ERR_INVALID, "untimed note_off after timed events: fill first or give it a frame");
     const int64_t i = s->pool->note_off(note);
     if (i >= 0) push_event(s, (uint32_t)i, S2R_EV_RELEASE, 0.0f, 0u);
     return S2R_OK;
@@ -475,15 +518,44 @@ int s2r_note_events(s2r_synth *s, const s2r_note_event *events, size_t n) {
     if (!s || (!events && n)) return S2R_ERR_INVALID;
     for (size_t k = 0; k < n; k++) {
         const s2r_note_event &e = events[k];
-        if (e.kind == S2R_NOTE_ON) {
-            const uint32_t i = s->pool->note_on(e.note, e.velocity);
-            push_event(s, i, S2R_EV_RESTART, s->pitch_table[e.note], s->seed_override[i]);
-        } else if (e.kind == S2R_NOTE_OFF) {
-            const int64_t i = s->pool->note_off(e.note);
-            if (i >= 0) push_event(s, (uint32_t)i, S2R_EV_RELEASE, 0.0f, 0u);
-        } else {
+        if (e.kind != S2R_NOTE_ON && e.kind != S2R_NOTE_OFF)
             return set_err(s, S2R_ERR_INVALID, "event %zu: unknown kind %u", k, (unsigned)e.kind);
+        const uint32_t frame = e.frame;
+        if (frame % 16u) return set_err(s, S2R_ERR_INVALID, "event %zu: frame %u is not a multiple of 16 (events land between 16-frame chunks, main.rs:138-143)", k, frame);
+        if (frame < s->fill_time) return set_err(s, S2R_ERR_INVALID, "event %zu: frame %u precedes an earlier event at %u", k, frame, s->fill_time);
+        if (frame == 0) {                     // takes effect before the next fill: folded per voice
+            if (e.kind == S2R_NOTE_ON) {
+                const uint32_t i = s->pool->note_on(e.note, e.velocity);
+                push_event(s, i, S2R_EV_RESTART, s->pitch_table[e.note], s->seed_override[i]);
+            } else {
+                const int64_t i = s->pool->note_off(e.note);
+                if (i >= 0) push_event(s, (uint32_t)i, S2R_EV_RELEASE, 0.0f, 0u);
+            }
+            continue;
         }
+        // inside the next fill: move the pool's clock to the event (the allocation policy sees the
+        // offsets every voice has AT that frame, like the reference between two 16-frame calls)
+        s->pool->advance(frame - s->fill_time);
+        s->fill_time = frame;
+        int64_t vi; uint32_t fl; float pitch = 0.0f; uint32_t seed = 0;
+        if (e.kind == S2R_NOTE_ON) {
+            vi = s->pool->note_on(e.note, e.velocity);
+            fl = S2R_EV_RESTART; pitch = s->pitch_table[e.note]; seed = s->seed_override[(size_t)vi];
+        } else {
+            vi = s->pool->note_off(e.note);
+            fl = S2R_EV_RELEASE;
+            if (vi < 0) continue;
+        }
+        if ((uint64_t)vi < s->shard_begin || (uint64_t)vi >= (uint64_t)s->shard_begin + s->shard_voices) continue;
+        if (s->tpending.size() >= s->tev_capacity) return set_err(s, S2R_ERR_INVALID, "more than %u timed events in one fill", s->tev_capacity);
+        const uint32_t local = (uint32_t)vi - s->shard_begin;
+        const int32_t idx = (int32_t)s->tpending.size();
+        S2rTimedEvent te{};
+        te.voice = local; te.frame = frame; te.flags = fl; te.pitch = pitch; te.seed = seed; te.next = -1;
+        if (s->tlast[local] >= 0) s->tpending[(size_t)s->tlast[local]].next = idx;
+        else te.flags |= S2R_TEV_FIRST;
+        s->tlast[local] = idx;
+        s->tpending.push_back(te);
     }
     return S2R_OK;
 }
@@ -524,6 +596,7 @@ int s2r_render_voices(s2r_synth *s, float *per_voice_out, size_t frames, uint32_
     if (rc != S2R_OK) return rc;
     if (frames == 0) return S2R_OK;
     if (!per_voice_out) return set_err(s, S2R_ERR_INVALID, "null output buffer");
+    if (!s->tpending.empty()) return set_err(s, S2R_ERR_INVALID, "s2r_render_voices does not take timed events; use s2r_fill");
     S2R_HIP(s, hipSetDevice(s->device));
     const size_t need = (size_t)s->shard_voices * frames;
     if (need > s->per_voice_cap) {
@@ -541,7 +614,9 @@ int s2r_render_voices(s2r_synth *s, float *per_voice_out, size_t frames, uint32_
 int s2r_export_state(s2r_synth *s, s2r_voice_state *voices) {
     if (!s || !voices) return S2R_ERR_INVALID;
     S2R_HIP(s, hipSetDevice(s->device));
-    int rc = flush_events(s, s->stream);
+    if (!s->tpending.empty()) return set_err(s, S2R_ERR_INVALID, "export_state with timed events pending: fill first");
+    EventSlot *ts = nullptr; const S2rTimedEvent *td = nullptr;
+    int rc = flush_events(s, s->stream, &ts, &td);
     if (rc != S2R_OK) return rc;
     const size_t pv = s->padded_voices;
     std::vector<uint32_t> h(pv * 7);
@@ -572,6 +647,7 @@ int s2r_import_state(s2r_synth *s, const s2r_voice_state *voices) {
     // pending events refer to the state being replaced
     for (const S2rVoiceEvent &e : s->pending) s->pending_slot[e.voice] = -1;
     s->pending.clear();
+    if (!s->tpending.empty()) return set_err(s, S2R_ERR_INVALID, "import_state with timed events pending");
     const size_t pv = s->padded_voices;
     std::vector<uint32_t> h(pv * 7, 0u);
     for (uint32_t i = 0; i < s->shard_voices; i++) {
@@ -597,7 +673,9 @@ int s2r_set_noise_seed(s2r_synth *s, uint32_t voice_index, uint32_t seed) {
     s->seed_override[voice_index] = seed;
     if (voice_index >= s->shard_begin && voice_index < s->shard_begin + s->shard_voices) {
         S2R_HIP(s, hipSetDevice(s->device));
-        int rc = flush_events(s, s->stream);
+        if (!s->tpending.empty()) return set_err(s, S2R_ERR_INVALID, "set_noise_seed with timed events pending: fill first");
+        EventSlot *ts = nullptr; const S2rTimedEvent *td = nullptr;
+        int rc = flush_events(s, s->stream, &ts, &td);
         if (rc != S2R_OK) return rc;
         S2R_HIP(s, hipMemcpyAsync(s->v.seed + (voice_index - s->shard_begin), &s->seed_override[voice_index],
                                   sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));

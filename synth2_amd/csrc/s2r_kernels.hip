@@ -477,8 +477,11 @@ __global__ void __launch_bounds__(64) s2r_classify_kernel(const S2rRenderParams 
     const uint32_t group = blockIdx.x, lane = threadIdx.x;
     const uint32_t vi = group * 64u + lane;
     if (group == 0 && lane == 0) p.coeff_count[p.coeff_parity ^ 1u] = 0u;       // ready for the next fill
-    bool moving = false;
+    bool moving = false, timed = false;
     if (vi < p.n_voices) {
+        // a voice that is re-triggered or released inside this fill invalidates anything computed
+        // from its state at the start of the fill: its whole group computes in-lane
+        if (p.tev != nullptr) timed = p.voice_ev_head[vi] >= 0;
         const uint32_t flags = p.v.flags[vi];
         if (flags & S2R_VF_STARTED) {
             const uint32_t offset = p.v.offset[vi];
@@ -489,7 +492,7 @@ __global__ void __launch_bounds__(64) s2r_classify_kernel(const S2rRenderParams 
             moving = !(e0.slope == 0.0f && t_last < e0.thr);
         }
     }
-    const bool any = __ballot(moving) != 0ull;
+    const bool any = __ballot(moving) != 0ull && __ballot(timed) == 0ull;
     if (lane == 0) {
         int32_t slot = -1;
         if (any) {
@@ -625,8 +628,10 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
 //     wave per SIMD at L = 1) at the price of L x the recurrence work (~10% of a frame).
 //   grid = ceil(n_voices / block_voices), blockDim.x = block_voices * L.
 // ---------------------------------------------------------------------------------------
-template <int OSC, bool FM, bool PV, int L, int MAXT>
+template <int OSC, bool FM, int MODE, int L, int MAXT>
 __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams p) {
+    constexpr bool PV = MODE == 1;       // also store every voice's frames (mix-disabled debug/parity output)
+    constexpr bool TEV = MODE == 2;      // note events that take effect inside the fill
     const uint32_t kSuper = p.super_frames;                      // 64 or 256, wave-uniform
     __shared__ uint64_t sT[S2R_EXP2F_N];
     __shared__ float sSin[OSC == S2R_OSC_SINE ? 1024 : 1];
@@ -653,7 +658,7 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
     // ---- load per-voice state (coalesced SoA reads; the L lanes of a voice read the same words) ----
     const bool in_range = vi < p.n_voices;
     const uint32_t flags = in_range ? p.v.flags[vi] : 0u;
-    const bool live = (flags & S2R_VF_STARTED) != 0u;          // synth.rs:178
+    bool live = (flags & S2R_VF_STARTED) != 0u;                // synth.rs:178
     VoiceRegs r;
     r.pitch = live ? p.v.pitch[vi] : 440.0f;
     r.offset = live ? p.v.offset[vi] : 0u;
@@ -670,7 +675,20 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
 
     // mod_env_to_osc_freq == 0: pow(2, mod*0) == 1 exactly, so freq == 1.0 * pitch and the
     // period (and everything derived from it by correctly rounded divisions) is constant.
-    const OscK k_const = make_osck<OSC>(p.sr / (1.0f * r.pitch));
+    OscK k_const = make_osck<OSC>(p.sr / (1.0f * r.pitch));
+
+    // timed events: this voice's chain for the fill (taken over and cleared for the next fill)
+    int32_t ev_idx = -1;
+    uint32_t ev_frame = 0xffffffffu;
+    bool ev_dirty = false;
+    uint32_t seed_now = seed;
+    if (TEV && in_range) {
+        ev_idx = p.voice_ev_head[vi];
+        if (ev_idx >= 0) {
+            ev_frame = p.tev[ev_idx].frame;
+            if (sub == 0) p.voice_ev_head[vi] = -1;
+        }
+    }
 
     // envelope stage registers; a threshold of -inf forces the cascade on this lane's first frame
     EnvRun ea = env_stage_at(p.amp, r.ro_a, r.end_a, 0.0f);
@@ -681,7 +699,7 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
 
     __syncthreads();
 
-    const bool wave_live = __ballot(live) != 0ull;
+    const bool wave_live = __ballot(live || ev_idx >= 0) != 0ull;
     const uint32_t x16_frames = p.frames & ~(uint32_t)(kChunk - 1);      // frames in full 16-chunks
     // preconditions of the branch-free chunk that hold for the whole fill once they hold at its start
     // (phase' = fmodf(phase + 1/period, 1) stays in [0,1) for a positive period)
@@ -716,6 +734,36 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
         }
     };
 
+    // note events that land on the 16-frame boundary `fpos` (synth.rs:61-80 applied between two
+    // 16-frame sample() calls, main.rs:140-142): restart or release this lane's voice
+    auto apply_events_at = [&](uint32_t fpos) {
+        if (__ballot(ev_frame == fpos) == 0ull) return;
+        while (ev_frame == fpos) {
+            const S2rTimedEvent e = p.tev[ev_idx];
+            if (e.flags & S2R_EV_RESTART) {                  // *voice = Voice { .. }, synth.rs:63-69
+                r.pitch = e.pitch;
+                r.offset = 0u - fpos;                        // current_frame_offset == 0 at frame fpos
+                r.release_u = 0u;
+                r.released = (e.flags & S2R_EV_RELEASE) != 0u;
+                r.phase = 0.0f; r.last = 0.0f;
+                seed_now = e.seed;
+                r.seed_rot = (e.seed << 5) | (e.seed >> 27);
+                live = true;
+                k_const = make_osck<OSC>(p.sr / (1.0f * r.pitch));
+            } else if ((e.flags & S2R_EV_RELEASE) && live && !r.released) {   // synth.rs:74-75
+                r.released = true;
+                r.release_u = r.offset + fpos;
+            }
+            ev_dirty = true;
+            ev_idx = e.next;
+            ev_frame = ev_idx >= 0 ? p.tev[ev_idx].frame : 0xffffffffu;
+        }
+        const float rf = r.released ? (float)r.release_u : 4294967296.0f;
+        r.ro_a = __builtin_fmaxf(rf, p.amp.sus_off); r.end_a = r.ro_a + p.amp.R;
+        r.ro_m = __builtin_fmaxf(rf, p.mod.sus_off); r.end_m = r.ro_m + p.mod.R;
+        thr_min = -__builtin_inff();                         // re-run the envelope cascade
+    };
+
     // Frames are walked in super-chunks of 64 (one barrier and one cross-wave combine each), each
     // made of 16-frame chunks (one wave-local transpose-and-add each).
     for (uint32_t sc0 = 0; sc0 < p.frames; sc0 += kSuper) {
@@ -723,6 +771,7 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
         const uint32_t n_x16 = (x16_frames > sc0) ? ((x16_frames - sc0 < n_sc) ? (x16_frames - sc0) : n_sc) : 0u;
         if (wave_live) {
             for (uint32_t c16 = 0; c16 < n_x16; c16 += kChunk) {
+                if (TEV) apply_events_at(sc0 + c16);
                 const uint32_t o_chunk = r.offset + sc0 + c16;
                 // one wave-uniform decision per 16 frames: nobody reaches an envelope threshold in here
                 if (fast_ok && __ballot(!((float)(o_chunk + (kChunk - 1)) < thr_min)) == 0ull) {
@@ -790,6 +839,7 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
                 reduce_chunk(c16, kChunk);
             }
             if (n_x16 < n_sc) {                                          // scalar tail (< 16 frames, last super-chunk)
+                if (TEV) apply_events_at(sc0 + n_x16);
                 for (uint32_t i = n_x16; i < n_sc; ++i) {
                     float out = frame_sisd<OSC>(p, r, r.offset + sc0 + i, sT, sSin);
                     out = live ? out : 0.0f;
@@ -820,9 +870,16 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
     // ---- write back the recurrence state ----
     if (live && sub == 0) {
         const uint32_t o = r.offset;
-        p.v.offset[vi] = (o > 0xffffffffu - p.frames) ? 0xffffffffu : o + p.frames;   // synth.rs:197
+        // (a voice restarted at frame f carries offset = -f here, so the sum is frames - f)
+        p.v.offset[vi] = (!ev_dirty && o > 0xffffffffu - p.frames) ? 0xffffffffu : o + p.frames;   // synth.rs:197
         p.v.phase[vi] = r.phase;
         p.v.lpf_last[vi] = r.last;
+        if (ev_dirty) {
+            p.v.pitch[vi] = r.pitch;
+            p.v.release[vi] = r.release_u;
+            p.v.flags[vi] = S2R_VF_STARTED | (r.released ? S2R_VF_RELEASED : 0u);
+            p.v.seed[vi] = seed_now;
+        }
     }
 }
 
@@ -882,6 +939,14 @@ __global__ void s2r_sum_rows_kernel(const float *rows, uint32_t n_rows, uint32_t
     out[f] = total;
 }
 
+// publishes the first timed event of every touched voice
+__global__ void s2r_tev_heads_kernel(int32_t *heads, const S2rTimedEvent *tev, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const S2rTimedEvent e = tev[i];
+    if (e.flags & S2R_TEV_FIRST) heads[e.voice] = (int32_t)i;
+}
+
 // note events folded per voice by the host (synth.rs:61-80)
 __global__ void s2r_events_kernel(const S2rVoiceArrays v, const S2rVoiceEvent *ev, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -905,7 +970,7 @@ __global__ void s2r_events_kernel(const S2rVoiceArrays v, const S2rVoiceEvent *e
     }
 }
 
-template <int OSC, bool FM, bool PV>
+template <int OSC, bool FM, int MODE>
 hipError_t launch_l(const S2rRenderParams &p0, uint32_t block_voices, uint32_t lanes, hipStream_t stream) {
     S2rRenderParams p = p0;
     const uint32_t grid = (p.n_voices + block_voices - 1) / block_voices;
@@ -918,14 +983,14 @@ hipError_t launch_l(const S2rRenderParams &p0, uint32_t block_voices, uint32_t l
     const uint32_t threads = block_voices * lanes;
     switch (lanes) {
     case 1:
-        if (threads <= 256) hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, PV, 1, 256>), dim3(grid), block, lds, stream, p);
-        else hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, PV, 1, 1024>), dim3(grid), block, lds, stream, p);
+        if (threads <= 256) hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, MODE, 1, 256>), dim3(grid), block, lds, stream, p);
+        else hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, MODE, 1, 1024>), dim3(grid), block, lds, stream, p);
         break;
     case 2:
-        if (threads <= 512) hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, PV, 2, 512>), dim3(grid), block, lds, stream, p);
-        else hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, PV, 2, 1024>), dim3(grid), block, lds, stream, p);
+        if (threads > 512) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, MODE, 2, 512>), dim3(grid), block, lds, stream, p);
         break;
-    case 4: hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, PV, 4, 1024>), dim3(grid), block, lds, stream, p); break;
+    case 4: hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, MODE, 4, 1024>), dim3(grid), block, lds, stream, p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -935,9 +1000,13 @@ template <int OSC>
 hipError_t launch_osc(const S2rRenderParams &p, uint32_t block_voices, uint32_t lanes, hipStream_t stream) {
     // pow(2, mod * amount) == 1 exactly iff amount is +-0 (mod is always finite and >= 0)
     const bool fm = p.amt_osc != 0.0f;
-    const bool pv = p.per_voice != nullptr;       // mix-disabled debug/parity variant
-    if (fm) return pv ? launch_l<OSC, true, true>(p, block_voices, lanes, stream) : launch_l<OSC, true, false>(p, block_voices, lanes, stream);
-    return pv ? launch_l<OSC, false, true>(p, block_voices, lanes, stream) : launch_l<OSC, false, false>(p, block_voices, lanes, stream);
+    const int mode = p.per_voice != nullptr ? 1 : (p.tev != nullptr ? 2 : 0);
+    if (p.per_voice != nullptr && p.tev != nullptr) return hipErrorInvalidValue;   // the host refuses this combination
+    switch (mode) {
+    case 1: return fm ? launch_l<OSC, true, 1>(p, block_voices, lanes, stream) : launch_l<OSC, false, 1>(p, block_voices, lanes, stream);
+    case 2: return fm ? launch_l<OSC, true, 2>(p, block_voices, lanes, stream) : launch_l<OSC, false, 2>(p, block_voices, lanes, stream);
+    default: return fm ? launch_l<OSC, true, 0>(p, block_voices, lanes, stream) : launch_l<OSC, false, 0>(p, block_voices, lanes, stream);
+    }
 }
 
 }  // namespace
@@ -954,7 +1023,7 @@ hipError_t s2r_launch_coeff(const S2rRenderParams &p, hipStream_t stream) {
 hipError_t s2r_launch_render(const S2rRenderParams &p, uint32_t block_voices, uint32_t lanes_per_voice, hipStream_t stream) {
     if (p.n_voices == 0 || p.frames == 0) return hipSuccess;
     if (block_voices < 64 || block_voices > 1024 || (block_voices & 63u)) return hipErrorInvalidValue;
-    if (block_voices * lanes_per_voice > 1024) return hipErrorInvalidValue;
+    if (block_voices * lanes_per_voice > 1024 || (lanes_per_voice == 2 && block_voices > 256)) return hipErrorInvalidValue;
     switch (p.osc_kind) {
     case S2R_OSC_SQUARE: return launch_osc<S2R_OSC_SQUARE>(p, block_voices, lanes_per_voice, stream);
     case S2R_OSC_SAW: return launch_osc<S2R_OSC_SAW>(p, block_voices, lanes_per_voice, stream);
@@ -976,6 +1045,12 @@ hipError_t s2r_launch_mix(const S2rMixParams &m, hipStream_t stream) {
 hipError_t s2r_launch_events(const S2rVoiceArrays &v, const S2rVoiceEvent *dev_events, uint32_t n, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(s2r_events_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, v, dev_events, n);
+    return hipGetLastError();
+}
+
+hipError_t s2r_launch_tev_heads(int32_t *heads, const S2rTimedEvent *tev, uint32_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(s2r_tev_heads_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, heads, tev, n);
     return hipGetLastError();
 }
 

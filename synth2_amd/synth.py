@@ -70,7 +70,7 @@ VOICE_STATE_DTYPE = np.dtype([("note", np.uint8), ("started", np.uint8), ("relea
                               ("pitch_hz", np.float32), ("phase_accum", np.float32), ("lpf_last", np.float32),
                               ("noise_seed", np.uint32), ("velocity", np.float32)])
 assert VOICE_STATE_DTYPE.itemsize == C.sizeof(VoiceState)
-NOTE_EVENT_DTYPE = np.dtype([("kind", np.uint8), ("note", np.uint8), ("_pad", np.uint8, (2,)), ("velocity", np.float32)])
+NOTE_EVENT_DTYPE = np.dtype([("kind", np.uint8), ("note", np.uint8), ("frame", np.uint16), ("velocity", np.float32)])
 assert NOTE_EVENT_DTYPE.itemsize == 8
 
 

@@ -362,3 +362,64 @@ def test_c3_full_size_65536_voices():
 def test_c4_shard_size_131072_voices():
     """BASELINE config 3's per-GPU share: 1 048 576 voices / 8 GPUs"""
     _full_size(131072, 2, 256)
+
+
+@pytest.mark.parametrize("voices,lanes", [(8, 1), (8, 4), (300, 1), (300, 2)])
+def test_timed_events_reproduce_the_16_frame_call_pattern(voices, lanes):
+    """note events stamped with a frame offset take effect INSIDE one 1024-frame launch exactly as
+    if the caller had called sample() 16 frames at a time with MIDI applied in between, which is
+    what s2_bin does (main.rs:138-143): the oracle is driven that way, chunk by chunk."""
+    pr = Pair(voices, lanes=lanes, max_frames=1024)
+    rng = np.random.RandomState(voices * 7 + lanes)
+    held = []
+    for b in range(8):
+        frames = 1024 if b != 5 else 1000                 # one ragged buffer: tail frames + an event at the tail boundary
+        n_ev = int(rng.randint(0, 40))
+        times = np.sort(rng.randint(0, (frames + 15) // 16, n_ev)) * 16
+        if b == 5 and n_ev:
+            times[-1] = 992                               # the scalar tail starts here
+        ev = np.zeros(n_ev, dtype=s2.NOTE_EVENT_DTYPE)
+        for i, t in enumerate(times):
+            on = (not held) or rng.randint(0, 3) > 0
+            if on:
+                note = int(rng.randint(40, 90)); held.append(note)
+            else:
+                note = held.pop(int(rng.randint(len(held))))
+            ev[i] = (1 if on else 0, note, int(t), 1.0)
+        pr.gpu.note_events(ev)
+        g = pr.gpu.sample(np.empty(frames, dtype=np.float32))
+        pv = np.zeros((voices, frames), dtype=np.float32)
+        k = 0
+        for c in range(0, frames, 16):
+            while k < n_ev and ev["frame"][k] == c:
+                if ev["kind"][k]:
+                    pr.cpu.note_on(int(ev["note"][k]))
+                else:
+                    pr.cpu.note_off(int(ev["note"][k]))
+                k += 1
+            n = min(16, frames - c)
+            pv[:, c:c + n] = pr.cpu.render_voices(n)
+        assert k == n_ev
+        o = s2o.mix_tree(pv, pr.block_voices, 1)
+        assert_bits_equal(g, o, "timed events, %d voices, L=%d, buffer %d" % (voices, lanes, b))
+    st = pr.gpu.export_state()
+    for v in range(voices):
+        cv = pr.cpu.voice(v)
+        assert bool(st["started"][v]) == bool(cv.has_current)
+        if cv.has_current:
+            assert st["current_frame_offset"][v] == cv.current_frame_offset
+            assert bool(st["released"][v]) == bool(cv.has_release)
+            if cv.has_release:
+                assert st["release_frame_offset"][v] == cv.release_frame_offset
+
+
+def test_timed_event_errors():
+    s = s2.Synth(8, max_frames=256)
+    ev = np.zeros(1, dtype=s2.NOTE_EVENT_DTYPE)
+    ev[0] = (1, 60, 24, 1.0)                 # not a multiple of 16
+    with pytest.raises(s2.S2rError):
+        s.note_events(ev)
+    ev[0] = (1, 60, 256, 1.0)                # at the end of the buffer: belongs to the next fill
+    s.note_events(ev)
+    with pytest.raises(s2.S2rError):
+        s.sample(np.empty(256, dtype=np.float32))
