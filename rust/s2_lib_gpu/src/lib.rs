@@ -44,7 +44,18 @@ pub mod ffi {
         _private: [u8; 0],
     }
 
+    /// include/s2r.h `s2r_note_event`: `frame` = 0 or the 16-frame boundary inside the next fill
+    #[repr(C)]
+    #[derive(Copy, Clone)]
+    pub struct S2rNoteEvent {
+        pub kind: u8, // 0 = note_off, 1 = note_on
+        pub note: u8,
+        pub frame: u16,
+        pub velocity: f32,
+    }
+
     extern "C" {
+        pub fn s2r_note_events(s: *mut S2rSynth, events: *const S2rNoteEvent, n: usize) -> c_int;
         pub fn s2r_create(cfg: *const S2rConfig, out: *mut *mut S2rSynth) -> c_int;
         pub fn s2r_destroy(s: *mut S2rSynth);
         pub fn s2r_load_patch(s: *mut S2rSynth, text: *const c_char, len: usize) -> c_int;
@@ -140,6 +151,15 @@ pub mod synth {
         /// synth.rs:72-80
         pub fn note_off(&mut self, note: Note) {
             let rc = unsafe { ffi::s2r_note_off(self.handle, note.0) };
+            if rc != 0 {
+                fail(self.handle, rc);
+            }
+        }
+
+        /// Events stamped with the 16-frame boundary (`frame`) at which s2_bin's loop
+        /// (main.rs:138-143) would have applied them; they take effect inside the next `sample`.
+        pub fn note_events(&mut self, events: &[ffi::S2rNoteEvent]) {
+            let rc = unsafe { ffi::s2r_note_events(self.handle, events.as_ptr(), events.len()) };
             if rc != 0 {
                 fail(self.handle, rc);
             }
