@@ -6,7 +6,7 @@
 set -u
 TAG=${1:-run}; shift || true
 OUT=/root/repo/gpurun_out/prof_$TAG
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 ARGS="--steps 16 --warmup 4 --no-cpu-baseline $*"

@@ -27,9 +27,21 @@ def main():
             r = rows[-1]
             out["dispatch"] = {k: r[k] for k in ("Kernel_Name", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count",
                                                   "SGPR_Count", "Workgroup_Size_X", "Grid_Size_X") if k in r}
+            rows.sort(key=lambda r: int(r["Start_Timestamp"]))
             d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
             out["dispatch"]["avg_ns"] = sum(d) / len(d)
             out["dispatch"]["n"] = len(d)
+            # bench.py launches the render kernel in a fixed order: warmup, the K timed steps, 16
+            # launches timed with HIP events (-> roofline.kernel_ms), 16 more with every shortcut off
+            # (-> roofline_valu.kernel_ms), ...; the same slices of the trace, for comparison
+            w = int(os.environ.get("S2R_PROF_WARMUP", "4")); k = int(os.environ.get("S2R_PROF_STEPS", "16"))
+            m = min(k, 16)
+            def avg(a, b):
+                seg = d[a:b]
+                return sum(seg) / len(seg) if seg else None
+            out["dispatch"]["phases_avg_ns"] = {"warmup": avg(0, w), "timed_steps": avg(w, w + k),
+                                                "kernel_ms_launches": avg(w + k, w + k + m),
+                                                "kernel_ms_all_modulating_launches": avg(w + k + m, w + k + 2 * m)}
     counters = defaultdict(list)
     for sub in ("pmc1", "pmc2", "pmc_fetch", "pmc_write"):
         for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
