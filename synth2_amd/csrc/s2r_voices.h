@@ -15,6 +15,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <deque>
 #include <functional>
 #include <queue>
 #include <utility>
@@ -40,7 +41,7 @@ class S2rVoicePool {
     // synth.rs:101-120
     uint32_t next_voice() const {
         if (idle_head_ < idle_.size()) return idle_[idle_head_];
-        return started_.top().second;
+        return started_front().second;
     }
 
     // synth.rs:61-70; returns the chosen index
@@ -49,9 +50,9 @@ class S2rVoicePool {
         if (idle_head_ < idle_.size()) {
             i = idle_[idle_head_++];
         } else {
-            // the chosen voice is always the heap's top, so the heap never holds stale entries
-            i = started_.top().second;
-            started_.pop();
+            // the chosen voice is always the queue's minimum, so it never holds stale entries
+            i = started_front().second;
+            started_pop();
             S2rHostVoice &old = voices_[i];
             if (!old.released) active_valid_[old.note]--;      // its active_ entry goes stale (gen bump)
         }
@@ -60,7 +61,7 @@ class S2rVoicePool {
         v.started = true; v.released = false;
         v.gen++;
         v.start_clock = now_; v.release_clock = 0;
-        started_.push({now_, i});
+        started_push(now_, i);
         push_active(note, i, v.gen);
         return i;
     }
@@ -95,8 +96,8 @@ class S2rVoicePool {
     }
     // greatest current_frame_offset among started voices (0 if none)
     uint64_t oldest_offset() const {
-        if (started_.empty()) return 0;
-        return now_ - started_.top().first;
+        if (buckets_.empty()) return 0;
+        return now_ - started_front().first;
     }
 
     // restore one voice (import_state); call rebuild() afterwards
@@ -123,21 +124,56 @@ class S2rVoicePool {
         }
         pending_.clear(); pending_min_clock_ = 0;
         idle_.clear(); idle_head_ = 0;
-        started_ = StartedHeap();
+        buckets_.clear();
+        std::vector<std::pair<uint64_t, uint32_t>> all;
         for (int n = 0; n < 256; n++) { active_[n] = ActiveHeap(); active_valid_[n] = 0; }
         for (uint32_t i = 0; i < voices_.size(); i++) {
             const S2rHostVoice &v = voices_[i];
             if (!v.started) { idle_.push_back(i); continue; }
-            started_.push({v.start_clock, i});
+            all.push_back({v.start_clock, i});
             if (!v.released) push_active(v.note, i, v.gen);
         }
+        std::sort(all.begin(), all.end());
+        for (const auto &e : all) started_push(e.first, e.second);
     }
 
   private:
     struct Pending { uint32_t i, offset, release_offset; };
-    typedef std::pair<uint64_t, uint32_t> StartedKey;                 // (start_clock, index)
-    typedef std::priority_queue<StartedKey, std::vector<StartedKey>, std::greater<StartedKey>> StartedHeap;
     typedef std::priority_queue<std::pair<uint32_t, uint32_t>> ActiveHeap;   // max (index, gen)
+
+    // Started voices ordered by (start_clock, index).  The pool clock never goes back, so keys
+    // arrive in non-decreasing clock order: a deque of per-clock buckets, each an index list that
+    // is sorted lazily when it reaches the front.  pop-min and push are O(1) amortised (one
+    // std::sort per bucket), against two ~19-level heap operations on a half-million-entry heap —
+    // every rank of an N-GPU run simulates the WHOLE pool's events, so this is on its critical path.
+    struct Bucket {
+        uint64_t clock;
+        std::vector<uint32_t> idx;
+        size_t head = 0;
+        bool sorted = true;
+    };
+    std::pair<uint64_t, uint32_t> started_front() const {     // (lazy sort: buckets_ is mutable)
+        Bucket &b = buckets_.front();
+        if (!b.sorted) { std::sort(b.idx.begin() + (std::ptrdiff_t)b.head, b.idx.end()); b.sorted = true; }
+        return {b.clock, b.idx[b.head]};
+    }
+    void started_pop() {
+        Bucket &b = buckets_.front();
+        if (++b.head == b.idx.size()) buckets_.pop_front();
+    }
+    void started_push(uint64_t clock, uint32_t i) {
+        if (buckets_.empty() || buckets_.back().clock != clock) {
+            buckets_.emplace_back();
+            buckets_.back().clock = clock;
+        }
+        Bucket &b = buckets_.back();
+        if (b.head > 0 && b.head < b.idx.size() && b.sorted && i <= b.idx[b.head]) {
+            b.idx[--b.head] = i;                  // re-queued at its own clock: still the minimum
+            return;
+        }
+        if (b.idx.size() > b.head && i < b.idx.back()) b.sorted = false;
+        b.idx.push_back(i);
+    }
 
     void push_active(uint8_t note, uint32_t i, uint32_t gen) {
         ActiveHeap &a = active_[note];
@@ -158,7 +194,7 @@ class S2rVoicePool {
     std::vector<S2rHostVoice> voices_;
     std::vector<uint32_t> idle_;        // ascending; consumed from idle_head_ (voices never go idle again)
     size_t idle_head_ = 0;
-    StartedHeap started_;               // one entry per started voice
+    mutable std::deque<Bucket> buckets_;   // one entry per started voice
     ActiveHeap active_[256];
     uint32_t active_valid_[256] = {};
     std::vector<Pending> pending_;
