@@ -252,6 +252,49 @@ float s2o_lpf_process(float *last, uint32_t sample_rate_u, float freq, float inp
     return out;
 }
 
+/* ------------------------------------------------------------------ dsp_filters.rs */
+
+/* dsp_filters.rs:25-45 (LP1), :60-80 (HP1), :99-130 (LP2), :149-180 (HP2).  No `fma` feature
+ * switch in that file: every operation is rounded separately, in Rust's evaluation order.
+ * sin/cos are Rust f32::sin/cos = the host libm's sinf/cosf. */
+float s2o_dsp_filter_process(int kind, float *x1p, float *x2p, float *y1p, float *y2p,
+                             uint32_t sample_rate_u, float cutoff_freq, float damping_factor, float input) {
+    const float PI = 3.14159274101257324f;
+    float sample_rate = (float)sample_rate_u;
+    float theta_cutoff = 2.0f * PI * cutoff_freq / sample_rate;
+    float x1 = *x1p, x2 = *x2p, y1 = *y1p, y2 = *y2p;
+    float x = input, y;
+    if (kind == S2O_FILT_LP1 || kind == S2O_FILT_HP1) {
+        float gamma = cosf(theta_cutoff) / (1.0f + sinf(theta_cutoff));
+        if (kind == S2O_FILT_LP1) {
+            float alpha = (1.0f - gamma) / 2.0f;
+            y = alpha * (x + x1) + gamma * y1;
+        } else {
+            float alpha = (1.0f + gamma) / 2.0f;
+            y = alpha * (x - x1) + gamma * y1;
+        }
+        *x1p = x; *y1p = y;
+        return y;
+    }
+    float s = sinf(theta_cutoff);
+    float beta = (1.0f / 2.0f) * ((1.0f - damping_factor / 2.0f * s) / (1.0f + damping_factor / 2.0f * s));
+    float gamma = (1.0f / 2.0f + beta) * cosf(theta_cutoff);
+    if (kind == S2O_FILT_LP2) {
+        float alpha = (1.0f / 2.0f + beta - gamma) / 4.0f;
+        y = 2.0f * (alpha * (x + 2.0f * x1 + x2) + gamma * y1 - beta * y2);
+    } else {
+        float alpha = (1.0f / 2.0f + beta + gamma) / 4.0f;
+        y = 2.0f * (alpha * (x - 2.0f * x1 + x2) + gamma * y1 - beta * y2);
+    }
+    *x2p = x1; *x1p = x; *y2p = y1; *y1p = y;
+    return y;
+}
+
+static float layer_filter(const s2o_layer_cfg *c, s2o_layer_state *st, uint32_t sr, float freq, float input) {
+    if (c->lpf_kind == S2O_FILT_ONEPOLE) return s2o_lpf_process(&st->lpf_last, sr, freq, input);
+    return s2o_dsp_filter_process(c->lpf_kind, &st->x1, &st->x2, &st->y1, &st->y2, sr, freq, c->lpf_damping, input);
+}
+
 /* ------------------------------------------------------------------ oscillators.rs */
 
 /* oscillators.rs:377-381  accum_phase */
@@ -363,7 +406,7 @@ static void sample_voice_x16(const s2o_layer_cfg *c, const plan_x16 *p, s2o_laye
     }
     st->has_phase = 1; st->phase_accum = next;                               /* oscillators.rs:492 */
     for (int i = 0; i < 16; i++)                                             /* :363-371 sequential */
-        samples[i] = s2o_lpf_process(&st->lpf_last, sr, p->lpf_freqs[i], samples[i]);
+        samples[i] = layer_filter(c, st, sr, p->lpf_freqs[i], samples[i]);
     for (int i = 0; i < 16; i++) out[i] = samples[i] * p->gains[i];          /* :373-376 */
 }
 
@@ -387,7 +430,7 @@ static float process_layer(const s2o_layer_cfg *c, s2o_layer_state *st, float pi
     float noise = s2o_hash_noise(st->seed, (float)offset);                   /* :289-291 */
     float noise_sample = noise * c->noise;                                   /* :292  MULTIPLY */
     float sample = osc_sample_ + noise_sample;
-    sample = s2o_lpf_process(&st->lpf_last, sr, lpf_freq, sample);
+    sample = layer_filter(c, st, sr, lpf_freq, sample);
     return sample * amp;                                                     /* :302 */
 }
 
@@ -432,6 +475,8 @@ s2o_layer_cfg s2o_default_config(void) {
     c.mod_env.attack_ms = 0.0f; c.mod_env.decay_ms = 200.0f; c.mod_env.sustain = 0.0f; c.mod_env.release_ms = 0.0f;
     c.mod_env_to_osc_freq = 0.0f;
     c.mod_env_to_lpf_freq = 10.0f;
+    c.lpf_kind = S2O_FILT_ONEPOLE;
+    c.lpf_damping = 1.41421354f;     /* "sqrt(2) is neutral", dsp_filters.rs:95 */
     return c;
 }
 

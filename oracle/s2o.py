@@ -22,11 +22,13 @@ class AdsrCfg(C.Structure):
 class LayerCfg(C.Structure):
     _fields_ = [("osc_kind", C.c_int32), ("osc_gain", C.c_float), ("noise", C.c_float), ("lpf_freq", C.c_float),
                 ("amp_env", AdsrCfg), ("mod_env", AdsrCfg),
-                ("mod_env_to_osc_freq", C.c_float), ("mod_env_to_lpf_freq", C.c_float)]
+                ("mod_env_to_osc_freq", C.c_float), ("mod_env_to_lpf_freq", C.c_float),
+                ("lpf_kind", C.c_int32), ("lpf_damping", C.c_float)]
 
 
 class LayerState(C.Structure):
-    _fields_ = [("has_phase", C.c_int32), ("phase_accum", C.c_float), ("seed", C.c_uint32), ("lpf_last", C.c_float)]
+    _fields_ = [("has_phase", C.c_int32), ("phase_accum", C.c_float), ("seed", C.c_uint32), ("lpf_last", C.c_float),
+                ("x1", C.c_float), ("x2", C.c_float), ("y1", C.c_float), ("y2", C.c_float)]
 
 
 class Voice(C.Structure):

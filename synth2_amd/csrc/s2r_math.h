@@ -248,3 +248,69 @@ S2R_HD float s2r_fmod_period(float off, float period) {
     return __builtin_fmodf(off, period);
 #endif
 }
+
+// ---------------------------------------------------------------------------------------
+// glibc sinf / cosf (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h; FMA ifunc variant):
+// double-precision polynomials after a quadrant reduction, rounded once to float.  Used by the
+// second-order filters of dsp_filters.rs (Rust f32::sin / f32::cos).  Valid for |y| < 120
+// (glibc's reduce_fast range; beyond it glibc switches to a 4/pi table walk that is not
+// restated here — the caller keeps theta = 2 pi f / sr below that).
+// ---------------------------------------------------------------------------------------
+typedef struct s2r_sincos_poly { double c0, c1, c2, c3, c4, s1, s2, s3; } s2r_sincos_poly;
+
+S2R_HD float s2r_sinf_poly(double x, double x2, int negate_cos, int n) {
+    const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5,
+                 c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
+    const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+    if ((n & 1) == 0) {
+        const double x3 = x * x2;
+        const double t1 = __builtin_fma(x2, s3, s2);
+        const double x7 = x3 * x2;
+        const double s = __builtin_fma(x3, s1, x);
+        return (float)__builtin_fma(x7, t1, s);
+    } else {
+        const double sg = negate_cos ? -1.0 : 1.0;
+        const double x4 = x2 * x2;
+        const double t2 = __builtin_fma(x2, sg * c4, sg * c3);
+        const double t1 = __builtin_fma(x2, sg * c1, sg * c0);
+        const double x6 = x4 * x2;
+        const double c = __builtin_fma(x4, sg * c2, t1);
+        return (float)__builtin_fma(x6, t2, c);
+    }
+}
+
+// quadrant reduction of reduce_fast (!TOINT_INTRINSICS): hpi_inv is 2/pi * 2^24
+S2R_HD double s2r_reduce_fast(double x, int *np) {
+    const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+    const double r = x * hpi_inv;
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    *np = n;
+    return __builtin_fma(-(double)n, hpi, x);
+}
+
+S2R_HD float s2r_sinf(float y) {
+    const uint32_t top = (s2r_f2u(y) >> 20) & 0x7ff;
+    double x = (double)y;
+    if (top < 0x3f4) {                                  // |y| < pi/4   (abstop12(0x1.921FB6p-1f) = 0x3f4)
+        if (top < 0x398) return y;                      // |y| < 2^-12
+        return s2r_sinf_poly(x, x * x, 0, 0);
+    }
+    int n;
+    x = s2r_reduce_fast(x, &n);
+    const double sg = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;      // sign[n & 3] = {1,-1,-1,1}
+    return s2r_sinf_poly(x * sg, x * x, (n & 2) != 0, n);
+}
+
+S2R_HD float s2r_cosf(float y) {
+    const uint32_t top = (s2r_f2u(y) >> 20) & 0x7ff;
+    double x = (double)y;
+    if (top < 0x3f4) {
+        if (top < 0x398) return 1.0f;
+        return s2r_sinf_poly(x, x * x, 0, 1);
+    }
+    int n;
+    x = s2r_reduce_fast(x, &n);
+    const int m = n + 1;
+    const double sg = ((m & 3) == 1 || (m & 3) == 2) ? -1.0 : 1.0;
+    return s2r_sinf_poly(x * sg, x * x, (m & 2) != 0, n ^ 1);
+}
