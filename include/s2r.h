@@ -61,7 +61,21 @@ typedef struct {
     s2r_adsr mod_env;
     float mod_env_to_osc_freq;     /* Bipolar<10>           sc::Modulations */
     float mod_env_to_lpf_freq;     /* Bipolar<10> */
+    /* Which filter the layer runs at the modulated cutoff.  The reference's live path is the
+     * one-pole of filters.rs (S2R_FILT_ONEPOLE, the default); dsp_filters.rs:25-180 holds four
+     * more that nothing in the reference calls yet — here they are selectable per patch. */
+    int32_t lpf_kind;              /* s2r_filter_kind */
+    float lpf_damping;             /* Unipolar<10>          SecondOrder*Filter.damping_factor
+                                      (dsp_filters.rs:95 "sqrt(2) is neutral"), LP2/HP2 only */
 } s2r_patch;
+
+typedef enum {
+    S2R_FILT_ONEPOLE = 0,          /* filters.rs:16-34          LowPassFilter */
+    S2R_FILT_LP1 = 1,              /* dsp_filters.rs:25-45      FirstOrderLowPassFilter */
+    S2R_FILT_HP1 = 2,              /* dsp_filters.rs:60-80      FirstOrderHighPassFilter */
+    S2R_FILT_LP2 = 3,              /* dsp_filters.rs:99-130     SecondOrderLowPassFilter */
+    S2R_FILT_HP2 = 4               /* dsp_filters.rs:149-180    SecondOrderHighPassFilter */
+} s2r_filter_kind;
 
 typedef struct {
     uint32_t struct_size;          /* = sizeof(s2r_config) */
@@ -96,6 +110,7 @@ typedef struct {
     float lpf_last;                /* LowPassFilterState.last */
     uint32_t noise_seed;           /* NoiseState.seed (always 0 in the reference, synth.rs:68) */
     float velocity;                /* stored, never used in rendering (synth.rs:18,26) */
+    float filt_x1, filt_x2, filt_y1, filt_y2;   /* dsp_filters.rs:12-17,82-89 filter states */
 } s2r_voice_state;
 
 typedef struct s2r_synth s2r_synth;

@@ -24,7 +24,8 @@ struct S2rEnv {
 };
 
 // Per-voice state, struct-of-arrays in HBM (one entry per shard voice, padded to a whole
-// number of workgroups).  28 B are read and 12 B written per started voice per fill.
+// number of workgroups).  28 B are read and 12 B written per started voice per fill
+// (+16 B each way under the second-order filters).
 struct S2rVoiceArrays {
     float *pitch;         // note_to_pitch(note)             synth.rs:179,208-212
     uint32_t *offset;     // current_frame_offset            synth.rs:27
@@ -33,7 +34,10 @@ struct S2rVoiceArrays {
     float *phase;         // OscillatorState.phase_accum     oscillators.rs:402-406
     float *lpf_last;      // LowPassFilterState.last         filters.rs:5-7
     uint32_t *seed;       // NoiseState.seed                 state.rs:17-21
+    // dsp_filters.rs:12-17,82-89 states; only touched by patches with lpf.kind != onepole
+    float *fx1, *fx2, *fy1, *fy2;
 };
+#define S2R_VOICE_WORDS 11
 
 struct S2rTimedEvent;
 
@@ -45,6 +49,8 @@ struct S2rRenderParams {
     float lpf_freq;
     float amt_osc;        // mod_env_to_osc_freq
     float amt_lpf;        // mod_env_to_lpf_freq
+    int32_t lpf_kind;     // s2r_filter_kind; != 0 renders through s2r_render_dspf_kernel
+    float lpf_damping;
     S2rEnv amp;
     S2rEnv mod;
     float sr;             // sample_rate as f32 (units.rs:21)

@@ -22,6 +22,7 @@
 namespace {
 
 constexpr int kEventSlots = 4;
+constexpr size_t kVoiceWords = S2R_VOICE_WORDS;    // 32-bit words of per-voice state (S2rVoiceArrays)
 
 // components/s2_bin/src/tables.rs:6-10 regenerated; see oracle/s2_oracle.c for the note on
 // the four entries the reference's literal table (tables.rs) rounds one ULP away from zero.
@@ -207,6 +208,16 @@ int check_fill(s2r_synth *s, size_t frames, uint32_t sample_rate) {
         return set_err(s, S2R_ERR_INVALID, "a timed event at frame %u does not fall inside this %zu-frame fill", s->fill_time, frames);
     if (s->pool->oldest_offset() + (frames - s->fill_time) > 0xffffffffull)
         return set_err(s, S2R_ERR_OFFSET_OVERFLOW, "a voice's frame offset would overflow u32 (the reference panics here)");
+    if (s->patch.lpf_kind != S2R_FILT_ONEPOLE) {
+        // dsp_filters.rs evaluates sin/cos of theta = 2 pi f / sr.  The device restatement of the libm
+        // routines is exact for every finite argument; only an overflowing 2 pi f (inf -> NaN, whose
+        // sign bit differs between x86 and the GPU) is refused.
+        const double amt = s->patch.mod_env_to_lpf_freq > 0.0f ? (double)s->patch.mod_env_to_lpf_freq : 0.0;
+        const double num_max = 2.0 * 3.14159265358979323846 * (double)s->patch.lpf_freq * std::exp2(amt) * 1.000001;
+        if (!(num_max < 3.4028234e38))
+            return set_err(s, S2R_ERR_PATCH_RANGE, "lpf.kind %d: 2 pi * lpf.freq * 2^mod_env_to_lpf_freq overflows f32",
+                           s->patch.lpf_kind);
+    }
     return S2R_OK;
 }
 
@@ -218,6 +229,8 @@ S2rRenderParams make_params(s2r_synth *s, size_t frames, uint32_t sample_rate) {
     p.lpf_freq = s->patch.lpf_freq;
     p.amt_osc = s->patch.mod_env_to_osc_freq;
     p.amt_lpf = s->patch.mod_env_to_lpf_freq;
+    p.lpf_kind = s->patch.lpf_kind;
+    p.lpf_damping = s->patch.lpf_damping;
     p.amp = resolve_env(s->patch.amp_env, sample_rate);
     p.mod = resolve_env(s->patch.mod_env, sample_rate);
     p.sr = (float)sample_rate;
@@ -234,7 +247,8 @@ S2rRenderParams make_params(s2r_synth *s, size_t frames, uint32_t sample_rate) {
     p.per_voice = nullptr;
     p.sin_table = s->sin_dev;
     // stream only where it is defined: no oscillator FM, the flat-envelope logic enabled
-    p.use_coeff = (s->use_coeff && !s->no_flat_shortcut && s->patch.mod_env_to_osc_freq == 0.0f && s->coeff != nullptr) ? 1 : 0;
+    p.use_coeff = (s->use_coeff && !s->no_flat_shortcut && s->patch.mod_env_to_osc_freq == 0.0f && s->coeff != nullptr &&
+                   s->patch.lpf_kind == S2R_FILT_ONEPOLE) ? 1 : 0;
     p.group_slot = s->group_slot; p.group_slot_w = s->group_slot; p.slot_group = s->slot_group;
     p.coeff_count = s->coeff_count; p.coeff_parity = s->coeff_parity; p.coeff_capacity = s->coeff_capacity;
     p.coeff = s->coeff;
@@ -402,8 +416,8 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
     CREATE_HIP(hipSetDevice(dev));
     CREATE_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     const size_t pv = s->padded_voices;
-    CREATE_HIP(hipMalloc(&s->voice_mem, pv * 7 * sizeof(uint32_t)));
-    CREATE_HIP(hipMemsetAsync(s->voice_mem, 0, pv * 7 * sizeof(uint32_t), s->stream));
+    CREATE_HIP(hipMalloc(&s->voice_mem, pv * kVoiceWords * sizeof(uint32_t)));
+    CREATE_HIP(hipMemsetAsync(s->voice_mem, 0, pv * kVoiceWords * sizeof(uint32_t), s->stream));
     uint32_t *base = (uint32_t *)s->voice_mem;
     s->v.pitch = (float *)(base + 0 * pv);
     s->v.offset = base + 1 * pv;
@@ -412,6 +426,10 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
     s->v.phase = (float *)(base + 4 * pv);
     s->v.lpf_last = (float *)(base + 5 * pv);
     s->v.seed = base + 6 * pv;
+    s->v.fx1 = (float *)(base + 7 * pv);
+    s->v.fx2 = (float *)(base + 8 * pv);
+    s->v.fy1 = (float *)(base + 9 * pv);
+    s->v.fy2 = (float *)(base + 10 * pv);
     CREATE_HIP(hipMalloc((void **)&s->block_partials, (size_t)s->n_blocks * cfg->max_frames * sizeof(float)));
     CREATE_HIP(hipMalloc((void **)&s->out_dev, (size_t)2 * cfg->max_frames * sizeof(float)));
     CREATE_HIP(hipHostMalloc((void **)&s->out_host, (size_t)2 * cfg->max_frames * sizeof(float), hipHostMallocDefault));
@@ -619,8 +637,8 @@ int s2r_export_state(s2r_synth *s, s2r_voice_state *voices) {
     int rc = flush_events(s, s->stream, &ts, &td);
     if (rc != S2R_OK) return rc;
     const size_t pv = s->padded_voices;
-    std::vector<uint32_t> h(pv * 7);
-    S2R_HIP(s, hipMemcpyAsync(h.data(), s->voice_mem, pv * 7 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    std::vector<uint32_t> h(pv * kVoiceWords);
+    S2R_HIP(s, hipMemcpyAsync(h.data(), s->voice_mem, pv * kVoiceWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     S2R_HIP(s, hipStreamSynchronize(s->stream));
     for (uint32_t i = 0; i < s->shard_voices; i++) {
         const S2rHostVoice &hv = s->pool->voice(s->shard_begin + i);
@@ -636,6 +654,8 @@ int s2r_export_state(s2r_synth *s, s2r_voice_state *voices) {
         o.phase_accum = s2r_u2f(h[4 * pv + i]);
         o.lpf_last = s2r_u2f(h[5 * pv + i]);
         o.noise_seed = h[6 * pv + i];
+        o.filt_x1 = s2r_u2f(h[7 * pv + i]); o.filt_x2 = s2r_u2f(h[8 * pv + i]);
+        o.filt_y1 = s2r_u2f(h[9 * pv + i]); o.filt_y2 = s2r_u2f(h[10 * pv + i]);
         o.velocity = hv.velocity;
     }
     return S2R_OK;
@@ -649,7 +669,7 @@ int s2r_import_state(s2r_synth *s, const s2r_voice_state *voices) {
     s->pending.clear();
     if (!s->tpending.empty()) return set_err(s, S2R_ERR_INVALID, "import_state with timed events pending");
     const size_t pv = s->padded_voices;
-    std::vector<uint32_t> h(pv * 7, 0u);
+    std::vector<uint32_t> h(pv * kVoiceWords, 0u);
     for (uint32_t i = 0; i < s->shard_voices; i++) {
         const s2r_voice_state &in = voices[i];
         h[0 * pv + i] = s2r_f2u(in.started ? in.pitch_hz : 0.0f);
@@ -659,11 +679,13 @@ int s2r_import_state(s2r_synth *s, const s2r_voice_state *voices) {
         h[4 * pv + i] = s2r_f2u(in.phase_accum);
         h[5 * pv + i] = s2r_f2u(in.lpf_last);
         h[6 * pv + i] = in.noise_seed;
+        h[7 * pv + i] = s2r_f2u(in.filt_x1); h[8 * pv + i] = s2r_f2u(in.filt_x2);
+        h[9 * pv + i] = s2r_f2u(in.filt_y1); h[10 * pv + i] = s2r_f2u(in.filt_y2);
         s->pool->set_voice(s->shard_begin + i, in.note, in.started != 0, in.released != 0,
                            in.current_frame_offset, in.release_frame_offset, in.velocity);
     }
     s->pool->rebuild();
-    S2R_HIP(s, hipMemcpyAsync(s->voice_mem, h.data(), pv * 7 * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+    S2R_HIP(s, hipMemcpyAsync(s->voice_mem, h.data(), pv * kVoiceWords * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
     S2R_HIP(s, hipStreamSynchronize(s->stream));
     return S2R_OK;
 }

@@ -424,10 +424,47 @@ __device__ __forceinline__ float recur_x16(const S2rRenderParams &p, VoiceRegs &
     return y * cf.amp;                                           // process.rs:373-376
 }
 
-// One frame of process_layer (scalar "sisd" path: process.rs:101-135,252-304).
-template <int OSC>
+// dsp_filters.rs:12-17,82-89: the delayed inputs / outputs of the first- and second-order filters
+struct Filt2 { float x1, x2, y1, y2; };
+
+// dsp_filters.rs:25-45 (LP1), :60-80 (HP1), :99-130 (LP2), :149-180 (HP2): one step at cutoff f.
+// That file has no `fma` switch: every operation is rounded separately, in Rust's evaluation
+// order; sin/cos are the libm routines (s2r_sinf/s2r_cosf, bit-exact for every finite theta).
+__device__ __forceinline__ float dsp_filter_step(int kind, float damping, float sr, float cutoff, float x, Filt2 &f) {
+    const float theta = 2.0f * 3.14159274101257324f * cutoff / sr;           // 2.0 * PI * cutoff_freq / sample_rate
+    const float sn = s2r_sinf(theta), cs = s2r_cosf(theta);
+    float y;
+    if (kind == S2R_FILT_LP1 || kind == S2R_FILT_HP1) {
+        const float gamma = cs / (1.0f + sn);
+        if (kind == S2R_FILT_LP1) {
+            const float alpha = (1.0f - gamma) / 2.0f;
+            y = alpha * (x + f.x1) + gamma * f.y1;
+        } else {
+            const float alpha = (1.0f + gamma) / 2.0f;
+            y = alpha * (x - f.x1) + gamma * f.y1;
+        }
+        f.x1 = x; f.y1 = y;
+        return y;
+    }
+    const float hd = damping / 2.0f;
+    const float beta = 0.5f * ((1.0f - hd * sn) / (1.0f + hd * sn));
+    const float gamma = (0.5f + beta) * cs;
+    if (kind == S2R_FILT_LP2) {
+        const float alpha = (0.5f + beta - gamma) / 4.0f;
+        y = 2.0f * (alpha * (x + 2.0f * f.x1 + f.x2) + gamma * f.y1 - beta * f.y2);
+    } else {
+        const float alpha = (0.5f + beta + gamma) / 4.0f;
+        y = 2.0f * (alpha * (x - 2.0f * f.x1 + f.x2) + gamma * f.y1 - beta * f.y2);
+    }
+    f.x2 = f.x1; f.x1 = x; f.y2 = f.y1; f.y1 = y;
+    return y;
+}
+
+// One frame of process_layer (scalar "sisd" path: process.rs:101-135,252-304).  DSPF: the layer's
+// filter is one of dsp_filters.rs (state in *f2) instead of the one-pole of filters.rs.
+template <int OSC, bool DSPF = false>
 __device__ float frame_sisd(const S2rRenderParams &p, VoiceRegs &r, uint32_t oi,
-                            const uint64_t *sT, const float *sSin) {
+                            const uint64_t *sT, const float *sSin, Filt2 *f2 = nullptr) {
     const float t = (float)oi;
     const float rel = r.released ? (float)r.release_u : 4294967296.0f;   // envelopes.rs:35
     const float amp = adsr_scalar(p.amp, t, rel);
@@ -442,6 +479,7 @@ __device__ float frame_sisd(const S2rRenderParams &p, VoiceRegs &r, uint32_t oi,
     const float osc_s = osc * p.osc_gain;                                // process.rs:287 (MULTIPLY)
     const float noise_s = (hash_noise(r.seed_rot, t)) * p.noise_level;   // process.rs:292 (MULTIPLY)
     const float s = osc_s + noise_s;
+    if (DSPF) return dsp_filter_step(p.lpf_kind, p.lpf_damping, p.sr, f_lpf, s, *f2) * amp;
     const float x = lpf_coeff<false>(p, f_lpf, sT);
     const float y = lpf_apply(x, s, r.last);
     return y * amp;
@@ -680,7 +718,7 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
     // timed events: this voice's chain for the fill (taken over and cleared for the next fill)
     int32_t ev_idx = -1;
     uint32_t ev_frame = 0xffffffffu;
-    bool ev_dirty = false;
+    bool ev_dirty = false, ev_restart = false;
     uint32_t seed_now = seed;
     if (TEV && in_range) {
         ev_idx = p.voice_ev_head[vi];
@@ -748,7 +786,7 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
                 r.phase = 0.0f; r.last = 0.0f;
                 seed_now = e.seed;
                 r.seed_rot = (e.seed << 5) | (e.seed >> 27);
-                live = true;
+                live = true; ev_restart = true;
                 k_const = make_osck<OSC>(p.sr / (1.0f * r.pitch));
             } else if ((e.flags & S2R_EV_RELEASE) && live && !r.released) {   // synth.rs:74-75
                 r.released = true;
@@ -879,6 +917,173 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
             p.v.release[vi] = r.release_u;
             p.v.flags[vi] = S2R_VF_STARTED | (r.released ? S2R_VF_RELEASED : 0u);
             p.v.seed[vi] = seed_now;
+            if (ev_restart) { p.v.fx1[vi] = 0.0f; p.v.fx2[vi] = 0.0f; p.v.fy1[vi] = 0.0f; p.v.fy2[vi] = 0.0f; }   // st::Layer::default()
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// render kernel for patches whose filter is one of dsp_filters.rs (lpf.kind != onepole).
+// Same voice-per-lane layout, state arrays, mixdown staging and timed events as
+// s2r_render_kernel (L = 1), but the frame loop is the plain one: every frame runs the envelope
+// cascade, both frequency modulations, the oscillator and the filter step, whose coefficients
+// need sin/cos of the modulated cutoff.  First correct version of this row;
+// none of the fast paths of the one-pole kernel apply yet.
+// ---------------------------------------------------------------------------------------
+template <int OSC>
+__global__ void __launch_bounds__(1024) s2r_render_dspf_kernel(const S2rRenderParams p) {
+    const uint32_t kSuper = p.super_frames;
+    const bool PV = p.per_voice != nullptr, TEV = p.tev != nullptr;          // wave-uniform
+    __shared__ uint64_t sT[S2R_EXP2F_N];
+    __shared__ float sSin[OSC == S2R_OSC_SINE ? 1024 : 1];
+    extern __shared__ float s_dyn[];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = tid >> 6, n_waves = blockDim.x >> 6;
+    constexpr uint32_t VW = 64, GW = 4;
+    const uint32_t n_groups = n_waves * GW;
+    float *const sW = s_dyn;                                     // [2][n_groups][kSuper]
+    float *const tile = s_dyn + 2 * n_groups * kSuper + wave * (kChunk * (VW + 1));
+    const uint32_t vi = blockIdx.x * blockDim.x + tid;
+
+    if (tid < S2R_EXP2F_N) sT[tid] = c_exp2f_table[tid];
+    if (OSC == S2R_OSC_SINE)
+        for (uint32_t i = tid; i < 1024u; i += blockDim.x) sSin[i] = p.sin_table[i];
+
+    const bool in_range = vi < p.n_voices;
+    const uint32_t flags = in_range ? p.v.flags[vi] : 0u;
+    bool live = (flags & S2R_VF_STARTED) != 0u;                  // synth.rs:178
+    VoiceRegs r;
+    r.pitch = live ? p.v.pitch[vi] : 440.0f;
+    r.offset = live ? p.v.offset[vi] : 0u;
+    r.release_u = live ? p.v.release[vi] : 0u;
+    r.released = live && (flags & S2R_VF_RELEASED) != 0u;
+    r.phase = live ? p.v.phase[vi] : 0.0f;
+    r.last = 0.0f;                                               // the one-pole state is not touched here
+    Filt2 f2;
+    f2.x1 = live ? p.v.fx1[vi] : 0.0f; f2.x2 = live ? p.v.fx2[vi] : 0.0f;
+    f2.y1 = live ? p.v.fy1[vi] : 0.0f; f2.y2 = live ? p.v.fy2[vi] : 0.0f;
+    const uint32_t seed = live ? p.v.seed[vi] : 0u;
+    r.seed_rot = (seed << 5) | (seed >> 27);
+    const float rel_f = r.released ? (float)r.release_u : 4294967296.0f;
+    r.ro_a = __builtin_fmaxf(rel_f, p.amp.sus_off); r.end_a = r.ro_a + p.amp.R;
+    r.ro_m = __builtin_fmaxf(rel_f, p.mod.sus_off); r.end_m = r.ro_m + p.mod.R;
+
+    int32_t ev_idx = -1;
+    uint32_t ev_frame = 0xffffffffu;
+    bool ev_dirty = false, ev_restart = false;
+    uint32_t seed_now = seed;
+    if (TEV && in_range) {
+        ev_idx = p.voice_ev_head[vi];
+        if (ev_idx >= 0) { ev_frame = p.tev[ev_idx].frame; p.voice_ev_head[vi] = -1; }
+    }
+    __syncthreads();
+
+    const bool wave_live = __ballot(live || ev_idx >= 0) != 0ull;
+    const uint32_t x16_frames = p.frames & ~(uint32_t)(kChunk - 1);
+    const size_t pv_base = (size_t)vi * p.frames;
+    float *bp = p.block_partials + (size_t)blockIdx.x * p.frames_stride;
+    uint32_t buf = 0;
+
+    auto reduce_chunk = [&](uint32_t f_base, uint32_t n_frames) {
+        const uint32_t f = lane & 15u, grp = lane >> 4;
+        if (f < n_frames) {
+            const float *src = tile + f * (VW + 1) + grp * 16u;
+            float acc = src[0];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) acc += src[k];
+            sW[(buf * n_groups + wave * GW + grp) * kSuper + f_base + f] = acc;
+        }
+    };
+    auto apply_events_at = [&](uint32_t fpos) {
+        if (__ballot(ev_frame == fpos) == 0ull) return;
+        while (ev_frame == fpos) {
+            const S2rTimedEvent e = p.tev[ev_idx];
+            if (e.flags & S2R_EV_RESTART) {                      // *voice = Voice { .. }, synth.rs:63-69
+                r.pitch = e.pitch;
+                r.offset = 0u - fpos;
+                r.release_u = 0u;
+                r.released = (e.flags & S2R_EV_RELEASE) != 0u;
+                r.phase = 0.0f;
+                f2.x1 = f2.x2 = f2.y1 = f2.y2 = 0.0f;
+                seed_now = e.seed;
+                r.seed_rot = (e.seed << 5) | (e.seed >> 27);
+                live = true; ev_restart = true;
+            } else if ((e.flags & S2R_EV_RELEASE) && live && !r.released) {   // synth.rs:74-75
+                r.released = true;
+                r.release_u = r.offset + fpos;
+            }
+            ev_dirty = true;
+            ev_idx = e.next;
+            ev_frame = ev_idx >= 0 ? p.tev[ev_idx].frame : 0xffffffffu;
+        }
+        const float rf = r.released ? (float)r.release_u : 4294967296.0f;
+        r.ro_a = __builtin_fmaxf(rf, p.amp.sus_off); r.end_a = r.ro_a + p.amp.R;
+        r.ro_m = __builtin_fmaxf(rf, p.mod.sus_off); r.end_m = r.ro_m + p.mod.R;
+    };
+
+    for (uint32_t sc0 = 0; sc0 < p.frames; sc0 += kSuper) {
+        const uint32_t n_sc = (p.frames - sc0 < kSuper) ? (p.frames - sc0) : kSuper;
+        const uint32_t n_x16 = (x16_frames > sc0) ? ((x16_frames - sc0 < n_sc) ? (x16_frames - sc0) : n_sc) : 0u;
+        if (wave_live) {
+            for (uint32_t c16 = 0; c16 < n_x16; c16 += kChunk) {
+                if (TEV) apply_events_at(sc0 + c16);
+                for (uint32_t j = 0; j < kChunk; ++j) {          // one frame of sample_voice_x16, process.rs:306-379
+                    const uint32_t oi = r.offset + sc0 + c16 + j;            // wrapping u32 add (process.rs:213-219)
+                    const float t = (float)oi;
+                    const float amp = env_value(env_stage_at(p.amp, r.ro_a, r.end_a, t), t);     // process.rs:144
+                    const float mod = env_value(env_stage_at(p.mod, r.ro_m, r.end_m, t), t);     // process.rs:145
+                    const float f_osc = s2r_pow2_sleef_core(mod * p.amt_osc) * r.pitch;          // process.rs:146-147,231-250
+                    const float f_lpf = s2r_pow2_sleef_core(mod * p.amt_lpf) * p.lpf_freq;       // process.rs:148-152
+                    const OscK k = make_osck<OSC>(p.sr / f_osc);                                 // units.rs:32-42
+                    const float nz = hash_noise(r.seed_rot, t) + p.noise_level;                  // process.rs:347-356 (ADD)
+                    const float ph = r.phase;                                                    // oscillators.rs:391-400
+                    r.phase = s2r_fmod1(ph + k.inv_period);
+                    const float off = __builtin_fmaf(k.period, ph, 0.0f);
+                    const float osc = osc_value<OSC>(k, off, sSin);
+                    const float smp = (osc + p.osc_gain) + nz;                                   // process.rs:342-345 (ADD), :358
+                    const float y = dsp_filter_step(p.lpf_kind, p.lpf_damping, p.sr, f_lpf, smp, f2);
+                    const float out = live ? y * amp : 0.0f;                                     // process.rs:373-376
+                    if (PV && in_range) p.per_voice[pv_base + sc0 + c16 + j] = out;
+                    tile[j * (VW + 1) + lane] = out;
+                }
+                reduce_chunk(c16, kChunk);
+            }
+            if (n_x16 < n_sc) {                                  // scalar tail (< 16 frames)
+                if (TEV) apply_events_at(sc0 + n_x16);
+                for (uint32_t i = n_x16; i < n_sc; ++i) {
+                    float out = frame_sisd<OSC, true>(p, r, r.offset + sc0 + i, sT, sSin, &f2);
+                    out = live ? out : 0.0f;
+                    if (PV && in_range) p.per_voice[pv_base + sc0 + i] = out;
+                    tile[(i - n_x16) * (VW + 1) + lane] = out;
+                }
+                reduce_chunk(n_x16, n_sc - n_x16);
+            }
+        } else {
+            for (uint32_t i = lane; i < GW * kSuper; i += 64u)
+                sW[(buf * n_groups + wave * GW + i / kSuper) * kSuper + (i % kSuper)] = 0.0f;
+            if (PV && in_range) for (uint32_t i = 0; i < n_sc; ++i) p.per_voice[pv_base + sc0 + i] = 0.0f;
+        }
+        __syncthreads();
+        for (uint32_t f = tid; f < n_sc; f += blockDim.x) {
+            float acc = sW[(buf * n_groups + 0) * kSuper + f];
+            for (uint32_t gq = 1; gq < n_groups; ++gq) acc += sW[(buf * n_groups + gq) * kSuper + f];
+            bp[sc0 + f] = acc;
+        }
+        buf ^= 1u;
+    }
+
+    if (live) {
+        const uint32_t o = r.offset;
+        p.v.offset[vi] = (!ev_dirty && o > 0xffffffffu - p.frames) ? 0xffffffffu : o + p.frames;   // synth.rs:197
+        p.v.phase[vi] = r.phase;
+        p.v.fx1[vi] = f2.x1; p.v.fx2[vi] = f2.x2; p.v.fy1[vi] = f2.y1; p.v.fy2[vi] = f2.y2;
+        if (ev_dirty) {
+            p.v.pitch[vi] = r.pitch;
+            p.v.release[vi] = r.release_u;
+            p.v.flags[vi] = S2R_VF_STARTED | (r.released ? S2R_VF_RELEASED : 0u);
+            p.v.seed[vi] = seed_now;
+            if (ev_restart) p.v.lpf_last[vi] = 0.0f;             // st::Layer::default()
         }
     }
 }
@@ -960,6 +1165,7 @@ __global__ void s2r_events_kernel(const S2rVoiceArrays v, const S2rVoiceEvent *e
         v.flags[vi] = S2R_VF_STARTED | ((e.flags & S2R_EV_RELEASE) ? S2R_VF_RELEASED : 0u);
         v.phase[vi] = 0.0f;
         v.lpf_last[vi] = 0.0f;
+        v.fx1[vi] = 0.0f; v.fx2[vi] = 0.0f; v.fy1[vi] = 0.0f; v.fy2[vi] = 0.0f;
         v.seed[vi] = e.seed;
     } else if (e.flags & S2R_EV_RELEASE) {                       // synth.rs:74-75
         const uint32_t fl = v.flags[vi];
@@ -997,7 +1203,19 @@ hipError_t launch_l(const S2rRenderParams &p0, uint32_t block_voices, uint32_t l
 }
 
 template <int OSC>
+hipError_t launch_dspf(const S2rRenderParams &p0, uint32_t block_voices, hipStream_t stream) {
+    S2rRenderParams p = p0;
+    const uint32_t grid = (p.n_voices + block_voices - 1) / block_voices;
+    const uint32_t n_waves = block_voices / 64, n_groups = n_waves * 4;
+    p.super_frames = n_groups <= 16 ? kSuperMax : 64u;
+    const size_t lds = sizeof(float) * ((size_t)2 * n_groups * p.super_frames + (size_t)n_waves * kChunk * 65);
+    hipLaunchKernelGGL((s2r_render_dspf_kernel<OSC>), dim3(grid), dim3(block_voices), lds, stream, p);
+    return hipGetLastError();
+}
+
+template <int OSC>
 hipError_t launch_osc(const S2rRenderParams &p, uint32_t block_voices, uint32_t lanes, hipStream_t stream) {
+    if (p.lpf_kind != S2R_FILT_ONEPOLE) return launch_dspf<OSC>(p, block_voices, stream);
     // pow(2, mod * amount) == 1 exactly iff amount is +-0 (mod is always finite and >= 0)
     const bool fm = p.amt_osc != 0.0f;
     const int mode = p.per_voice != nullptr ? 1 : (p.tev != nullptr ? 2 : 0);

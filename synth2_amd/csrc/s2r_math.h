@@ -252,9 +252,9 @@ S2R_HD float s2r_fmod_period(float off, float period) {
 // ---------------------------------------------------------------------------------------
 // glibc sinf / cosf (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h; FMA ifunc variant):
 // double-precision polynomials after a quadrant reduction, rounded once to float.  Used by the
-// second-order filters of dsp_filters.rs (Rust f32::sin / f32::cos).  Valid for |y| < 120
-// (glibc's reduce_fast range; beyond it glibc switches to a 4/pi table walk that is not
-// restated here — the caller keeps theta = 2 pi f / sr below that).
+// second-order filters of dsp_filters.rs (Rust f32::sin / f32::cos).  |y| < 120 goes through
+// reduce_fast, larger finite arguments through reduce_large (a 192-bit window of 4/pi);
+// inf / NaN give NaN (glibc's NaN sign is not reproduced: callers keep arguments finite).
 // ---------------------------------------------------------------------------------------
 typedef struct s2r_sincos_poly { double c0, c1, c2, c3, c4, s1, s2, s3; } s2r_sincos_poly;
 
@@ -288,6 +288,30 @@ S2R_HD double s2r_reduce_fast(double x, int *np) {
     return __builtin_fma(-(double)n, hpi, x);
 }
 
+// reduce_large: the argument's 24-bit mantissa times the 96 bits of 4/pi that matter for its
+// exponent, in integer arithmetic; returns the remainder in [-pi/4, pi/4] and the quadrant
+S2R_HD double s2r_reduce_large(uint32_t xi, int *np) {
+    // __inv_pio4: 4/pi = 0x1.45F306DC9C882A53F84EAFA3EA69BB81B6C52B3278872...p0 in 32-bit windows, 8 bits apart
+    const uint32_t inv_pio4[24] = {
+        0xa2u, 0xa2f9u, 0xa2f983u, 0xa2f9836eu, 0xf9836e4eu, 0x836e4e44u, 0x6e4e4415u, 0x4e441529u,
+        0x441529fcu, 0x1529fc27u, 0x29fc2757u, 0xfc2757d1u, 0x2757d1f5u, 0x57d1f534u, 0xd1f534ddu, 0xf534ddc0u,
+        0x34ddc0dbu, 0xddc0db62u, 0xc0db6295u, 0xdb629599u, 0x6295993cu, 0x95993c43u, 0x993c4390u, 0x3c439041u};
+    const double pi63 = 0x1.921FB54442D18p-62;
+    const uint32_t *arr = &inv_pio4[(xi >> 26) & 15];
+    const int shift = (xi >> 23) & 7;
+    xi = (xi & 0xffffffu) | 0x800000u;
+    xi <<= shift;
+    uint64_t res0 = (uint64_t)(uint32_t)(xi * arr[0]);
+    const uint64_t res1 = (uint64_t)xi * arr[4];
+    const uint64_t res2 = (uint64_t)xi * arr[8];
+    res0 = (res2 >> 32) | (res0 << 32);
+    res0 += res1;
+    const uint64_t n = (res0 + (1ULL << 61)) >> 62;
+    res0 -= n << 62;
+    *np = (int)n;
+    return (double)(int64_t)res0 * pi63;
+}
+
 S2R_HD float s2r_sinf(float y) {
     const uint32_t top = (s2r_f2u(y) >> 20) & 0x7ff;
     double x = (double)y;
@@ -296,6 +320,15 @@ S2R_HD float s2r_sinf(float y) {
         return s2r_sinf_poly(x, x * x, 0, 0);
     }
     int n;
+    if (__builtin_expect(top >= 0x42f, 0)) {            // |y| >= 120
+        if (top >= 0x7f8) return y - y;                 // inf, NaN
+        const uint32_t xi = s2r_f2u(y);
+        const int sign = (int)(xi >> 31);
+        x = s2r_reduce_large(xi, &n);
+        const int q = n + sign;
+        const double sgl = ((q & 3) == 1 || (q & 3) == 2) ? -1.0 : 1.0;
+        return s2r_sinf_poly(x * sgl, x * x, (q & 2) != 0, n);
+    }
     x = s2r_reduce_fast(x, &n);
     const double sg = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;      // sign[n & 3] = {1,-1,-1,1}
     return s2r_sinf_poly(x * sg, x * x, (n & 2) != 0, n);
@@ -309,6 +342,15 @@ S2R_HD float s2r_cosf(float y) {
         return s2r_sinf_poly(x, x * x, 0, 1);
     }
     int n;
+    if (__builtin_expect(top >= 0x42f, 0)) {            // |y| >= 120
+        if (top >= 0x7f8) return y - y;
+        const uint32_t xi = s2r_f2u(y);
+        const int sign = (int)(xi >> 31);
+        x = s2r_reduce_large(xi, &n);
+        const int q = n + sign;
+        const double sgl = ((q & 3) == 1 || (q & 3) == 2) ? -1.0 : 1.0;
+        return s2r_sinf_poly(x * sgl, x * x, (q & 2) != 0, n ^ 1);
+    }
     x = s2r_reduce_fast(x, &n);
     const int m = n + 1;
     const double sg = ((m & 3) == 1 || (m & 3) == 2) ? -1.0 : 1.0;

@@ -49,7 +49,12 @@ class Patch(C.Structure):
     """static_config.rs:4-24 (sc::Layer)"""
     _fields_ = [("osc_kind", C.c_int32), ("osc_gain", C.c_float), ("noise", C.c_float), ("lpf_freq", C.c_float),
                 ("amp_env", Adsr), ("mod_env", Adsr),
-                ("mod_env_to_osc_freq", C.c_float), ("mod_env_to_lpf_freq", C.c_float)]
+                ("mod_env_to_osc_freq", C.c_float), ("mod_env_to_lpf_freq", C.c_float),
+                ("lpf_kind", C.c_int32), ("lpf_damping", C.c_float)]
+
+
+# s2r_filter_kind: filters.rs one-pole (the reference's live path) and dsp_filters.rs:25-180
+FILT_ONEPOLE, FILT_LP1, FILT_HP1, FILT_LP2, FILT_HP2 = 0, 1, 2, 3, 4
 
 
 class Config(C.Structure):
@@ -62,13 +67,15 @@ class VoiceState(C.Structure):
     _fields_ = [("note", C.c_uint8), ("started", C.c_uint8), ("released", C.c_uint8), ("_pad", C.c_uint8),
                 ("current_frame_offset", C.c_uint32), ("release_frame_offset", C.c_uint32),
                 ("pitch_hz", C.c_float), ("phase_accum", C.c_float), ("lpf_last", C.c_float),
-                ("noise_seed", C.c_uint32), ("velocity", C.c_float)]
+                ("noise_seed", C.c_uint32), ("velocity", C.c_float),
+                ("filt_x1", C.c_float), ("filt_x2", C.c_float), ("filt_y1", C.c_float), ("filt_y2", C.c_float)]
 
 
 VOICE_STATE_DTYPE = np.dtype([("note", np.uint8), ("started", np.uint8), ("released", np.uint8), ("_pad", np.uint8),
                               ("current_frame_offset", np.uint32), ("release_frame_offset", np.uint32),
                               ("pitch_hz", np.float32), ("phase_accum", np.float32), ("lpf_last", np.float32),
-                              ("noise_seed", np.uint32), ("velocity", np.float32)])
+                              ("noise_seed", np.uint32), ("velocity", np.float32),
+                              ("filt_x1", np.float32), ("filt_x2", np.float32), ("filt_y1", np.float32), ("filt_y2", np.float32)])
 assert VOICE_STATE_DTYPE.itemsize == C.sizeof(VoiceState)
 NOTE_EVENT_DTYPE = np.dtype([("kind", np.uint8), ("note", np.uint8), ("frame", np.uint16), ("velocity", np.float32)])
 assert NOTE_EVENT_DTYPE.itemsize == 8

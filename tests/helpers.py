@@ -20,6 +20,8 @@ def oracle_cfg_from_patch(p):
         dst.attack_ms, dst.decay_ms, dst.sustain, dst.release_ms = src.attack_ms, src.decay_ms, src.sustain, src.release_ms
     c.mod_env_to_osc_freq = p.mod_env_to_osc_freq
     c.mod_env_to_lpf_freq = p.mod_env_to_lpf_freq
+    c.lpf_kind = p.lpf_kind
+    c.lpf_damping = p.lpf_damping
     return c
 
 

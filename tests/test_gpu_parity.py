@@ -423,3 +423,154 @@ def test_timed_event_errors():
     s.note_events(ev)
     with pytest.raises(s2.S2rError):
         s.sample(np.empty(256, dtype=np.float32))
+
+
+# ---------------------------------------------------------------------------------------------
+# dsp_filters.rs filters as the layer's filter (lpf.kind != onepole)
+# ---------------------------------------------------------------------------------------------
+DSP_KINDS = [s2.FILT_LP1, s2.FILT_HP1, s2.FILT_LP2, s2.FILT_HP2]
+
+
+@pytest.mark.parametrize("kind", DSP_KINDS)
+@pytest.mark.parametrize("osc,fm", [(s2.OSC_SAW, 0.0), (s2.OSC_SQUARE, 2.5), (s2.OSC_TRIANGLE, 0.0), (s2.OSC_SINE, -1.5)])
+def test_dsp_filters_per_voice(kind, osc, fm):
+    """every first/second-order filter of dsp_filters.rs:25-180 at the modulated cutoff, mix off"""
+    patch = make_patch(osc_kind=osc, mod_env_to_osc_freq=fm, noise=0.25, osc_gain=0.75, lpf_kind=kind,
+                       lpf_freq=900.0, mod_env_to_lpf_freq=3.0, lpf_damping=0.6)
+    patch.mod_env.attack_ms = 5.0
+    patch.mod_env.sustain = 0.3
+    patch.mod_env.release_ms = 40.0
+    pr = Pair(96, patch)
+    for v in range(70):
+        pr.note_on(30 + (v * 7) % 70)
+    for k in range(6):
+        g, o = pr.render_voices(512)
+        assert_bits_equal(g, o, "filter %d osc %d fm %g block %d" % (kind, osc, fm, k))
+        if k == 2:
+            for v in range(0, 70, 3):
+                pr.note_off(30 + (v * 7) % 70)
+
+
+@pytest.mark.parametrize("kind", DSP_KINDS)
+@pytest.mark.parametrize("frames", [1, 15, 17, 1000])
+def test_dsp_filters_tail_frames_and_mix(kind, frames):
+    """ragged fills (scalar tail runs the same filter at the libm-modulated cutoff) and the mix tree"""
+    patch = make_patch(lpf_kind=kind, noise=0.5, osc_gain=0.5, mod_env_to_osc_freq=1.25, lpf_damping=1.41421354)
+    pr = Pair(300, patch, block_voices=128)
+    for v in range(200):
+        pr.note_on(40 + (3 * v) % 60)
+    for k in range(4):
+        g, o, pv = pr.sample(frames)
+        assert_bits_equal(g, o, "filter %d, %d frames, call %d" % (kind, frames, k))
+        if k == 1:
+            pr.note_off(43)
+            pr.note_off(61)
+
+
+def test_dsp_filter_cutoff_range_and_damping_extremes():
+    """theta = 2 pi f / sr far past pi (cutoff above Nyquist: the reference does not clamp; theta
+    reaches ~2700 here, the large-argument reduction of sinf/cosf) and the ends of Unipolar<10>
+    damping; the host refuses only a cutoff whose 2 pi f overflows f32"""
+    for damping in (0.0, 0.2, 10.0):
+        patch = make_patch(lpf_kind=s2.FILT_LP2, lpf_freq=20000.0, mod_env_to_lpf_freq=10.0, lpf_damping=damping)
+        patch.mod_env.decay_ms = 20.0
+        pr = Pair(16, patch)
+        for v in range(12):
+            pr.note_on(36 + 5 * v)
+        for k in range(3):
+            with np.errstate(all="ignore"):
+                g, o = pr.render_voices(256)
+            assert_bits_equal(g, o, "damping %g block %d" % (damping, k))
+    s = s2.Synth(8, max_frames=256)
+    s.set_patch(make_patch(lpf_kind=s2.FILT_HP2, lpf_freq=3.0e37, mod_env_to_lpf_freq=10.0))
+    with pytest.raises(s2.S2rError) as e:
+        s.sample(np.empty(256, dtype=np.float32), 48000)
+    assert e.value.status == -5
+
+
+def test_dsp_filter_state_survives_patch_switches_and_checkpoints():
+    """x1,x2,y1,y2 belong to the voice (st::Layer): they are zeroed by note_on only, are carried by
+    export/import, and are left alone while the patch runs the one-pole"""
+    lp2 = make_patch(lpf_kind=s2.FILT_LP2, lpf_freq=1500.0, lpf_damping=0.4)
+    one = make_patch()
+    pr = Pair(8, lp2)
+    for n in (50, 57, 64):
+        pr.note_on(n)
+    g, o = pr.render_voices(256)
+    assert_bits_equal(g, o, "lp2 first")
+    st = pr.gpu.export_state()
+    for v in range(3):
+        cs = pr.cpu.voice(v).state
+        for a, b in (("filt_x1", cs.x1), ("filt_x2", cs.x2), ("filt_y1", cs.y1), ("filt_y2", cs.y2)):
+            assert np.float32(st[a][v]).view(np.uint32) == np.float32(b).view(np.uint32)
+    pr.gpu.set_patch(one); pr.cpu.config = __import__("helpers").oracle_cfg_from_patch(one)
+    g, o = pr.render_voices(256)
+    assert_bits_equal(g, o, "one-pole in between")
+    pr.note_on(70)                                   # restarted under the one-pole: its filter state is zero
+    pr.gpu.import_state(pr.gpu.export_state())       # round trip through the checkpoint format
+    pr.gpu.set_patch(lp2); pr.cpu.config = __import__("helpers").oracle_cfg_from_patch(lp2)
+    for k in range(2):
+        g, o = pr.render_voices(256)
+        assert_bits_equal(g, o, "lp2 resumed %d" % k)
+
+
+@pytest.mark.parametrize("kind", [s2.FILT_LP2, s2.FILT_HP1])
+def test_dsp_filters_with_timed_events(kind):
+    """timed events (16-frame boundaries inside one launch) under the dsp filters"""
+    voices = 100
+    patch = make_patch(lpf_kind=kind, lpf_freq=700.0, lpf_damping=0.9)
+    pr = Pair(voices, patch, max_frames=1024)
+    rng = np.random.RandomState(5 + kind)
+    held = []
+    for b in range(5):
+        frames = 1024 if b != 3 else 1000
+        n_ev = int(rng.randint(1, 40))
+        times = np.sort(rng.randint(0, (frames + 15) // 16, n_ev)) * 16
+        ev = np.zeros(n_ev, dtype=s2.NOTE_EVENT_DTYPE)
+        for i, t in enumerate(times):
+            on = (not held) or rng.randint(0, 3) > 0
+            if on:
+                note = int(rng.randint(40, 90)); held.append(note)
+            else:
+                note = held.pop(int(rng.randint(len(held))))
+            ev[i] = (1 if on else 0, note, int(t), 1.0)
+        pr.gpu.note_events(ev)
+        g = pr.gpu.sample(np.empty(frames, dtype=np.float32))
+        pv = np.zeros((voices, frames), dtype=np.float32)
+        k = 0
+        for c in range(0, frames, 16):
+            while k < n_ev and ev["frame"][k] == c:
+                if ev["kind"][k]:
+                    pr.cpu.note_on(int(ev["note"][k]))
+                else:
+                    pr.cpu.note_off(int(ev["note"][k]))
+                k += 1
+            n = min(16, frames - c)
+            pv[:, c:c + n] = pr.cpu.render_voices(n)
+        o = s2o.mix_tree(pv, pr.block_voices, 1)
+        assert_bits_equal(g, o, "timed events under filter %d, buffer %d" % (kind, b))
+
+
+def test_dsp_filters_full_size_linearity_free_properties():
+    """65536 voices under LP2: the oracle is too slow for the whole pool, so check (a) a 2048-voice
+    window of per-voice rows bit-exactly and (b) that the mix equals the documented tree over the
+    GPU's own per-voice rows (the summation order is size-independent)."""
+    voices = 65536
+    patch = make_patch(lpf_kind=s2.FILT_LP2, lpf_freq=1200.0, lpf_damping=0.7, noise=0.1)
+    a = s2.Synth(voices, max_frames=256)
+    b = s2.Synth(voices, max_frames=256)
+    a.set_patch(patch); b.set_patch(patch)
+    ev = np.zeros(voices, dtype=s2.NOTE_EVENT_DTYPE)
+    ev["kind"] = 1
+    ev["note"] = (np.arange(voices) * 13) % 100 + 20
+    ev["velocity"] = 1.0
+    a.note_events(ev); b.note_events(ev)
+    ora = s2o.OracleSynth(2048)
+    ora.config = __import__("helpers").oracle_cfg_from_patch(patch)
+    for i in range(2048):
+        ora.note_on(int(ev["note"][i]))
+    for k in range(2):
+        mix = a.sample(np.empty(256, dtype=np.float32))
+        pv = b.render_voices(256)
+        assert_bits_equal(pv[:2048], ora.render_voices(256, threads=8), "first 2048 voices, buffer %d" % k)
+        assert_bits_equal(mix, s2o.mix_tree(pv, a.block_voices, 1), "mix vs tree over GPU rows, buffer %d" % k)

@@ -74,6 +74,12 @@ def test_patch_full_grammar():
     assert (p.mod_env_to_osc_freq, p.mod_env_to_lpf_freq) == (-2.5, 7.0)
     for kind, code in (("square", 0), ("saw", 1), ("triangle", 2), ("sine", 3)):
         assert s2.parse_patch("synth x { osc.kind = %s }" % kind).osc_kind == code
+    # the filter selector: filters.rs one-pole by default, dsp_filters.rs:25-180 by name
+    d = s2.parse_patch("synth x { }")
+    assert d.lpf_kind == s2.FILT_ONEPOLE and d.lpf_damping == np.float32(2.0 ** 0.5)
+    for kind, code in (("onepole", 0), ("lp1", 1), ("hp1", 2), ("lp2", 3), ("hp2", 4)):
+        q = s2.parse_patch("synth x { lpf.kind = %s; lpf.damping = 0.25 }" % kind)
+        assert q.lpf_kind == code and q.lpf_damping == 0.25
 
 
 @pytest.mark.parametrize("text,status", [
@@ -88,6 +94,9 @@ def test_patch_full_grammar():
     ("synth x { amp_env.attack = -1 }", -5),
     ("synth x { lpf.freq = nan }", -5),
     ("synth x { osc.kind = 7 }", -5),
+    ("synth x { lpf.kind = bandpass }", -4),
+    ("synth x { lpf.kind = 5 }", -5),
+    ("synth x { lpf.damping = 10.5 }", -5),           # Unipolar<10>, dsp_filters.rs:96
 ])
 def test_patch_errors(text, status):
     with pytest.raises(s2.S2rError) as e:

@@ -274,3 +274,29 @@ def test_offset_saturates_and_panic_flag():
     s.sample(16)
     assert s.panicked                          # process.rs:36 "overflow"
     assert s.voice(0).current_frame_offset == 0xFFFFFFFF      # synth.rs:197 saturating_add
+
+
+def test_dsp_filters_restatement_properties():
+    """dsp_filters.rs:25-180 has no tests or golden vectors in the reference ("parity unpinned" for
+    this row beyond the restatement itself): check the textbook properties the coefficient
+    formulas imply — unit DC gain for the low-passes, zero DC gain for the high-passes, and the
+    exact first output alpha * x (x2 for the second-order forms) from a zero state."""
+    import ctypes as C
+    L = s2o.lib()
+    L.s2o_dsp_filter_process.restype = C.c_float
+    L.s2o_dsp_filter_process.argtypes = [C.c_int] + [C.POINTER(C.c_float)] * 4 + [C.c_uint32, C.c_float, C.c_float, C.c_float]
+    for kind, dc in ((1, 1.0), (2, 0.0), (3, 1.0), (4, 0.0)):
+        st = [C.c_float(0.0) for _ in range(4)]
+        y = 0.0
+        for i in range(4000):
+            y = L.s2o_dsp_filter_process(kind, st[0], st[1], st[2], st[3], 48000, 1000.0, 1.41421354, 1.0)
+        assert abs(y - dc) < 1e-4, (kind, y)
+    # first output from rest, LP1: alpha = (1 - cos/(1+sin))/2 in f32 steps
+    f = np.float32
+    theta = f(f(f(2.0) * f(np.pi)) * f(1000.0)) / f(48000.0)
+    gamma = f(np.cos(theta, dtype=np.float32)) / f(f(1.0) + f(np.sin(theta, dtype=np.float32)))
+    alpha = f(f(1.0) - gamma) / f(2.0)
+    st = [C.c_float(0.0) for _ in range(4)]
+    y = L.s2o_dsp_filter_process(1, st[0], st[1], st[2], st[3], 48000, 1000.0, 1.0, 0.5)
+    assert abs(y - float(alpha * f(0.5))) <= 1e-9
+    assert st[0].value == 0.5 and st[2].value == y

@@ -78,6 +78,16 @@ def test_pow2_sleef_product_matches_oracle_restatement(libm_xcheck):
     _run(libm_xcheck, "sleef2", -10, -0.00390625)
 
 
+def test_sinf_cosf_match_host_libm(libm_xcheck):
+    """dsp_filters.rs theta.sin()/.cos(): theta = 2 pi f / sr in [0, ~2700] for Unipolar/Bipolar
+    patch ranges; every float of [0, 8] and of two large-argument windows here, all 2^32 under S2R_SLOW"""
+    for fn in ("sinf", "cosf"):
+        _run(libm_xcheck, fn, 0, 8)
+        _run(libm_xcheck, fn, 119, 121)          # reduce_fast / reduce_large switch
+        _run(libm_xcheck, fn, 2600, 2800)
+        _run(libm_xcheck, fn, 1e30, 1.0001e30)
+
+
 def test_noise_quotient_all_u16(libm_xcheck):
     _run(libm_xcheck, "div65535")
 
@@ -102,5 +112,7 @@ def test_sleef_restatement_matches_c_sleef(sleef_xcheck):
 def test_full_sweeps(libm_xcheck, sleef_xcheck):
     _run(libm_xcheck, "expf", "all")
     _run(libm_xcheck, "powf2", "all")
+    _run(libm_xcheck, "sinf", "all")
+    _run(libm_xcheck, "cosf", "all")
     _run(sleef_xcheck, "pow2", -10, 10)
     _run(sleef_xcheck, "grid", 200000000, 7)
