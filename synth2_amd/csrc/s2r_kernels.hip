@@ -430,34 +430,42 @@ struct Filt2 { float x1, x2, y1, y2; };
 // dsp_filters.rs:25-45 (LP1), :60-80 (HP1), :99-130 (LP2), :149-180 (HP2): one step at cutoff f.
 // That file has no `fma` switch: every operation is rounded separately, in Rust's evaluation
 // order; sin/cos are the libm routines (s2r_sinf/s2r_cosf, bit-exact for every finite theta).
-__device__ __forceinline__ float dsp_filter_step(int kind, float damping, float sr, float cutoff, float x, Filt2 &f) {
+struct FiltCoef { float alpha, beta, gamma; };
+
+__device__ __forceinline__ FiltCoef dsp_filter_coef(int kind, float damping, float sr, float cutoff) {
     const float theta = 2.0f * 3.14159274101257324f * cutoff / sr;           // 2.0 * PI * cutoff_freq / sample_rate
     const float sn = s2r_sinf(theta), cs = s2r_cosf(theta);
+    FiltCoef c;
+    if (kind == S2R_FILT_LP1 || kind == S2R_FILT_HP1) {
+        c.beta = 0.0f;
+        c.gamma = cs / (1.0f + sn);
+        c.alpha = (kind == S2R_FILT_LP1) ? (1.0f - c.gamma) / 2.0f : (1.0f + c.gamma) / 2.0f;
+        return c;
+    }
+    const float hd = damping / 2.0f;
+    c.beta = 0.5f * ((1.0f - hd * sn) / (1.0f + hd * sn));
+    c.gamma = (0.5f + c.beta) * cs;
+    c.alpha = (kind == S2R_FILT_LP2) ? (0.5f + c.beta - c.gamma) / 4.0f : (0.5f + c.beta + c.gamma) / 4.0f;
+    return c;
+}
+
+__device__ __forceinline__ float dsp_filter_apply(int kind, const FiltCoef &c, float x, Filt2 &f) {
     float y;
     if (kind == S2R_FILT_LP1 || kind == S2R_FILT_HP1) {
-        const float gamma = cs / (1.0f + sn);
-        if (kind == S2R_FILT_LP1) {
-            const float alpha = (1.0f - gamma) / 2.0f;
-            y = alpha * (x + f.x1) + gamma * f.y1;
-        } else {
-            const float alpha = (1.0f + gamma) / 2.0f;
-            y = alpha * (x - f.x1) + gamma * f.y1;
-        }
+        const float xs = (kind == S2R_FILT_LP1) ? x + f.x1 : x - f.x1;
+        y = c.alpha * xs + c.gamma * f.y1;
         f.x1 = x; f.y1 = y;
         return y;
     }
-    const float hd = damping / 2.0f;
-    const float beta = 0.5f * ((1.0f - hd * sn) / (1.0f + hd * sn));
-    const float gamma = (0.5f + beta) * cs;
-    if (kind == S2R_FILT_LP2) {
-        const float alpha = (0.5f + beta - gamma) / 4.0f;
-        y = 2.0f * (alpha * (x + 2.0f * f.x1 + f.x2) + gamma * f.y1 - beta * f.y2);
-    } else {
-        const float alpha = (0.5f + beta + gamma) / 4.0f;
-        y = 2.0f * (alpha * (x - 2.0f * f.x1 + f.x2) + gamma * f.y1 - beta * f.y2);
-    }
+    const float xs = (kind == S2R_FILT_LP2) ? (x + 2.0f * f.x1 + f.x2) : (x - 2.0f * f.x1 + f.x2);
+    y = 2.0f * (c.alpha * xs + c.gamma * f.y1 - c.beta * f.y2);
     f.x2 = f.x1; f.x1 = x; f.y2 = f.y1; f.y1 = y;
     return y;
+}
+
+__device__ __forceinline__ float dsp_filter_step(int kind, float damping, float sr, float cutoff, float x, Filt2 &f) {
+    const FiltCoef c = dsp_filter_coef(kind, damping, sr, cutoff);
+    return dsp_filter_apply(kind, c, x, f);
 }
 
 // One frame of process_layer (scalar "sisd" path: process.rs:101-135,252-304).  DSPF: the layer's
@@ -973,6 +981,9 @@ __global__ void __launch_bounds__(1024) s2r_render_dspf_kernel(const S2rRenderPa
     uint32_t ev_frame = 0xffffffffu;
     bool ev_dirty = false, ev_restart = false;
     uint32_t seed_now = seed;
+    uint32_t mod_key = 0xffffffffu;          // bits of the mod value `k` and `fc` were computed for (a NaN: never equal)
+    OscK k = make_osck<OSC>(p.sr / r.pitch);
+    FiltCoef fc; fc.alpha = fc.beta = fc.gamma = 0.0f;
     if (TEV && in_range) {
         ev_idx = p.voice_ev_head[vi];
         if (ev_idx >= 0) { ev_frame = p.tev[ev_idx].frame; p.voice_ev_head[vi] = -1; }
@@ -1005,6 +1016,7 @@ __global__ void __launch_bounds__(1024) s2r_render_dspf_kernel(const S2rRenderPa
                 r.release_u = 0u;
                 r.released = (e.flags & S2R_EV_RELEASE) != 0u;
                 r.phase = 0.0f;
+                mod_key = 0xffffffffu;                               // the oscillator constants depend on the pitch
                 f2.x1 = f2.x2 = f2.y1 = f2.y2 = 0.0f;
                 seed_now = e.seed;
                 r.seed_rot = (e.seed << 5) | (e.seed >> 27);
@@ -1033,16 +1045,22 @@ __global__ void __launch_bounds__(1024) s2r_render_dspf_kernel(const S2rRenderPa
                     const float t = (float)oi;
                     const float amp = env_value(env_stage_at(p.amp, r.ro_a, r.end_a, t), t);     // process.rs:144
                     const float mod = env_value(env_stage_at(p.mod, r.ro_m, r.end_m, t), t);     // process.rs:145
-                    const float f_osc = s2r_pow2_sleef_core(mod * p.amt_osc) * r.pitch;          // process.rs:146-147,231-250
-                    const float f_lpf = s2r_pow2_sleef_core(mod * p.amt_lpf) * p.lpf_freq;       // process.rs:148-152
-                    const OscK k = make_osck<OSC>(p.sr / f_osc);                                 // units.rs:32-42
+                    // everything below `mod` that depends on it alone (and on the voice's pitch) is kept
+                    // from the previous frame while no lane's mod envelope value changed
+                    if (__ballot(s2r_f2u(mod) != mod_key) != 0ull) {
+                        const float f_osc = s2r_pow2_sleef_core(mod * p.amt_osc) * r.pitch;      // process.rs:146-147,231-250
+                        const float f_lpf = s2r_pow2_sleef_core(mod * p.amt_lpf) * p.lpf_freq;   // process.rs:148-152
+                        k = make_osck<OSC>(p.sr / f_osc);                                        // units.rs:32-42
+                        fc = dsp_filter_coef(p.lpf_kind, p.lpf_damping, p.sr, f_lpf);
+                        mod_key = s2r_f2u(mod);
+                    }
                     const float nz = hash_noise(r.seed_rot, t) + p.noise_level;                  // process.rs:347-356 (ADD)
                     const float ph = r.phase;                                                    // oscillators.rs:391-400
                     r.phase = s2r_fmod1(ph + k.inv_period);
                     const float off = __builtin_fmaf(k.period, ph, 0.0f);
                     const float osc = osc_value<OSC>(k, off, sSin);
                     const float smp = (osc + p.osc_gain) + nz;                                   // process.rs:342-345 (ADD), :358
-                    const float y = dsp_filter_step(p.lpf_kind, p.lpf_damping, p.sr, f_lpf, smp, f2);
+                    const float y = dsp_filter_apply(p.lpf_kind, fc, smp, f2);
                     const float out = live ? y * amp : 0.0f;                                     // process.rs:373-376
                     if (PV && in_range) p.per_voice[pv_base + sc0 + c16 + j] = out;
                     tile[j * (VW + 1) + lane] = out;
