@@ -67,6 +67,8 @@ typedef struct {
     int32_t lpf_kind;              /* s2r_filter_kind */
     float lpf_damping;             /* Unipolar<10>          SecondOrder*Filter.damping_factor
                                       (dsp_filters.rs:95 "sqrt(2) is neutral"), LP2/HP2 only */
+    float lpf_q;                   /* Unipolar<10>          SecondOrderBandPassFilter.quality_factor
+                                      (dsp_filters.rs:194 "3 is neutral"), BP2 only; must be > 0 */
 } s2r_patch;
 
 typedef enum {
@@ -74,7 +76,8 @@ typedef enum {
     S2R_FILT_LP1 = 1,              /* dsp_filters.rs:25-45      FirstOrderLowPassFilter */
     S2R_FILT_HP1 = 2,              /* dsp_filters.rs:60-80      FirstOrderHighPassFilter */
     S2R_FILT_LP2 = 3,              /* dsp_filters.rs:99-130     SecondOrderLowPassFilter */
-    S2R_FILT_HP2 = 4               /* dsp_filters.rs:149-180    SecondOrderHighPassFilter */
+    S2R_FILT_HP2 = 4,              /* dsp_filters.rs:149-180    SecondOrderHighPassFilter */
+    S2R_FILT_BP2 = 5               /* dsp_filters.rs:199-230    SecondOrderBandPassFilter (center = the cutoff) */
 } s2r_filter_kind;
 
 typedef struct {

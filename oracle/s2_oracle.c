@@ -254,9 +254,9 @@ float s2o_lpf_process(float *last, uint32_t sample_rate_u, float freq, float inp
 
 /* ------------------------------------------------------------------ dsp_filters.rs */
 
-/* dsp_filters.rs:25-45 (LP1), :60-80 (HP1), :99-130 (LP2), :149-180 (HP2).  No `fma` feature
- * switch in that file: every operation is rounded separately, in Rust's evaluation order.
- * sin/cos are Rust f32::sin/cos = the host libm's sinf/cosf. */
+/* dsp_filters.rs:25-45 (LP1), :60-80 (HP1), :99-130 (LP2), :149-180 (HP2), :199-230 (BP2).  No
+ * `fma` feature switch in that file: every operation is rounded separately, in Rust's evaluation
+ * order.  sin/cos/tan are Rust f32::sin/cos/tan = the host libm's sinf/cosf/tanf. */
 float s2o_dsp_filter_process(int kind, float *x1p, float *x2p, float *y1p, float *y2p,
                              uint32_t sample_rate_u, float cutoff_freq, float damping_factor, float input) {
     const float PI = 3.14159274101257324f;
@@ -276,6 +276,16 @@ float s2o_dsp_filter_process(int kind, float *x1p, float *x2p, float *y1p, float
         *x1p = x; *y1p = y;
         return y;
     }
+    if (kind == S2O_FILT_BP2) {                                  /* theta_center, quality_factor */
+        float quality_factor = damping_factor;
+        float tq = tanf(theta_cutoff / (2.0f * quality_factor));
+        float beta = (1.0f / 2.0f) * ((1.0f - tq) / (1.0f + tq));
+        float gamma = (1.0f / 2.0f + beta) * cosf(theta_cutoff);
+        float alpha = (1.0f / 2.0f - beta) / 2.0f;
+        y = 2.0f * (alpha * (x - x2) + gamma * y1 - beta * y2);
+        *x2p = x1; *x1p = x; *y2p = y1; *y1p = y;
+        return y;
+    }
     float s = sinf(theta_cutoff);
     float beta = (1.0f / 2.0f) * ((1.0f - damping_factor / 2.0f * s) / (1.0f + damping_factor / 2.0f * s));
     float gamma = (1.0f / 2.0f + beta) * cosf(theta_cutoff);
@@ -292,7 +302,8 @@ float s2o_dsp_filter_process(int kind, float *x1p, float *x2p, float *y1p, float
 
 static float layer_filter(const s2o_layer_cfg *c, s2o_layer_state *st, uint32_t sr, float freq, float input) {
     if (c->lpf_kind == S2O_FILT_ONEPOLE) return s2o_lpf_process(&st->lpf_last, sr, freq, input);
-    return s2o_dsp_filter_process(c->lpf_kind, &st->x1, &st->x2, &st->y1, &st->y2, sr, freq, c->lpf_damping, input);
+    return s2o_dsp_filter_process(c->lpf_kind, &st->x1, &st->x2, &st->y1, &st->y2, sr, freq,
+                                  c->lpf_kind == S2O_FILT_BP2 ? c->lpf_q : c->lpf_damping, input);
 }
 
 /* ------------------------------------------------------------------ oscillators.rs */
@@ -477,6 +488,7 @@ s2o_layer_cfg s2o_default_config(void) {
     c.mod_env_to_lpf_freq = 10.0f;
     c.lpf_kind = S2O_FILT_ONEPOLE;
     c.lpf_damping = 1.41421354f;     /* "sqrt(2) is neutral", dsp_filters.rs:95 */
+    c.lpf_q = 3.0f;                  /* "3 is neutral", dsp_filters.rs:194 */
     return c;
 }
 

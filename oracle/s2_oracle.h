@@ -47,10 +47,11 @@ typedef struct {
      * filter sample_voice[_x16] runs at the modulated cutoff.  0 = filters.rs one-pole (the
      * reference's live path). */
     int32_t lpf_kind;
-    float lpf_damping;           /* SecondOrder*Filter.damping_factor, Unipolar<10> */
+    float lpf_damping;           /* SecondOrder{Low,High}PassFilter.damping_factor, Unipolar<10> */
+    float lpf_q;                 /* SecondOrderBandPassFilter.quality_factor, Unipolar<10> */
 } s2o_layer_cfg;
 
-enum { S2O_FILT_ONEPOLE = 0, S2O_FILT_LP1 = 1, S2O_FILT_HP1 = 2, S2O_FILT_LP2 = 3, S2O_FILT_HP2 = 4 };
+enum { S2O_FILT_ONEPOLE = 0, S2O_FILT_LP1 = 1, S2O_FILT_HP1 = 2, S2O_FILT_LP2 = 3, S2O_FILT_HP2 = 4, S2O_FILT_BP2 = 5 };
 
 /* state.rs:10-21, oscillators.rs:402-406, filters.rs:5-7 */
 typedef struct {
@@ -138,9 +139,10 @@ float s2o_lpf_process(float *last, uint32_t sample_rate, float freq, float input
 void s2o_modulate_freq_unipolar_x16(float freq, const float mod[16], float amount, float out[16]); /* process.rs:231-250 */
 float s2o_modulate_freq_unipolar(float freq, float mod, float amount);          /* process.rs:221-229 */
 float s2o_sleef_powf(float x, float y);                                         /* sleef::Sleef::pow */
-/* dsp_filters.rs:25-180: one step of the first/second-order LP/HP filters (kind = S2O_FILT_*) */
+/* dsp_filters.rs:25-230: one step of the first/second-order filters (kind = S2O_FILT_*);
+ * `shape` is damping_factor for LP2/HP2, quality_factor for BP2, unused by LP1/HP1 */
 float s2o_dsp_filter_process(int kind, float *x1, float *x2, float *y1, float *y2,
-                             uint32_t sample_rate, float cutoff, float damping, float input);
+                             uint32_t sample_rate, float cutoff, float shape, float input);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,7 @@ class LayerCfg(C.Structure):
     _fields_ = [("osc_kind", C.c_int32), ("osc_gain", C.c_float), ("noise", C.c_float), ("lpf_freq", C.c_float),
                 ("amp_env", AdsrCfg), ("mod_env", AdsrCfg),
                 ("mod_env_to_osc_freq", C.c_float), ("mod_env_to_lpf_freq", C.c_float),
-                ("lpf_kind", C.c_int32), ("lpf_damping", C.c_float)]
+                ("lpf_kind", C.c_int32), ("lpf_damping", C.c_float), ("lpf_q", C.c_float)]
 
 
 class LayerState(C.Structure):

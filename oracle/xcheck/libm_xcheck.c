@@ -7,7 +7,8 @@
  *   expf   : Rust f32::exp  -> glibc expf   (filters.rs:21)
  *   powf2  : Rust 2f32.powf -> glibc powf   (process.rs:227, synth.rs:210)
  *   sleef2 : sleef pow(2,y) -> oracle/s2o_sleef.c (itself pinned to C SLEEF by sleef_xcheck)
- *   sinf/cosf : Rust f32::sin/cos -> glibc sinf/cosf (dsp_filters.rs:30-31,105-109), |x| < 120
+ *   sinf/cosf : Rust f32::sin/cos -> glibc sinf/cosf (dsp_filters.rs:30-31,105-109)
+ *   tanf   : Rust f32::tan  -> glibc tanf (dsp_filters.rs:205-207)
  *
  * usage: libm_xcheck expf|powf2|sleef2 <lo> <hi>     (every float in [lo,hi])
  *        libm_xcheck expf all | powf2 all            (every one of the 2^32 bit patterns)
@@ -34,6 +35,7 @@ static inline void one(uint32_t u) {
     else if (mode == 1) { mine = s2r_pow2_libm(x, T); volatile float two = 2.0f; ref = powf(two, x); }
     else if (mode == 3) { mine = s2r_sinf(x); ref = sinf(x); }
     else if (mode == 4) { mine = s2r_cosf(x); ref = cosf(x); }
+    else if (mode == 5) { mine = s2r_tanf(x); ref = tanf(x); }
     else { mine = s2r_pow2_sleef(x); ref = s2o_sleef_powf(2.0f, x); }
     checked++;
     if (mine != mine && ref != ref) return;
@@ -76,7 +78,7 @@ int main(int argc, char **argv) {
     }
     if (argc >= 4 && !strcmp(argv[1], "div")) return div_mode(strtof(argv[2], 0), (uint32_t)strtoul(argv[3], 0, 10));
     if (argc < 3) return 2;
-    mode = !strcmp(argv[1], "expf") ? 0 : !strcmp(argv[1], "powf2") ? 1 : !strcmp(argv[1], "sinf") ? 3 : !strcmp(argv[1], "cosf") ? 4 : 2;
+    mode = !strcmp(argv[1], "expf") ? 0 : !strcmp(argv[1], "powf2") ? 1 : !strcmp(argv[1], "sinf") ? 3 : !strcmp(argv[1], "cosf") ? 4 : !strcmp(argv[1], "tanf") ? 5 : 2;
     if (!strcmp(argv[2], "all")) {
         uint32_t u = 0; do { one(u); } while (++u != 0);
     } else {

@@ -50,7 +50,7 @@ struct S2rRenderParams {
     float amt_osc;        // mod_env_to_osc_freq
     float amt_lpf;        // mod_env_to_lpf_freq
     int32_t lpf_kind;     // s2r_filter_kind; != 0 renders through s2r_render_dspf_kernel
-    float lpf_damping;
+    float lpf_damping;    // damping_factor (LP2/HP2) or quality_factor (BP2)
     S2rEnv amp;
     S2rEnv mod;
     float sr;             // sample_rate as f32 (units.rs:21)

@@ -217,6 +217,10 @@ int check_fill(s2r_synth *s, size_t frames, uint32_t sample_rate) {
         if (!(num_max < 3.4028234e38))
             return set_err(s, S2R_ERR_PATCH_RANGE, "lpf.kind %d: 2 pi * lpf.freq * 2^mod_env_to_lpf_freq overflows f32",
                            s->patch.lpf_kind);
+        // dsp_filters.rs:205-207: tan(theta / (2 Q)); Q = 0 makes that tan(inf) = NaN (same sign caveat)
+        if (s->patch.lpf_kind == S2R_FILT_BP2 &&
+            !(s->patch.lpf_q > 0.0f && num_max / (double)sample_rate / (2.0 * (double)s->patch.lpf_q) < 3.4028234e38))
+            return set_err(s, S2R_ERR_PATCH_RANGE, "lpf.kind bp2 needs lpf.q > 0 (tan(theta / (2 q)) must stay finite)");
     }
     return S2R_OK;
 }
@@ -230,7 +234,7 @@ S2rRenderParams make_params(s2r_synth *s, size_t frames, uint32_t sample_rate) {
     p.amt_osc = s->patch.mod_env_to_osc_freq;
     p.amt_lpf = s->patch.mod_env_to_lpf_freq;
     p.lpf_kind = s->patch.lpf_kind;
-    p.lpf_damping = s->patch.lpf_damping;
+    p.lpf_damping = s->patch.lpf_kind == S2R_FILT_BP2 ? s->patch.lpf_q : s->patch.lpf_damping;
     p.amp = resolve_env(s->patch.amp_env, sample_rate);
     p.mod = resolve_env(s->patch.mod_env, sample_rate);
     p.sr = (float)sample_rate;

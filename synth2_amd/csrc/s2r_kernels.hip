@@ -427,15 +427,23 @@ __device__ __forceinline__ float recur_x16(const S2rRenderParams &p, VoiceRegs &
 // dsp_filters.rs:12-17,82-89: the delayed inputs / outputs of the first- and second-order filters
 struct Filt2 { float x1, x2, y1, y2; };
 
-// dsp_filters.rs:25-45 (LP1), :60-80 (HP1), :99-130 (LP2), :149-180 (HP2): one step at cutoff f.
+// dsp_filters.rs:25-45 (LP1), :60-80 (HP1), :99-130 (LP2), :149-180 (HP2), :199-230 (BP2): one step at cutoff f.
 // That file has no `fma` switch: every operation is rounded separately, in Rust's evaluation
 // order; sin/cos are the libm routines (s2r_sinf/s2r_cosf, bit-exact for every finite theta).
 struct FiltCoef { float alpha, beta, gamma; };
 
 __device__ __forceinline__ FiltCoef dsp_filter_coef(int kind, float damping, float sr, float cutoff) {
     const float theta = 2.0f * 3.14159274101257324f * cutoff / sr;           // 2.0 * PI * cutoff_freq / sample_rate
-    const float sn = s2r_sinf(theta), cs = s2r_cosf(theta);
+    const float cs = s2r_cosf(theta);
     FiltCoef c;
+    if (kind == S2R_FILT_BP2) {                                  // dsp_filters.rs:204-209; damping == quality_factor
+        const float tq = s2r_tanf(theta / (2.0f * damping));
+        c.beta = 0.5f * ((1.0f - tq) / (1.0f + tq));
+        c.gamma = (0.5f + c.beta) * cs;
+        c.alpha = (0.5f - c.beta) / 2.0f;
+        return c;
+    }
+    const float sn = s2r_sinf(theta);
     if (kind == S2R_FILT_LP1 || kind == S2R_FILT_HP1) {
         c.beta = 0.0f;
         c.gamma = cs / (1.0f + sn);
@@ -457,7 +465,8 @@ __device__ __forceinline__ float dsp_filter_apply(int kind, const FiltCoef &c, f
         f.x1 = x; f.y1 = y;
         return y;
     }
-    const float xs = (kind == S2R_FILT_LP2) ? (x + 2.0f * f.x1 + f.x2) : (x - 2.0f * f.x1 + f.x2);
+    const float xs = (kind == S2R_FILT_LP2) ? (x + 2.0f * f.x1 + f.x2)
+                   : (kind == S2R_FILT_HP2) ? (x - 2.0f * f.x1 + f.x2) : (x - f.x2);      // BP2: dsp_filters.rs:217-221
     y = 2.0f * (c.alpha * xs + c.gamma * f.y1 - c.beta * f.y2);
     f.x2 = f.x1; f.x1 = x; f.y2 = f.y1; f.y1 = y;
     return y;

@@ -356,3 +356,81 @@ S2R_HD float s2r_cosf(float y) {
     const double sg = ((m & 3) == 1 || (m & 3) == 2) ? -1.0 : 1.0;
     return s2r_sinf_poly(x * sg, x * x, (m & 2) != 0, n ^ 1);
 }
+
+// ---------------------------------------------------------------------------------------
+// glibc 2.35 tanf (sysdeps/ieee754/flt-32/s_tanf.c, k_tanf.c, e_rem_pio2f.c): fdlibm's float
+// kernel (no FMA variant in that release: every product and sum rounded separately) after the
+// sincosf quadrant reduction in double.  Used by the band-pass of dsp_filters.rs:199-230
+// ((theta / (2 Q)).tan()).  Every finite argument.
+// ---------------------------------------------------------------------------------------
+
+// __kernel_tanf: tan(x + y) on [-pi/4, pi/4] (iy = 1) or -1/tan(x + y) (iy = -1)
+S2R_HD float s2r_kernel_tanf(float x, float y, int iy) {
+    const float pio4 = 7.8539812565e-01f, pio4lo = 3.7748947079e-08f;      // 0x3f490fda, 0x33222168
+    const float T0 = 3.3333334327e-01f, T1 = 1.3333334029e-01f, T2 = 5.3968254477e-02f, T3 = 2.1869488060e-02f,
+                T4 = 8.8632395491e-03f, T5 = 3.5920790397e-03f, T6 = 1.4562094584e-03f, T7 = 5.8804126456e-04f,
+                T8 = 2.4646313977e-04f, T9 = 7.8179444245e-05f, T10 = 7.1407252108e-05f, T11 = -1.8558637748e-05f,
+                T12 = 2.5907305826e-05f;
+    const int32_t hx = (int32_t)s2r_f2u(x);
+    const int32_t ix = hx & 0x7fffffff;
+    float z, r, v, w, s;
+    if (ix < 0x39000000) {                               // |x| < 2^-13
+        if ((int)x == 0) {
+            if ((ix | (iy + 1)) == 0) return 1.0f / __builtin_fabsf(x);
+            else if (iy == 1) return x;
+            else return -1.0f / x;
+        }
+    }
+    if (ix >= 0x3f2ca140) {                              // |x| >= 0.6744
+        if (hx < 0) { x = -x; y = -y; }
+        z = pio4 - x;
+        w = pio4lo - y;
+        x = z + w; y = 0.0f;
+        if (__builtin_fabsf(x) < 0x1p-13f) return (float)(1 - ((hx >> 30) & 2)) * (float)iy * (1.0f - 2.0f * (float)iy * x);
+    }
+    z = x * x;
+    w = z * z;
+    r = T1 + w * (T3 + w * (T5 + w * (T7 + w * (T9 + w * T11))));
+    v = z * (T2 + w * (T4 + w * (T6 + w * (T8 + w * (T10 + w * T12)))));
+    s = z * x;
+    r = y + z * (s * (r + v) + y);
+    r += T0 * s;
+    w = x + r;
+    if (ix >= 0x3f2ca140) {
+        v = (float)iy;
+        return (float)(1 - ((hx >> 30) & 2)) * (v - 2.0f * (x - (w * w / (w + v) - r)));
+    }
+    if (iy == 1) return w;
+    // -1 / (x + r), accurately
+    float a, t;
+    z = s2r_u2f(s2r_f2u(w) & 0xfffff000u);
+    v = r - (z - x);
+    t = a = -1.0f / w;
+    t = s2r_u2f(s2r_f2u(t) & 0xfffff000u);
+    s = 1.0f + t * z;
+    return t + a * (s + t * v);
+}
+
+S2R_HD float s2r_tanf(float x) {
+    const uint32_t xi = s2r_f2u(x);
+    const int32_t ix = (int32_t)(xi & 0x7fffffffu);
+    if (ix <= 0x3f490fda) return s2r_kernel_tanf(x, 0.0f, 1);
+    if (ix >= 0x7f800000) return x - x;                  // inf, NaN
+    // __ieee754_rem_pio2f (2.35): the sincosf reductions in double, NOT contracted here (this
+    // routine has no FMA build: mulsd + subsd), remainder handed on as a float head + tail
+    double dx = (double)x;
+    int n;
+    if (((xi >> 20) & 0x7ff) < 0x42f) {                  // |x| < 120: reduce_fast
+        const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+        const double r = dx * hpi_inv;
+        n = ((int32_t)r + 0x800000) >> 24;
+        const double prod = (double)n * hpi;
+        dx = dx - prod;
+    } else {
+        dx = s2r_reduce_large(xi, &n);
+        if (xi >> 31) dx = -dx;
+    }
+    const float y0 = (float)dx;
+    const float y1 = (float)(dx - (double)y0);
+    return s2r_kernel_tanf(y0, y1, 1 - ((n & 1) << 1));
+}

@@ -4,12 +4,12 @@
 //
 //   file   := "synth" IDENT "{" { entry } "}"
 //   entry  := KEY "=" VALUE [";" | ","]
-//   KEY    := osc.kind | osc.gain | noise | lpf.freq | lpf.kind | lpf.damping
+//   KEY    := osc.kind | osc.gain | noise | lpf.freq | lpf.kind | lpf.damping | lpf.q
 //           | amp_env.attack | amp_env.decay | amp_env.sustain | amp_env.release
 //           | mod_env.attack | mod_env.decay | mod_env.sustain | mod_env.release
 //           | mod_env_to_osc_freq | mod_env_to_lpf_freq
 //   VALUE  := number | square | saw | triangle | sine        (kind names only for osc.kind)
-//           | onepole | lp1 | hp1 | lp2 | hp2                 (kind names only for lpf.kind)
+//           | onepole | lp1 | hp1 | lp2 | hp2 | bp2           (kind names only for lpf.kind)
 //
 // Units follow static_config.rs: *.attack/decay/release in ms (Ms), lpf.freq in Hz,
 // gains/levels/sustain Unipolar<1>, the two modulation amounts Bipolar<10>.
@@ -30,6 +30,7 @@ void s2r_default_patch(s2r_patch *p) {      // synth.rs:125-152
     p->mod_env_to_lpf_freq = 10.0f;
     p->lpf_kind = S2R_FILT_ONEPOLE;          // filters.rs: the only filter the reference wires up
     p->lpf_damping = 1.41421354f;            // dsp_filters.rs:95 "sqrt(2) is neutral"
+    p->lpf_q = 3.0f;                         // dsp_filters.rs:194 "3 is neutral"
 }
 
 namespace {
@@ -91,8 +92,9 @@ int s2r_validate_patch(const s2r_patch *p, std::string *err) {
     }
     if (!in_range(p->mod_env_to_osc_freq, -10.0f, 10.0f)) return fail(err, S2R_ERR_PATCH_RANGE, "mod_env_to_osc_freq outside Bipolar<10> [-10,10]");
     if (!in_range(p->mod_env_to_lpf_freq, -10.0f, 10.0f)) return fail(err, S2R_ERR_PATCH_RANGE, "mod_env_to_lpf_freq outside Bipolar<10> [-10,10]");
-    if (p->lpf_kind < S2R_FILT_ONEPOLE || p->lpf_kind > S2R_FILT_HP2) return fail(err, S2R_ERR_PATCH_RANGE, "lpf.kind out of range");
+    if (p->lpf_kind < S2R_FILT_ONEPOLE || p->lpf_kind > S2R_FILT_BP2) return fail(err, S2R_ERR_PATCH_RANGE, "lpf.kind out of range");
     if (!in_range(p->lpf_damping, 0.0f, 10.0f)) return fail(err, S2R_ERR_PATCH_RANGE, "lpf.damping outside Unipolar<10> [0,10]");
+    if (!in_range(p->lpf_q, 0.0f, 10.0f)) return fail(err, S2R_ERR_PATCH_RANGE, "lpf.q outside Unipolar<10> [0,10]");
     return S2R_OK;
 }
 
@@ -130,6 +132,7 @@ int s2r_parse_patch(const char *text, size_t len, s2r_patch *out, std::string *n
                 else if (kind == "hp1") p.lpf_kind = S2R_FILT_HP1;
                 else if (kind == "lp2") p.lpf_kind = S2R_FILT_LP2;
                 else if (kind == "hp2") p.lpf_kind = S2R_FILT_HP2;
+                else if (kind == "bp2") p.lpf_kind = S2R_FILT_BP2;
                 else return fail(err, S2R_ERR_PATCH_SYNTAX, at("unknown filter kind " + kind));
             } else if (lx.number(&num)) {
                 p.lpf_kind = (int32_t)num;
@@ -141,6 +144,7 @@ int s2r_parse_patch(const char *text, size_t len, s2r_patch *out, std::string *n
             else if (key == "noise") p.noise = v;
             else if (key == "lpf.freq") p.lpf_freq = v;
             else if (key == "lpf.damping") p.lpf_damping = v;
+            else if (key == "lpf.q") p.lpf_q = v;
             else if (key == "amp_env.attack") p.amp_env.attack_ms = v;
             else if (key == "amp_env.decay") p.amp_env.decay_ms = v;
             else if (key == "amp_env.sustain") p.amp_env.sustain = v;

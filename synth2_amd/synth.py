@@ -50,11 +50,11 @@ class Patch(C.Structure):
     _fields_ = [("osc_kind", C.c_int32), ("osc_gain", C.c_float), ("noise", C.c_float), ("lpf_freq", C.c_float),
                 ("amp_env", Adsr), ("mod_env", Adsr),
                 ("mod_env_to_osc_freq", C.c_float), ("mod_env_to_lpf_freq", C.c_float),
-                ("lpf_kind", C.c_int32), ("lpf_damping", C.c_float)]
+                ("lpf_kind", C.c_int32), ("lpf_damping", C.c_float), ("lpf_q", C.c_float)]
 
 
 # s2r_filter_kind: filters.rs one-pole (the reference's live path) and dsp_filters.rs:25-180
-FILT_ONEPOLE, FILT_LP1, FILT_HP1, FILT_LP2, FILT_HP2 = 0, 1, 2, 3, 4
+FILT_ONEPOLE, FILT_LP1, FILT_HP1, FILT_LP2, FILT_HP2, FILT_BP2 = 0, 1, 2, 3, 4, 5
 
 
 class Config(C.Structure):

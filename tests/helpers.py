@@ -22,6 +22,7 @@ def oracle_cfg_from_patch(p):
     c.mod_env_to_lpf_freq = p.mod_env_to_lpf_freq
     c.lpf_kind = p.lpf_kind
     c.lpf_damping = p.lpf_damping
+    c.lpf_q = p.lpf_q
     return c
 
 

@@ -428,7 +428,7 @@ def test_timed_event_errors():
 # ---------------------------------------------------------------------------------------------
 # dsp_filters.rs filters as the layer's filter (lpf.kind != onepole)
 # ---------------------------------------------------------------------------------------------
-DSP_KINDS = [s2.FILT_LP1, s2.FILT_HP1, s2.FILT_LP2, s2.FILT_HP2]
+DSP_KINDS = [s2.FILT_LP1, s2.FILT_HP1, s2.FILT_LP2, s2.FILT_HP2, s2.FILT_BP2]
 
 
 @pytest.mark.parametrize("kind", DSP_KINDS)
@@ -436,7 +436,7 @@ DSP_KINDS = [s2.FILT_LP1, s2.FILT_HP1, s2.FILT_LP2, s2.FILT_HP2]
 def test_dsp_filters_per_voice(kind, osc, fm):
     """every first/second-order filter of dsp_filters.rs:25-180 at the modulated cutoff, mix off"""
     patch = make_patch(osc_kind=osc, mod_env_to_osc_freq=fm, noise=0.25, osc_gain=0.75, lpf_kind=kind,
-                       lpf_freq=900.0, mod_env_to_lpf_freq=3.0, lpf_damping=0.6)
+                       lpf_freq=900.0, mod_env_to_lpf_freq=3.0, lpf_damping=0.6, lpf_q=1.7)
     patch.mod_env.attack_ms = 5.0
     patch.mod_env.sustain = 0.3
     patch.mod_env.release_ms = 40.0
@@ -481,7 +481,21 @@ def test_dsp_filter_cutoff_range_and_damping_extremes():
             with np.errstate(all="ignore"):
                 g, o = pr.render_voices(256)
             assert_bits_equal(g, o, "damping %g block %d" % (damping, k))
+    for q in (0.2, 3.0, 10.0):                       # band-pass: tan(theta / (2 q)) up to ~6800 rad
+        patch = make_patch(lpf_kind=s2.FILT_BP2, lpf_freq=20000.0, mod_env_to_lpf_freq=10.0, lpf_q=q)
+        patch.mod_env.decay_ms = 20.0
+        pr = Pair(16, patch)
+        for v in range(12):
+            pr.note_on(36 + 5 * v)
+        for k in range(3):
+            with np.errstate(all="ignore"):
+                g, o = pr.render_voices(256)
+            assert_bits_equal(g, o, "q %g block %d" % (q, k))
     s = s2.Synth(8, max_frames=256)
+    s.set_patch(make_patch(lpf_kind=s2.FILT_BP2, lpf_q=0.0))
+    with pytest.raises(s2.S2rError) as e:
+        s.sample(np.empty(256, dtype=np.float32), 48000)
+    assert e.value.status == -5
     s.set_patch(make_patch(lpf_kind=s2.FILT_HP2, lpf_freq=3.0e37, mod_env_to_lpf_freq=10.0))
     with pytest.raises(s2.S2rError) as e:
         s.sample(np.empty(256, dtype=np.float32), 48000)
@@ -514,7 +528,7 @@ def test_dsp_filter_state_survives_patch_switches_and_checkpoints():
         assert_bits_equal(g, o, "lp2 resumed %d" % k)
 
 
-@pytest.mark.parametrize("kind", [s2.FILT_LP2, s2.FILT_HP1])
+@pytest.mark.parametrize("kind", [s2.FILT_LP2, s2.FILT_HP1, s2.FILT_BP2])
 def test_dsp_filters_with_timed_events(kind):
     """timed events (16-frame boundaries inside one launch) under the dsp filters"""
     voices = 100

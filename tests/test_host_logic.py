@@ -77,9 +77,10 @@ def test_patch_full_grammar():
     # the filter selector: filters.rs one-pole by default, dsp_filters.rs:25-180 by name
     d = s2.parse_patch("synth x { }")
     assert d.lpf_kind == s2.FILT_ONEPOLE and d.lpf_damping == np.float32(2.0 ** 0.5)
-    for kind, code in (("onepole", 0), ("lp1", 1), ("hp1", 2), ("lp2", 3), ("hp2", 4)):
-        q = s2.parse_patch("synth x { lpf.kind = %s; lpf.damping = 0.25 }" % kind)
-        assert q.lpf_kind == code and q.lpf_damping == 0.25
+    assert d.lpf_q == 3.0
+    for kind, code in (("onepole", 0), ("lp1", 1), ("hp1", 2), ("lp2", 3), ("hp2", 4), ("bp2", 5)):
+        q = s2.parse_patch("synth x { lpf.kind = %s; lpf.damping = 0.25; lpf.q = 1.5 }" % kind)
+        assert q.lpf_kind == code and q.lpf_damping == 0.25 and q.lpf_q == 1.5
 
 
 @pytest.mark.parametrize("text,status", [
@@ -95,7 +96,8 @@ def test_patch_full_grammar():
     ("synth x { lpf.freq = nan }", -5),
     ("synth x { osc.kind = 7 }", -5),
     ("synth x { lpf.kind = bandpass }", -4),
-    ("synth x { lpf.kind = 5 }", -5),
+    ("synth x { lpf.kind = 6 }", -5),
+    ("synth x { lpf.q = 11 }", -5),                   # Unipolar<10>, dsp_filters.rs:195
     ("synth x { lpf.damping = 10.5 }", -5),           # Unipolar<10>, dsp_filters.rs:96
 ])
 def test_patch_errors(text, status):

@@ -86,6 +86,10 @@ def test_sinf_cosf_match_host_libm(libm_xcheck):
         _run(libm_xcheck, fn, 119, 121)          # reduce_fast / reduce_large switch
         _run(libm_xcheck, fn, 2600, 2800)
         _run(libm_xcheck, fn, 1e30, 1.0001e30)
+    # dsp_filters.rs:205-207 (theta / (2 q)).tan()
+    _run(libm_xcheck, "tanf", 0, 8)
+    _run(libm_xcheck, "tanf", 119, 121)
+    _run(libm_xcheck, "tanf", 6000, 7000)
 
 
 def test_noise_quotient_all_u16(libm_xcheck):
@@ -114,5 +118,6 @@ def test_full_sweeps(libm_xcheck, sleef_xcheck):
     _run(libm_xcheck, "powf2", "all")
     _run(libm_xcheck, "sinf", "all")
     _run(libm_xcheck, "cosf", "all")
+    _run(libm_xcheck, "tanf", "all")
     _run(sleef_xcheck, "pow2", -10, 10)
     _run(sleef_xcheck, "grid", 200000000, 7)
