@@ -105,7 +105,7 @@ typedef struct {
     uint8_t note;                  /* Voice.note */
     uint8_t started;               /* current_frame_offset.is_some() */
     uint8_t released;              /* release_frame_offset.is_some() */
-    uint8_t _pad;
+    uint8_t program;               /* patch bank index the voice was started with */
     uint32_t current_frame_offset;
     uint32_t release_frame_offset;
     float pitch_hz;                /* note_to_pitch(note), synth.rs:208-212 */
@@ -128,6 +128,16 @@ void s2r_destroy(s2r_synth *s);
 int s2r_load_patch(s2r_synth *s, const char *text, size_t len);
 int s2r_set_patch(s2r_synth *s, const s2r_patch *patch);
 int s2r_get_patch(const s2r_synth *s, s2r_patch *out);
+
+/* Patch bank ("per-voice patches"; build-defined, the reference has one patch per
+ * Synth).  A bank of 1..S2R_MAX_BANK patches; the current program (MIDI program change) selects
+ * the patch a note_on gives its voice, and the voice keeps it until it is restarted.
+ * s2r_set_patch / s2r_load_patch / s2r_get_patch address patch 0; a fresh handle has a bank of
+ * one.  A voice whose program lies past a later, smaller bank renders with patch 0. */
+#define S2R_MAX_BANK 256u
+int s2r_set_patch_bank(s2r_synth *s, const s2r_patch *patches, uint32_t n);
+uint32_t s2r_patch_bank_size(const s2r_synth *s);
+int s2r_program_change(s2r_synth *s, uint32_t program);      /* S2R_ERR_INVALID if program >= bank size */
 void s2r_default_patch(s2r_patch *out);                      /* synth.rs:125-152 */
 
 /* Synth::note_on(Note, Velocity) (synth.rs:61-70) incl. next_voice (synth.rs:101-120).
@@ -146,7 +156,9 @@ int s2r_note_off(s2r_synth *s, uint8_t note);
  * next fill at that frame, exactly as if the caller had split the fill there — s2_bin's
  * apply-MIDI-every-16-frames loop (main.rs:138-143) reproduced inside one launch.  Events
  * must be submitted in non-decreasing frame order. */
-typedef enum { S2R_NOTE_OFF = 0, S2R_NOTE_ON = 1 } s2r_note_kind;
+typedef enum { S2R_NOTE_OFF = 0, S2R_NOTE_ON = 1,
+               S2R_PROGRAM_CHANGE = 2   /* `note` = patch bank index for the note_ons that follow */
+} s2r_note_kind;
 typedef struct { uint8_t kind; uint8_t note; uint16_t frame; float velocity; } s2r_note_event;
 int s2r_note_events(s2r_synth *s, const s2r_note_event *events, size_t n);
 

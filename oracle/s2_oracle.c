@@ -499,7 +499,24 @@ s2o_synth *s2o_synth_new(uint32_t num_voices) {
     s->voices = (s2o_voice *)calloc(num_voices ? num_voices : 1, sizeof(s2o_voice)); /* Voice::default(), :41-51 */
     return s;
 }
-void s2o_synth_free(s2o_synth *s) { if (s) { free(s->voices); free(s); } }
+void s2o_synth_free(s2o_synth *s) { if (s) { free(s->voices); free(s->bank); free(s); } }
+
+void s2o_set_bank(s2o_synth *s, const s2o_layer_cfg *cfgs, uint32_t n) {
+    free(s->bank);
+    s->bank = NULL; s->bank_size = 0;
+    if (n) {
+        s->bank = (s2o_layer_cfg *)malloc(sizeof(s2o_layer_cfg) * n);
+        memcpy(s->bank, cfgs, sizeof(s2o_layer_cfg) * n);
+        s->bank_size = n;
+    }
+    if (s->current_program >= n) s->current_program = 0;
+}
+void s2o_program_change(s2o_synth *s, uint32_t program) { s->current_program = program; }
+
+static const s2o_layer_cfg *voice_config(const s2o_synth *s, const s2o_voice *v) {
+    if (!s->bank_size) return &s->config;
+    return &s->bank[v->program < s->bank_size ? v->program : 0];
+}
 
 /* synth.rs:101-120: the voice with the greatest current_frame_offset (None = u32::MAX),
  * first such index on ties (strict `>`). */
@@ -520,6 +537,7 @@ void s2o_note_on(s2o_synth *s, uint8_t note, float velocity) {
     v->note = note; v->velocity = velocity;
     v->has_current = 1; v->current_frame_offset = 0;
     v->has_release = 0;
+    v->program = s->current_program;
 }
 
 /* synth.rs:72-96: LAST index whose note matches and which is active */
@@ -544,7 +562,7 @@ static void render_one_voice(s2o_synth *s, s2o_voice *v, float *row, size_t fram
     while (done < frames) {
         size_t n = frames - done < 16 ? frames - done : 16;
         float buf[16] = {0};
-        if (s2o_process_layer_buf_simd(&s->config, &v->state, pitch, sr, v->current_frame_offset,
+        if (s2o_process_layer_buf_simd(voice_config(s, v), &v->state, pitch, sr, v->current_frame_offset,
                                        v->has_release, v->release_frame_offset, buf, n) != 0)
             s->panicked = 1;
         memcpy(row + done, buf, n * sizeof(float));

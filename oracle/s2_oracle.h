@@ -71,6 +71,7 @@ typedef struct {
     int32_t has_release;
     uint32_t release_frame_offset;
     s2o_layer_state state;
+    uint32_t program;       /* patch bank index the voice was started with (build-defined extension) */
 } s2o_voice;
 
 /* synth.rs:9-12, with NUM_VOICES (synth.rs:7) made a run-time size */
@@ -80,6 +81,11 @@ typedef struct {
     s2o_voice *voices;
     int32_t panicked;        /* set where the reference would panic (process.rs:36,71) */
     uint64_t double_release; /* synth.rs:77 warn counter */
+    /* patch bank (build-defined): bank_size == 0 -> `config` for every voice;
+     * otherwise a voice renders with bank[its program] (bank[0] when the index is past the bank) */
+    s2o_layer_cfg *bank;
+    uint32_t bank_size;
+    uint32_t current_program;
 } s2o_synth;
 
 /* GPU mix-tree description: every 16 consecutive voices are added in index
@@ -93,6 +99,8 @@ typedef struct { uint32_t block_voices; uint32_t groups; } s2o_tree;
 s2o_layer_cfg s2o_default_config(void);                     /* synth.rs:125-152 */
 s2o_synth *s2o_synth_new(uint32_t num_voices);              /* synth.rs:54-59 */
 void s2o_synth_free(s2o_synth *s);
+void s2o_set_bank(s2o_synth *s, const s2o_layer_cfg *cfgs, uint32_t n);   /* n == 0: back to `config` */
+void s2o_program_change(s2o_synth *s, uint32_t program);
 void s2o_note_on(s2o_synth *s, uint8_t note, float velocity);   /* synth.rs:61-70,101-120 */
 void s2o_note_off(s2o_synth *s, uint8_t note);                  /* synth.rs:72-96 */
 uint32_t s2o_next_voice_index(const s2o_synth *s);              /* synth.rs:101-120 */

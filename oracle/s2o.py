@@ -34,12 +34,13 @@ class LayerState(C.Structure):
 class Voice(C.Structure):
     _fields_ = [("note", C.c_uint8), ("velocity", C.c_float), ("has_current", C.c_int32),
                 ("current_frame_offset", C.c_uint32), ("has_release", C.c_int32),
-                ("release_frame_offset", C.c_uint32), ("state", LayerState)]
+                ("release_frame_offset", C.c_uint32), ("state", LayerState), ("program", C.c_uint32)]
 
 
 class SynthS(C.Structure):
     _fields_ = [("config", LayerCfg), ("num_voices", C.c_uint32), ("voices", C.POINTER(Voice)),
-                ("panicked", C.c_int32), ("double_release", C.c_uint64)]
+                ("panicked", C.c_int32), ("double_release", C.c_uint64),
+                ("bank", C.POINTER(LayerCfg)), ("bank_size", C.c_uint32), ("current_program", C.c_uint32)]
 
 
 class Tree(C.Structure):
@@ -68,6 +69,8 @@ def lib():
     L.s2o_synth_new.argtypes = [C.c_uint32]
     L.s2o_synth_free.argtypes = [P]
     L.s2o_note_on.argtypes = [P, C.c_uint8, C.c_float]
+    L.s2o_set_bank.argtypes = [P, C.POINTER(LayerCfg), C.c_uint32]
+    L.s2o_program_change.argtypes = [P, C.c_uint32]
     L.s2o_note_off.argtypes = [P, C.c_uint8]
     L.s2o_next_voice_index.restype = C.c_uint32
     L.s2o_next_voice_index.argtypes = [P]
@@ -142,6 +145,13 @@ class OracleSynth:
     @config.setter
     def config(self, c):
         self.p.contents.config = c
+
+    def set_bank(self, cfgs):
+        arr = (LayerCfg * len(cfgs))(*cfgs)
+        self.L.s2o_set_bank(self.p, arr, len(cfgs))
+
+    def program_change(self, program):
+        self.L.s2o_program_change(self.p, program)
 
     def note_on(self, note, velocity=1.0):
         self.L.s2o_note_on(self.p, note, velocity)

@@ -36,8 +36,19 @@ struct S2rVoiceArrays {
     uint32_t *seed;       // NoiseState.seed                 state.rs:17-21
     // dsp_filters.rs:12-17,82-89 states; only touched by patches with lpf.kind != onepole
     float *fx1, *fx2, *fy1, *fy2;
+    uint32_t *program;    // index into the patch bank the voice was started with (0 without a bank)
 };
-#define S2R_VOICE_WORDS 11
+#define S2R_VOICE_WORDS 12
+
+// One patch of the bank, resolved for the fill's sample rate (what S2rRenderParams carries for
+// the single-patch kernels).
+struct S2rBankEntry {
+    int32_t osc_kind;
+    float osc_gain, noise_level, lpf_freq, amt_osc, amt_lpf;
+    int32_t lpf_kind;
+    float lpf_shape;      // damping_factor (LP2/HP2) or quality_factor (BP2)
+    S2rEnv amp, mod;
+};
 
 struct S2rTimedEvent;
 
@@ -78,18 +89,23 @@ struct S2rRenderParams {
     // timed events of this fill (nullptr: none)
     const S2rTimedEvent *tev;
     int32_t *voice_ev_head;     // [padded voices] index of the voice's first timed event, -1 = none
+    // patch bank (bank_size > 1: s2r_render_general_kernel<ANY, true>; the fields above then hold patch 0)
+    const S2rBankEntry *bank;
+    uint32_t bank_size;
 };
 
 // Coalesced note events, one record per touched voice per fill (host folds the event
 // stream of synth.rs:61-80 between two fills into the voice's final state).
 struct S2rVoiceEvent {
     uint32_t voice;       // shard-local index
-    uint32_t flags;       // bit0: restart (note_on), bit1: release (note_off after the last on)
+    uint32_t flags;       // bit0: restart (note_on), bit1: release (note_off after the last on),
+                          // bits 16..: the program (patch bank index) a restart carries
     float pitch;          // valid when restart
     uint32_t seed;        // NoiseState.seed for the restarted voice (reference: 0)
 };
 #define S2R_EV_RESTART 1u
 #define S2R_EV_RELEASE 2u
+#define S2R_EV_PROGRAM_SHIFT 16
 
 // A note event that takes effect INSIDE a fill, at a 16-frame boundary — what s2_bin does by
 // calling sample() 16 frames at a time with MIDI applied in between (main.rs:138-143), here
@@ -102,7 +118,8 @@ struct S2rTimedEvent {
     float pitch;          // valid when restart
     uint32_t seed;
     int32_t next;         // index of the voice's next event in this fill, -1 = none
-    uint32_t _pad[2];
+    uint32_t program;     // patch bank index of a restart
+    uint32_t _pad;
 };
 #define S2R_TEV_FIRST 0x100u
 

@@ -102,7 +102,10 @@ struct s2r_synth {
     s2r_config cfg{};
     int device = 0;
     uint32_t shard_begin = 0, shard_voices = 0, padded_voices = 0, block_voices = 256, n_blocks = 0, mix_groups = 1, lanes = 1;
-    s2r_patch patch{};
+    std::vector<s2r_patch> bank;                 // bank[0] is "the" patch of the reference's Synth
+    uint32_t program = 0;                        // current program: the patch the next note_on gives its voice
+    S2rBankEntry *bank_dev = nullptr;            // S2R_MAX_BANK entries, resolved for bank_rate
+    bool bank_dirty = true; uint32_t bank_rate = 0;
     std::unique_ptr<S2rVoicePool> pool;
     std::vector<uint32_t> seed_override;         // per pool voice; 0 = reference behaviour
     // event folding (one record per touched shard voice between two fills)
@@ -152,7 +155,7 @@ int set_err(s2r_synth *s, int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return set_err((s), S2R_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
-void push_event(s2r_synth *s, uint32_t pool_index, uint32_t flags, float pitch, uint32_t seed) {
+void push_event(s2r_synth *s, uint32_t pool_index, uint32_t flags, float pitch, uint32_t seed, uint32_t program = 0) {
     if (pool_index < s->shard_begin || pool_index >= s->shard_begin + s->shard_voices) return;
     const uint32_t local = pool_index - s->shard_begin;
     int32_t slot = s->pending_slot[local];
@@ -162,7 +165,9 @@ void push_event(s2r_synth *s, uint32_t pool_index, uint32_t flags, float pitch, 
         s->pending.push_back(S2rVoiceEvent{local, 0u, 0.0f, 0u});
     }
     S2rVoiceEvent &e = s->pending[(size_t)slot];
-    if (flags & S2R_EV_RESTART) { e.flags = S2R_EV_RESTART; e.pitch = pitch; e.seed = seed; }   // wipes an earlier release
+    if (flags & S2R_EV_RESTART) {                 // wipes an earlier release
+        e.flags = S2R_EV_RESTART | (program << S2R_EV_PROGRAM_SHIFT); e.pitch = pitch; e.seed = seed;
+    }
     if (flags & S2R_EV_RELEASE) e.flags |= S2R_EV_RELEASE;
 }
 
@@ -208,40 +213,42 @@ int check_fill(s2r_synth *s, size_t frames, uint32_t sample_rate) {
         return set_err(s, S2R_ERR_INVALID, "a timed event at frame %u does not fall inside this %zu-frame fill", s->fill_time, frames);
     if (s->pool->oldest_offset() + (frames - s->fill_time) > 0xffffffffull)
         return set_err(s, S2R_ERR_OFFSET_OVERFLOW, "a voice's frame offset would overflow u32 (the reference panics here)");
-    if (s->patch.lpf_kind != S2R_FILT_ONEPOLE) {
+    for (size_t k = 0; k < s->bank.size(); k++) {
+        const s2r_patch &pt = s->bank[k];
+        if (pt.lpf_kind == S2R_FILT_ONEPOLE) continue;
         // dsp_filters.rs evaluates sin/cos of theta = 2 pi f / sr.  The device restatement of the libm
         // routines is exact for every finite argument; only an overflowing 2 pi f (inf -> NaN, whose
         // sign bit differs between x86 and the GPU) is refused.
-        const double amt = s->patch.mod_env_to_lpf_freq > 0.0f ? (double)s->patch.mod_env_to_lpf_freq : 0.0;
-        const double num_max = 2.0 * 3.14159265358979323846 * (double)s->patch.lpf_freq * std::exp2(amt) * 1.000001;
+        const double amt = pt.mod_env_to_lpf_freq > 0.0f ? (double)pt.mod_env_to_lpf_freq : 0.0;
+        const double num_max = 2.0 * 3.14159265358979323846 * (double)pt.lpf_freq * std::exp2(amt) * 1.000001;
         if (!(num_max < 3.4028234e38))
-            return set_err(s, S2R_ERR_PATCH_RANGE, "lpf.kind %d: 2 pi * lpf.freq * 2^mod_env_to_lpf_freq overflows f32",
-                           s->patch.lpf_kind);
+            return set_err(s, S2R_ERR_PATCH_RANGE, "patch %zu, lpf.kind %d: 2 pi * lpf.freq * 2^mod_env_to_lpf_freq overflows f32",
+                           k, pt.lpf_kind);
         // dsp_filters.rs:205-207: tan(theta / (2 Q)); Q = 0 makes that tan(inf) = NaN (same sign caveat)
-        if (s->patch.lpf_kind == S2R_FILT_BP2 &&
-            !(s->patch.lpf_q > 0.0f && num_max / (double)sample_rate / (2.0 * (double)s->patch.lpf_q) < 3.4028234e38))
-            return set_err(s, S2R_ERR_PATCH_RANGE, "lpf.kind bp2 needs lpf.q > 0 (tan(theta / (2 q)) must stay finite)");
+        if (pt.lpf_kind == S2R_FILT_BP2 &&
+            !(pt.lpf_q > 0.0f && num_max / (double)sample_rate / (2.0 * (double)pt.lpf_q) < 3.4028234e38))
+            return set_err(s, S2R_ERR_PATCH_RANGE, "patch %zu: lpf.kind bp2 needs lpf.q > 0 (tan(theta / (2 q)) must stay finite)", k);
     }
     return S2R_OK;
 }
 
 S2rRenderParams make_params(s2r_synth *s, size_t frames, uint32_t sample_rate) {
     S2rRenderParams p{};
-    p.osc_kind = s->patch.osc_kind;
-    p.osc_gain = s->patch.osc_gain;
-    p.noise_level = s->patch.noise;
-    p.lpf_freq = s->patch.lpf_freq;
-    p.amt_osc = s->patch.mod_env_to_osc_freq;
-    p.amt_lpf = s->patch.mod_env_to_lpf_freq;
-    p.lpf_kind = s->patch.lpf_kind;
-    p.lpf_damping = s->patch.lpf_kind == S2R_FILT_BP2 ? s->patch.lpf_q : s->patch.lpf_damping;
-    p.amp = resolve_env(s->patch.amp_env, sample_rate);
-    p.mod = resolve_env(s->patch.mod_env, sample_rate);
+    p.osc_kind = s->bank[0].osc_kind;
+    p.osc_gain = s->bank[0].osc_gain;
+    p.noise_level = s->bank[0].noise;
+    p.lpf_freq = s->bank[0].lpf_freq;
+    p.amt_osc = s->bank[0].mod_env_to_osc_freq;
+    p.amt_lpf = s->bank[0].mod_env_to_lpf_freq;
+    p.lpf_kind = s->bank[0].lpf_kind;
+    p.lpf_damping = s->bank[0].lpf_kind == S2R_FILT_BP2 ? s->bank[0].lpf_q : s->bank[0].lpf_damping;
+    p.amp = resolve_env(s->bank[0].amp_env, sample_rate);
+    p.mod = resolve_env(s->bank[0].mod_env, sample_rate);
     p.sr = (float)sample_rate;
     p.rcp_sr = 1.0f / p.sr;
     // 2^-10 <= pow2 <= 2^10 (|mod * amount| <= 10), so lpf_freq in [2^-30, 2^30] keeps the
     // dividend inside the window the 3-op quotient was verified for
-    p.fast_div_sr = (fast_div_rate(sample_rate) && s->patch.lpf_freq >= 0x1p-30f && s->patch.lpf_freq <= 0x1p30f) ? 1 : 0;
+    p.fast_div_sr = (fast_div_rate(sample_rate) && s->bank[0].lpf_freq >= 0x1p-30f && s->bank[0].lpf_freq <= 0x1p30f) ? 1 : 0;
     p.no_flat_shortcut = s->no_flat_shortcut ? 1 : 0;
     p.frames = (uint32_t)frames;
     p.n_voices = s->shard_voices;
@@ -251,8 +258,10 @@ S2rRenderParams make_params(s2r_synth *s, size_t frames, uint32_t sample_rate) {
     p.per_voice = nullptr;
     p.sin_table = s->sin_dev;
     // stream only where it is defined: no oscillator FM, the flat-envelope logic enabled
-    p.use_coeff = (s->use_coeff && !s->no_flat_shortcut && s->patch.mod_env_to_osc_freq == 0.0f && s->coeff != nullptr &&
-                   s->patch.lpf_kind == S2R_FILT_ONEPOLE) ? 1 : 0;
+    p.use_coeff = (s->use_coeff && !s->no_flat_shortcut && s->bank[0].mod_env_to_osc_freq == 0.0f && s->coeff != nullptr &&
+                   s->bank[0].lpf_kind == S2R_FILT_ONEPOLE && s->bank.size() == 1) ? 1 : 0;
+    p.bank = s->bank_dev;
+    p.bank_size = (uint32_t)s->bank.size();
     p.group_slot = s->group_slot; p.group_slot_w = s->group_slot; p.slot_group = s->slot_group;
     p.coeff_count = s->coeff_count; p.coeff_parity = s->coeff_parity; p.coeff_capacity = s->coeff_capacity;
     p.coeff = s->coeff;
@@ -266,6 +275,23 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
     const S2rTimedEvent *tev_dev = nullptr;
     int rc = flush_events(s, stream, &timed_slot, &tev_dev);
     if (rc != S2R_OK) return rc;
+    if (s->bank.size() > 1 && (s->bank_dirty || s->bank_rate != sample_rate)) {
+        // resolve every patch for this sample rate (Ms::as_samples, units.rs:44-53) and replace the
+        // device copy; rare (bank edits, rate changes), so a synchronous hand-over is fine
+        std::vector<S2rBankEntry> host(s->bank.size());
+        for (size_t k = 0; k < s->bank.size(); k++) {
+            const s2r_patch &pt = s->bank[k];
+            S2rBankEntry &e = host[k];
+            e.osc_kind = pt.osc_kind; e.osc_gain = pt.osc_gain; e.noise_level = pt.noise; e.lpf_freq = pt.lpf_freq;
+            e.amt_osc = pt.mod_env_to_osc_freq; e.amt_lpf = pt.mod_env_to_lpf_freq; e.lpf_kind = pt.lpf_kind;
+            e.lpf_shape = pt.lpf_kind == S2R_FILT_BP2 ? pt.lpf_q : pt.lpf_damping;
+            e.amp = resolve_env(pt.amp_env, sample_rate);
+            e.mod = resolve_env(pt.mod_env, sample_rate);
+        }
+        S2R_HIP(s, hipMemcpyAsync(s->bank_dev, host.data(), host.size() * sizeof(S2rBankEntry), hipMemcpyHostToDevice, stream));
+        S2R_HIP(s, hipStreamSynchronize(stream));
+        s->bank_dirty = false; s->bank_rate = sample_rate;
+    }
     S2rRenderParams p = make_params(s, frames, sample_rate);
     p.per_voice = per_voice_dev;
     p.tev = tev_dev;
@@ -326,6 +352,7 @@ void release_all(s2r_synth *s) {
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     if (s->voice_mem) (void)hipFree(s->voice_mem);
+    if (s->bank_dev) (void)hipFree(s->bank_dev);
     if (s->block_partials) (void)hipFree(s->block_partials);
     if (s->out_dev) (void)hipFree(s->out_dev);
     if (s->out_host) (void)hipHostFree(s->out_host);
@@ -401,7 +428,8 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
         if (l != 1 && l != 2 && l != 4) { delete s; return S2R_ERR_INVALID; }
         s->lanes = l;
     }
-    s2r_default_patch(&s->patch);
+    s->bank.resize(1);
+    s2r_default_patch(&s->bank[0]);
     s->pool.reset(new S2rVoicePool(cfg->total_voices));
     s->seed_override.assign(cfg->total_voices, 0u);
     s->pending_slot.assign(shard_voices, -1);
@@ -434,6 +462,8 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
     s->v.fx2 = (float *)(base + 8 * pv);
     s->v.fy1 = (float *)(base + 9 * pv);
     s->v.fy2 = (float *)(base + 10 * pv);
+    s->v.program = base + 11 * pv;
+    CREATE_HIP(hipMalloc((void **)&s->bank_dev, S2R_MAX_BANK * sizeof(S2rBankEntry)));
     CREATE_HIP(hipMalloc((void **)&s->block_partials, (size_t)s->n_blocks * cfg->max_frames * sizeof(float)));
     CREATE_HIP(hipMalloc((void **)&s->out_dev, (size_t)2 * cfg->max_frames * sizeof(float)));
     CREATE_HIP(hipHostMalloc((void **)&s->out_host, (size_t)2 * cfg->max_frames * sizeof(float), hipHostMallocDefault));
@@ -489,13 +519,37 @@ int s2r_set_patch(s2r_synth *s, const s2r_patch *patch) {
     std::string err;
     int rc = s2r_validate_patch(patch, &err);
     if (rc != S2R_OK) return set_err(s, rc, "%s", err.c_str());
-    s->patch = *patch;
+    s->bank[0] = *patch;
+    s->bank_dirty = true;
+    return S2R_OK;
+}
+
+int s2r_set_patch_bank(s2r_synth *s, const s2r_patch *patches, uint32_t n) {
+    if (!s || !patches) return S2R_ERR_INVALID;
+    if (n == 0 || n > S2R_MAX_BANK) return set_err(s, S2R_ERR_INVALID, "a patch bank holds 1..%u patches, not %u", S2R_MAX_BANK, n);
+    for (uint32_t k = 0; k < n; k++) {
+        std::string err;
+        int rc = s2r_validate_patch(&patches[k], &err);
+        if (rc != S2R_OK) return set_err(s, rc, "patch %u: %s", k, err.c_str());
+    }
+    s->bank.assign(patches, patches + n);
+    if (s->program >= n) s->program = 0;
+    s->bank_dirty = true;
+    return S2R_OK;
+}
+
+uint32_t s2r_patch_bank_size(const s2r_synth *s) { return s ? (uint32_t)s->bank.size() : 0u; }
+
+int s2r_program_change(s2r_synth *s, uint32_t program) {
+    if (!s) return S2R_ERR_INVALID;
+    if (program >= s->bank.size()) return set_err(s, S2R_ERR_INVALID, "program %u: the bank holds %zu patches", program, s->bank.size());
+    s->program = program;
     return S2R_OK;
 }
 
 int s2r_get_patch(const s2r_synth *s, s2r_patch *out) {
     if (!s || !out) return S2R_ERR_INVALID;
-    *out = s->patch;
+    *out = s->bank[0];
     return S2R_OK;
 }
 
@@ -505,7 +559,8 @@ int s2r_load_patch(s2r_synth *s, const char *text, size_t len) {
     std::string err;
     int rc = s2r_parse_patch(text ? text : "", len, &p, nullptr, &err);
     if (rc != S2R_OK) return set_err(s, rc, "%s", err.c_str());
-    s->patch = p;
+    s->bank[0] = p;
+    s->bank_dirty = true;
     return S2R_OK;
 }
 
@@ -522,7 +577,7 @@ int s2r_note_on_ex(s2r_synth *s, uint8_t note, float velocity, uint32_t *voice_i
     if (s->fill_time) return set_err(s, S2R_ERR_INVALID, "untimed note_on after timed events: fill first or give it a frame");
     const uint32_t i = s->pool->note_on(note, velocity);
     if (voice_index_out) *voice_index_out = i;
-    push_event(s, i, S2R_EV_RESTART, s->pitch_table[note], s->seed_override[i]);
+    push_event(s, i, S2R_EV_RESTART, s->pitch_table[note], s->seed_override[i], s->program);
     return S2R_OK;
 }
 
@@ -540,6 +595,11 @@ int s2r_note_events(s2r_synth *s, const s2r_note_event *events, size_t n) {
     if (!s || (!events && n)) return S2R_ERR_INVALID;
     for (size_t k = 0; k < n; k++) {
         const s2r_note_event &e = events[k];
+        if (e.kind == S2R_PROGRAM_CHANGE) {      // host-side state: which patch the following note_ons get
+            if (e.note >= s->bank.size()) return set_err(s, S2R_ERR_INVALID, "event %zu: program %u, the bank holds %zu patches", k, (unsigned)e.note, s->bank.size());
+            s->program = e.note;
+            continue;
+        }
         if (e.kind != S2R_NOTE_ON && e.kind != S2R_NOTE_OFF)
             return set_err(s, S2R_ERR_INVALID, "event %zu: unknown kind %u", k, (unsigned)e.kind);
         const uint32_t frame = e.frame;
@@ -548,7 +608,7 @@ int s2r_note_events(s2r_synth *s, const s2r_note_event *events, size_t n) {
         if (frame == 0) {                     // takes effect before the next fill: folded per voice
             if (e.kind == S2R_NOTE_ON) {
                 const uint32_t i = s->pool->note_on(e.note, e.velocity);
-                push_event(s, i, S2R_EV_RESTART, s->pitch_table[e.note], s->seed_override[i]);
+                push_event(s, i, S2R_EV_RESTART, s->pitch_table[e.note], s->seed_override[i], s->program);
             } else {
                 const int64_t i = s->pool->note_off(e.note);
                 if (i >= 0) push_event(s, (uint32_t)i, S2R_EV_RELEASE, 0.0f, 0u);
@@ -574,6 +634,7 @@ int s2r_note_events(s2r_synth *s, const s2r_note_event *events, size_t n) {
         const int32_t idx = (int32_t)s->tpending.size();
         S2rTimedEvent te{};
         te.voice = local; te.frame = frame; te.flags = fl; te.pitch = pitch; te.seed = seed; te.next = -1;
+        te.program = s->program;
         if (s->tlast[local] >= 0) s->tpending[(size_t)s->tlast[local]].next = idx;
         else te.flags |= S2R_TEV_FIRST;
         s->tlast[local] = idx;
@@ -660,6 +721,7 @@ int s2r_export_state(s2r_synth *s, s2r_voice_state *voices) {
         o.noise_seed = h[6 * pv + i];
         o.filt_x1 = s2r_u2f(h[7 * pv + i]); o.filt_x2 = s2r_u2f(h[8 * pv + i]);
         o.filt_y1 = s2r_u2f(h[9 * pv + i]); o.filt_y2 = s2r_u2f(h[10 * pv + i]);
+        o.program = (uint8_t)h[11 * pv + i];
         o.velocity = hv.velocity;
     }
     return S2R_OK;
@@ -685,6 +747,7 @@ int s2r_import_state(s2r_synth *s, const s2r_voice_state *voices) {
         h[6 * pv + i] = in.noise_seed;
         h[7 * pv + i] = s2r_f2u(in.filt_x1); h[8 * pv + i] = s2r_f2u(in.filt_x2);
         h[9 * pv + i] = s2r_f2u(in.filt_y1); h[10 * pv + i] = s2r_f2u(in.filt_y2);
+        h[11 * pv + i] = in.program;
         s->pool->set_voice(s->shard_begin + i, in.note, in.started != 0, in.released != 0,
                            in.current_frame_offset, in.release_frame_offset, in.velocity);
     }

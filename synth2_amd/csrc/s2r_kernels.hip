@@ -269,15 +269,40 @@ __device__ __forceinline__ float osc_value(const OscK &k, float off, const float
     }
 }
 
+// OSC == S2R_OSC_ANY: the oscillator kind is a per-lane run-time value (patch banks)
+constexpr int S2R_OSC_ANY = 4;
+
+template <int OSC>
+__device__ __forceinline__ OscK make_osck_any(int kind, float period) {
+    if (OSC != S2R_OSC_ANY) return make_osck<OSC>(period);
+    OscK k;
+    k.period = period;
+    k.inv_period = 1.0f / period;
+    k.a = k.b = k.c = 0.0f;
+    if (kind == S2R_OSC_SAW) k.a = -2.0f / period;
+    if (kind == S2R_OSC_SQUARE || kind == S2R_OSC_TRIANGLE) k.a = period / 2.0f;
+    if (kind == S2R_OSC_TRIANGLE) { k.b = -2.0f / k.a; k.c = 2.0f / k.a; }
+    return k;
+}
+
+template <int OSC>
+__device__ __forceinline__ float osc_value_any(int kind, const OscK &k, float off, const float *sSin) {
+    if (OSC != S2R_OSC_ANY) return osc_value<(OSC == S2R_OSC_ANY ? 0 : OSC)>(k, off, sSin);
+    if (kind == S2R_OSC_SAW) return osc_value<S2R_OSC_SAW>(k, off, sSin);
+    if (kind == S2R_OSC_SQUARE) return osc_value<S2R_OSC_SQUARE>(k, off, sSin);
+    if (kind == S2R_OSC_TRIANGLE) return osc_value<S2R_OSC_TRIANGLE>(k, off, sSin);
+    return osc_value<S2R_OSC_SINE>(k, off, sSin);
+}
+
 // filters.rs:20-21: x = exp(-2 pi f / sr)
-template <bool FASTDIV>
-__device__ __forceinline__ float lpf_arg(const S2rRenderParams &p, float f_lpf) {
+template <bool FASTDIV, class P = S2rRenderParams>
+__device__ __forceinline__ float lpf_arg(const P &p, float f_lpf) {
     const float num = (-2.0f * 3.14159274101257324f) * f_lpf;   // -2.0 * pi * freq
     return FASTDIV ? s2r_div_const_nocheck(num, p.sr, p.rcp_sr) : (num / p.sr);
 }
-template <bool FASTDIV>
-__device__ __forceinline__ float lpf_coeff(const S2rRenderParams &p, float f_lpf, const uint64_t *sT) {
-    return s2r_expf(lpf_arg<FASTDIV>(p, f_lpf), sT);
+template <bool FASTDIV, class P = S2rRenderParams>
+__device__ __forceinline__ float lpf_coeff(const P &p, float f_lpf, const uint64_t *sT) {
+    return s2r_expf(lpf_arg<FASTDIV, P>(p, f_lpf), sT);
 }
 
 // filters.rs:23-33: out = a0.mul_add(input, -b1 * last) with a0 = 1 - x, b1 = -x
@@ -479,8 +504,8 @@ __device__ __forceinline__ float dsp_filter_step(int kind, float damping, float 
 
 // One frame of process_layer (scalar "sisd" path: process.rs:101-135,252-304).  DSPF: the layer's
 // filter is one of dsp_filters.rs (state in *f2) instead of the one-pole of filters.rs.
-template <int OSC, bool DSPF = false>
-__device__ float frame_sisd(const S2rRenderParams &p, VoiceRegs &r, uint32_t oi,
+template <int OSC, bool DSPF = false, class P = S2rRenderParams>
+__device__ float frame_sisd(const P &p, VoiceRegs &r, uint32_t oi,
                             const uint64_t *sT, const float *sSin, Filt2 *f2 = nullptr) {
     const float t = (float)oi;
     const float rel = r.released ? (float)r.release_u : 4294967296.0f;   // envelopes.rs:35
@@ -488,16 +513,16 @@ __device__ float frame_sisd(const S2rRenderParams &p, VoiceRegs &r, uint32_t oi,
     const float mod = adsr_scalar(p.mod, t, rel);
     const float f_osc = s2r_pow2_libm(mod * p.amt_osc, sT) * r.pitch;    // process.rs:221-229
     const float f_lpf = s2r_pow2_libm(mod * p.amt_lpf, sT) * p.lpf_freq;
-    const OscK k = make_osck<OSC>(p.sr / f_osc);
+    const OscK k = make_osck_any<OSC>(p.osc_kind, p.sr / f_osc);
     const float ph = r.phase;
     const float off = __builtin_fmaf(k.period, ph, 0.0f);                // oscillators.rs:212
-    const float osc = osc_value<OSC>(k, off, sSin);
+    const float osc = osc_value_any<OSC>(p.osc_kind, k, off, sSin);
     r.phase = s2r_fmod1(ph + k.inv_period);                              // oscillators.rs:377-381
     const float osc_s = osc * p.osc_gain;                                // process.rs:287 (MULTIPLY)
     const float noise_s = (hash_noise(r.seed_rot, t)) * p.noise_level;   // process.rs:292 (MULTIPLY)
     const float s = osc_s + noise_s;
     if (DSPF) return dsp_filter_step(p.lpf_kind, p.lpf_damping, p.sr, f_lpf, s, *f2) * amp;
-    const float x = lpf_coeff<false>(p, f_lpf, sT);
+    const float x = lpf_coeff<false, P>(p, f_lpf, sT);
     const float y = lpf_apply(x, s, r.last);
     return y * amp;
 }
@@ -736,7 +761,7 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
     int32_t ev_idx = -1;
     uint32_t ev_frame = 0xffffffffu;
     bool ev_dirty = false, ev_restart = false;
-    uint32_t seed_now = seed;
+    uint32_t seed_now = seed, program_now = 0u;
     if (TEV && in_range) {
         ev_idx = p.voice_ev_head[vi];
         if (ev_idx >= 0) {
@@ -803,6 +828,7 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
                 r.phase = 0.0f; r.last = 0.0f;
                 seed_now = e.seed;
                 r.seed_rot = (e.seed << 5) | (e.seed >> 27);
+                program_now = e.program;
                 live = true; ev_restart = true;
                 k_const = make_osck<OSC>(p.sr / (1.0f * r.pitch));
             } else if ((e.flags & S2R_EV_RELEASE) && live && !r.released) {   // synth.rs:74-75
@@ -934,25 +960,49 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
             p.v.release[vi] = r.release_u;
             p.v.flags[vi] = S2R_VF_STARTED | (r.released ? S2R_VF_RELEASED : 0u);
             p.v.seed[vi] = seed_now;
-            if (ev_restart) { p.v.fx1[vi] = 0.0f; p.v.fx2[vi] = 0.0f; p.v.fy1[vi] = 0.0f; p.v.fy2[vi] = 0.0f; }   // st::Layer::default()
+            if (ev_restart) {                                    // st::Layer::default(), and the program it was started with
+                p.v.fx1[vi] = 0.0f; p.v.fx2[vi] = 0.0f; p.v.fy1[vi] = 0.0f; p.v.fy2[vi] = 0.0f;
+                p.v.program[vi] = program_now;
+            }
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------
-// render kernel for patches whose filter is one of dsp_filters.rs (lpf.kind != onepole).
-// Same voice-per-lane layout, state arrays, mixdown staging and timed events as
-// s2r_render_kernel (L = 1), but the frame loop is the plain one: every frame runs the envelope
-// cascade, both frequency modulations, the oscillator and the filter step, whose coefficients
-// need sin/cos of the modulated cutoff.  First correct version of this row;
-// none of the fast paths of the one-pole kernel apply yet.
+// general render kernel: everything the tuned one-pole kernel above does not cover.
+//   BANK = false: one patch (kernel arguments), filter = one of dsp_filters.rs (lpf.kind != onepole);
+//   BANK = true : a bank of patches, every voice renders with bank[its program] — oscillator kind,
+//                 filter kind and every level are per-lane values (OSC == S2R_OSC_ANY).
+// Same voice-per-lane layout, state arrays, mixdown staging and timed events as s2r_render_kernel
+// (L = 1), but the plain frame loop: per frame the envelope cascade, the oscillator and the filter
+// step; the oscillator constants and the filter coefficients (pow2, exp or sin/cos/tan, the
+// divisions) are recomputed only when some lane's mod-envelope value differs from the previous
+// frame's (wave-uniform test).  DESIGN.md 4.6, 4.7.
 // ---------------------------------------------------------------------------------------
-template <int OSC>
-__global__ void __launch_bounds__(1024) s2r_render_dspf_kernel(const S2rRenderParams p) {
+struct LanePatch {           // field names as in S2rRenderParams: frame_sisd & co. take either
+    int32_t osc_kind;
+    float osc_gain, noise_level, lpf_freq, amt_osc, amt_lpf;
+    int32_t lpf_kind;
+    float lpf_damping;
+    S2rEnv amp, mod;
+    float sr, rcp_sr;
+};
+
+__device__ __forceinline__ LanePatch lane_patch_from_bank(const S2rBankEntry *bank, uint32_t n, uint32_t program, float sr) {
+    const S2rBankEntry e = bank[program < n ? program : 0u];     // an index past the bank renders with patch 0
+    LanePatch lp;
+    lp.osc_kind = e.osc_kind; lp.osc_gain = e.osc_gain; lp.noise_level = e.noise_level; lp.lpf_freq = e.lpf_freq;
+    lp.amt_osc = e.amt_osc; lp.amt_lpf = e.amt_lpf; lp.lpf_kind = e.lpf_kind; lp.lpf_damping = e.lpf_shape;
+    lp.amp = e.amp; lp.mod = e.mod; lp.sr = sr; lp.rcp_sr = 0.0f;
+    return lp;
+}
+
+template <int OSC, bool BANK>
+__global__ void __launch_bounds__(1024) s2r_render_general_kernel(const S2rRenderParams p) {
     const uint32_t kSuper = p.super_frames;
     const bool PV = p.per_voice != nullptr, TEV = p.tev != nullptr;          // wave-uniform
     __shared__ uint64_t sT[S2R_EXP2F_N];
-    __shared__ float sSin[OSC == S2R_OSC_SINE ? 1024 : 1];
+    __shared__ float sSin[(OSC == S2R_OSC_SINE || OSC == S2R_OSC_ANY) ? 1024 : 1];
     extern __shared__ float s_dyn[];
 
     const uint32_t tid = threadIdx.x;
@@ -964,34 +1014,48 @@ __global__ void __launch_bounds__(1024) s2r_render_dspf_kernel(const S2rRenderPa
     const uint32_t vi = blockIdx.x * blockDim.x + tid;
 
     if (tid < S2R_EXP2F_N) sT[tid] = c_exp2f_table[tid];
-    if (OSC == S2R_OSC_SINE)
+    if (OSC == S2R_OSC_SINE || OSC == S2R_OSC_ANY)
         for (uint32_t i = tid; i < 1024u; i += blockDim.x) sSin[i] = p.sin_table[i];
 
     const bool in_range = vi < p.n_voices;
     const uint32_t flags = in_range ? p.v.flags[vi] : 0u;
     bool live = (flags & S2R_VF_STARTED) != 0u;                  // synth.rs:178
+    LanePatch lp;
+    uint32_t program = 0u;
+    if (BANK) {
+        program = live ? p.v.program[vi] : 0u;
+        lp = lane_patch_from_bank(p.bank, p.bank_size, program, p.sr);
+    } else {
+        lp.osc_kind = p.osc_kind; lp.osc_gain = p.osc_gain; lp.noise_level = p.noise_level; lp.lpf_freq = p.lpf_freq;
+        lp.amt_osc = p.amt_osc; lp.amt_lpf = p.amt_lpf; lp.lpf_kind = p.lpf_kind; lp.lpf_damping = p.lpf_damping;
+        lp.amp = p.amp; lp.mod = p.mod; lp.sr = p.sr; lp.rcp_sr = p.rcp_sr;
+    }
     VoiceRegs r;
     r.pitch = live ? p.v.pitch[vi] : 440.0f;
     r.offset = live ? p.v.offset[vi] : 0u;
     r.release_u = live ? p.v.release[vi] : 0u;
     r.released = live && (flags & S2R_VF_RELEASED) != 0u;
     r.phase = live ? p.v.phase[vi] : 0.0f;
-    r.last = 0.0f;                                               // the one-pole state is not touched here
+    r.last = live ? p.v.lpf_last[vi] : 0.0f;
     Filt2 f2;
     f2.x1 = live ? p.v.fx1[vi] : 0.0f; f2.x2 = live ? p.v.fx2[vi] : 0.0f;
     f2.y1 = live ? p.v.fy1[vi] : 0.0f; f2.y2 = live ? p.v.fy2[vi] : 0.0f;
     const uint32_t seed = live ? p.v.seed[vi] : 0u;
     r.seed_rot = (seed << 5) | (seed >> 27);
-    const float rel_f = r.released ? (float)r.release_u : 4294967296.0f;
-    r.ro_a = __builtin_fmaxf(rel_f, p.amp.sus_off); r.end_a = r.ro_a + p.amp.R;
-    r.ro_m = __builtin_fmaxf(rel_f, p.mod.sus_off); r.end_m = r.ro_m + p.mod.R;
+    auto set_release_thresholds = [&]() {
+        const float rf = r.released ? (float)r.release_u : 4294967296.0f;    // u32::MAX as f32
+        r.ro_a = __builtin_fmaxf(rf, lp.amp.sus_off); r.end_a = r.ro_a + lp.amp.R;
+        r.ro_m = __builtin_fmaxf(rf, lp.mod.sus_off); r.end_m = r.ro_m + lp.mod.R;
+    };
+    set_release_thresholds();
 
     int32_t ev_idx = -1;
     uint32_t ev_frame = 0xffffffffu;
-    bool ev_dirty = false, ev_restart = false;
+    bool ev_dirty = false;
     uint32_t seed_now = seed;
-    uint32_t mod_key = 0xffffffffu;          // bits of the mod value `k` and `fc` were computed for (a NaN: never equal)
-    OscK k = make_osck<OSC>(p.sr / r.pitch);
+    uint32_t mod_key = 0xffffffffu;          // bits of the mod value `k`, `xc`, `fc` were computed for (a NaN: never equal)
+    OscK k = make_osck_any<OSC>(lp.osc_kind, lp.sr / r.pitch);
+    float xc = 0.0f;                         // one-pole coefficient exp(-2 pi f / sr), filters.rs:21
     FiltCoef fc; fc.alpha = fc.beta = fc.gamma = 0.0f;
     if (TEV && in_range) {
         ev_idx = p.voice_ev_head[vi];
@@ -1011,7 +1075,7 @@ __global__ void __launch_bounds__(1024) s2r_render_dspf_kernel(const S2rRenderPa
             const float *src = tile + f * (VW + 1) + grp * 16u;
             float acc = src[0];
 #pragma unroll
-            for (int k = 1; k < 16; ++k) acc += src[k];
+            for (int q = 1; q < 16; ++q) acc += src[q];
             sW[(buf * n_groups + wave * GW + grp) * kSuper + f_base + f] = acc;
         }
     };
@@ -1024,12 +1088,13 @@ __global__ void __launch_bounds__(1024) s2r_render_dspf_kernel(const S2rRenderPa
                 r.offset = 0u - fpos;
                 r.release_u = 0u;
                 r.released = (e.flags & S2R_EV_RELEASE) != 0u;
-                r.phase = 0.0f;
-                mod_key = 0xffffffffu;                               // the oscillator constants depend on the pitch
+                r.phase = 0.0f; r.last = 0.0f;
+                mod_key = 0xffffffffu;                           // the oscillator constants depend on the pitch
                 f2.x1 = f2.x2 = f2.y1 = f2.y2 = 0.0f;
                 seed_now = e.seed;
                 r.seed_rot = (e.seed << 5) | (e.seed >> 27);
-                live = true; ev_restart = true;
+                if (BANK) { program = e.program; lp = lane_patch_from_bank(p.bank, p.bank_size, program, p.sr); }
+                live = true;
             } else if ((e.flags & S2R_EV_RELEASE) && live && !r.released) {   // synth.rs:74-75
                 r.released = true;
                 r.release_u = r.offset + fpos;
@@ -1038,9 +1103,7 @@ __global__ void __launch_bounds__(1024) s2r_render_dspf_kernel(const S2rRenderPa
             ev_idx = e.next;
             ev_frame = ev_idx >= 0 ? p.tev[ev_idx].frame : 0xffffffffu;
         }
-        const float rf = r.released ? (float)r.release_u : 4294967296.0f;
-        r.ro_a = __builtin_fmaxf(rf, p.amp.sus_off); r.end_a = r.ro_a + p.amp.R;
-        r.ro_m = __builtin_fmaxf(rf, p.mod.sus_off); r.end_m = r.ro_m + p.mod.R;
+        set_release_thresholds();
     };
 
     for (uint32_t sc0 = 0; sc0 < p.frames; sc0 += kSuper) {
@@ -1052,24 +1115,25 @@ __global__ void __launch_bounds__(1024) s2r_render_dspf_kernel(const S2rRenderPa
                 for (uint32_t j = 0; j < kChunk; ++j) {          // one frame of sample_voice_x16, process.rs:306-379
                     const uint32_t oi = r.offset + sc0 + c16 + j;            // wrapping u32 add (process.rs:213-219)
                     const float t = (float)oi;
-                    const float amp = env_value(env_stage_at(p.amp, r.ro_a, r.end_a, t), t);     // process.rs:144
-                    const float mod = env_value(env_stage_at(p.mod, r.ro_m, r.end_m, t), t);     // process.rs:145
-                    // everything below `mod` that depends on it alone (and on the voice's pitch) is kept
-                    // from the previous frame while no lane's mod envelope value changed
+                    const float amp = env_value(env_stage_at(lp.amp, r.ro_a, r.end_a, t), t);    // process.rs:144
+                    const float mod = env_value(env_stage_at(lp.mod, r.ro_m, r.end_m, t), t);    // process.rs:145
                     if (__ballot(s2r_f2u(mod) != mod_key) != 0ull) {
-                        const float f_osc = s2r_pow2_sleef_core(mod * p.amt_osc) * r.pitch;      // process.rs:146-147,231-250
-                        const float f_lpf = s2r_pow2_sleef_core(mod * p.amt_lpf) * p.lpf_freq;   // process.rs:148-152
-                        k = make_osck<OSC>(p.sr / f_osc);                                        // units.rs:32-42
-                        fc = dsp_filter_coef(p.lpf_kind, p.lpf_damping, p.sr, f_lpf);
+                        const float f_osc = s2r_pow2_sleef_core(mod * lp.amt_osc) * r.pitch;     // process.rs:146-147,231-250
+                        const float f_lpf = s2r_pow2_sleef_core(mod * lp.amt_lpf) * lp.lpf_freq; // process.rs:148-152
+                        k = make_osck_any<OSC>(lp.osc_kind, lp.sr / f_osc);                      // units.rs:32-42
+                        if (lp.lpf_kind == S2R_FILT_ONEPOLE) xc = lpf_coeff<false, LanePatch>(lp, f_lpf, sT);
+                        else fc = dsp_filter_coef(lp.lpf_kind, lp.lpf_damping, lp.sr, f_lpf);
                         mod_key = s2r_f2u(mod);
                     }
-                    const float nz = hash_noise(r.seed_rot, t) + p.noise_level;                  // process.rs:347-356 (ADD)
+                    const float nz = hash_noise(r.seed_rot, t) + lp.noise_level;                 // process.rs:347-356 (ADD)
                     const float ph = r.phase;                                                    // oscillators.rs:391-400
                     r.phase = s2r_fmod1(ph + k.inv_period);
                     const float off = __builtin_fmaf(k.period, ph, 0.0f);
-                    const float osc = osc_value<OSC>(k, off, sSin);
-                    const float smp = (osc + p.osc_gain) + nz;                                   // process.rs:342-345 (ADD), :358
-                    const float y = dsp_filter_apply(p.lpf_kind, fc, smp, f2);
+                    const float osc = osc_value_any<OSC>(lp.osc_kind, k, off, sSin);
+                    const float smp = (osc + lp.osc_gain) + nz;                                  // process.rs:342-345 (ADD), :358
+                    float y;
+                    if (lp.lpf_kind == S2R_FILT_ONEPOLE) y = lpf_apply(xc, smp, r.last);         // process.rs:363-371
+                    else y = dsp_filter_apply(lp.lpf_kind, fc, smp, f2);
                     const float out = live ? y * amp : 0.0f;                                     // process.rs:373-376
                     if (PV && in_range) p.per_voice[pv_base + sc0 + c16 + j] = out;
                     tile[j * (VW + 1) + lane] = out;
@@ -1079,7 +1143,9 @@ __global__ void __launch_bounds__(1024) s2r_render_dspf_kernel(const S2rRenderPa
             if (n_x16 < n_sc) {                                  // scalar tail (< 16 frames)
                 if (TEV) apply_events_at(sc0 + n_x16);
                 for (uint32_t i = n_x16; i < n_sc; ++i) {
-                    float out = frame_sisd<OSC, true>(p, r, r.offset + sc0 + i, sT, sSin, &f2);
+                    float out;
+                    if (lp.lpf_kind == S2R_FILT_ONEPOLE) out = frame_sisd<OSC, false, LanePatch>(lp, r, r.offset + sc0 + i, sT, sSin, nullptr);
+                    else out = frame_sisd<OSC, true, LanePatch>(lp, r, r.offset + sc0 + i, sT, sSin, &f2);
                     out = live ? out : 0.0f;
                     if (PV && in_range) p.per_voice[pv_base + sc0 + i] = out;
                     tile[(i - n_x16) * (VW + 1) + lane] = out;
@@ -1104,13 +1170,14 @@ __global__ void __launch_bounds__(1024) s2r_render_dspf_kernel(const S2rRenderPa
         const uint32_t o = r.offset;
         p.v.offset[vi] = (!ev_dirty && o > 0xffffffffu - p.frames) ? 0xffffffffu : o + p.frames;   // synth.rs:197
         p.v.phase[vi] = r.phase;
+        p.v.lpf_last[vi] = r.last;
         p.v.fx1[vi] = f2.x1; p.v.fx2[vi] = f2.x2; p.v.fy1[vi] = f2.y1; p.v.fy2[vi] = f2.y2;
         if (ev_dirty) {
             p.v.pitch[vi] = r.pitch;
             p.v.release[vi] = r.release_u;
             p.v.flags[vi] = S2R_VF_STARTED | (r.released ? S2R_VF_RELEASED : 0u);
             p.v.seed[vi] = seed_now;
-            if (ev_restart) p.v.lpf_last[vi] = 0.0f;             // st::Layer::default()
+            if (BANK) p.v.program[vi] = program;
         }
     }
 }
@@ -1194,6 +1261,7 @@ __global__ void s2r_events_kernel(const S2rVoiceArrays v, const S2rVoiceEvent *e
         v.lpf_last[vi] = 0.0f;
         v.fx1[vi] = 0.0f; v.fx2[vi] = 0.0f; v.fy1[vi] = 0.0f; v.fy2[vi] = 0.0f;
         v.seed[vi] = e.seed;
+        v.program[vi] = e.flags >> S2R_EV_PROGRAM_SHIFT;
     } else if (e.flags & S2R_EV_RELEASE) {                       // synth.rs:74-75
         const uint32_t fl = v.flags[vi];
         if ((fl & S2R_VF_STARTED) && !(fl & S2R_VF_RELEASED)) {
@@ -1229,20 +1297,20 @@ hipError_t launch_l(const S2rRenderParams &p0, uint32_t block_voices, uint32_t l
     return hipGetLastError();
 }
 
-template <int OSC>
-hipError_t launch_dspf(const S2rRenderParams &p0, uint32_t block_voices, hipStream_t stream) {
+template <int OSC, bool BANK>
+hipError_t launch_general(const S2rRenderParams &p0, uint32_t block_voices, hipStream_t stream) {
     S2rRenderParams p = p0;
     const uint32_t grid = (p.n_voices + block_voices - 1) / block_voices;
     const uint32_t n_waves = block_voices / 64, n_groups = n_waves * 4;
     p.super_frames = n_groups <= 16 ? kSuperMax : 64u;
     const size_t lds = sizeof(float) * ((size_t)2 * n_groups * p.super_frames + (size_t)n_waves * kChunk * 65);
-    hipLaunchKernelGGL((s2r_render_dspf_kernel<OSC>), dim3(grid), dim3(block_voices), lds, stream, p);
+    hipLaunchKernelGGL((s2r_render_general_kernel<OSC, BANK>), dim3(grid), dim3(block_voices), lds, stream, p);
     return hipGetLastError();
 }
 
 template <int OSC>
 hipError_t launch_osc(const S2rRenderParams &p, uint32_t block_voices, uint32_t lanes, hipStream_t stream) {
-    if (p.lpf_kind != S2R_FILT_ONEPOLE) return launch_dspf<OSC>(p, block_voices, stream);
+    if (p.lpf_kind != S2R_FILT_ONEPOLE) return launch_general<OSC, false>(p, block_voices, stream);
     // pow(2, mod * amount) == 1 exactly iff amount is +-0 (mod is always finite and >= 0)
     const bool fm = p.amt_osc != 0.0f;
     const int mode = p.per_voice != nullptr ? 1 : (p.tev != nullptr ? 2 : 0);
@@ -1269,6 +1337,7 @@ hipError_t s2r_launch_render(const S2rRenderParams &p, uint32_t block_voices, ui
     if (p.n_voices == 0 || p.frames == 0) return hipSuccess;
     if (block_voices < 64 || block_voices > 1024 || (block_voices & 63u)) return hipErrorInvalidValue;
     if (block_voices * lanes_per_voice > 1024 || (lanes_per_voice == 2 && block_voices > 256)) return hipErrorInvalidValue;
+    if (p.bank_size > 1) return launch_general<S2R_OSC_ANY, true>(p, block_voices, stream);
     switch (p.osc_kind) {
     case S2R_OSC_SQUARE: return launch_osc<S2R_OSC_SQUARE>(p, block_voices, lanes_per_voice, stream);
     case S2R_OSC_SAW: return launch_osc<S2R_OSC_SAW>(p, block_voices, lanes_per_voice, stream);

@@ -51,6 +51,9 @@ class ShardedSynth:
     def note_off(self, note):
         self.renderer.note_off(note)
 
+    def set_patch_bank(self, patches):
+        self.renderer.set_patch_bank(patches)
+
     def load_patch(self, text):
         self.renderer.load_patch(text)
 

@@ -64,14 +64,14 @@ class Config(C.Structure):
 
 
 class VoiceState(C.Structure):
-    _fields_ = [("note", C.c_uint8), ("started", C.c_uint8), ("released", C.c_uint8), ("_pad", C.c_uint8),
+    _fields_ = [("note", C.c_uint8), ("started", C.c_uint8), ("released", C.c_uint8), ("program", C.c_uint8),
                 ("current_frame_offset", C.c_uint32), ("release_frame_offset", C.c_uint32),
                 ("pitch_hz", C.c_float), ("phase_accum", C.c_float), ("lpf_last", C.c_float),
                 ("noise_seed", C.c_uint32), ("velocity", C.c_float),
                 ("filt_x1", C.c_float), ("filt_x2", C.c_float), ("filt_y1", C.c_float), ("filt_y2", C.c_float)]
 
 
-VOICE_STATE_DTYPE = np.dtype([("note", np.uint8), ("started", np.uint8), ("released", np.uint8), ("_pad", np.uint8),
+VOICE_STATE_DTYPE = np.dtype([("note", np.uint8), ("started", np.uint8), ("released", np.uint8), ("program", np.uint8),
                               ("current_frame_offset", np.uint32), ("release_frame_offset", np.uint32),
                               ("pitch_hz", np.float32), ("phase_accum", np.float32), ("lpf_last", np.float32),
                               ("noise_seed", np.uint32), ("velocity", np.float32),
@@ -127,6 +127,9 @@ def load_library():
         "s2r_load_patch": (C.c_int, [H, C.c_char_p, C.c_size_t]),
         "s2r_set_patch": (C.c_int, [H, C.POINTER(Patch)]),
         "s2r_get_patch": (C.c_int, [H, C.POINTER(Patch)]),
+        "s2r_set_patch_bank": (C.c_int, [H, C.POINTER(Patch), C.c_uint32]),
+        "s2r_patch_bank_size": (C.c_uint32, [H]),
+        "s2r_program_change": (C.c_int, [H, C.c_uint32]),
         "s2r_default_patch": (None, [C.POINTER(Patch)]),
         "s2r_note_on": (C.c_int, [H, C.c_uint8, C.c_float]),
         "s2r_note_on_ex": (C.c_int, [H, C.c_uint8, C.c_float, C.POINTER(C.c_uint32)]),
@@ -268,6 +271,18 @@ class Synth:
 
     def set_patch(self, patch):
         self._check(self.L.s2r_set_patch(self.h, C.byref(patch)))
+
+    def set_patch_bank(self, patches):
+        """1..256 patches; the current program picks the one a note_on gives its voice"""
+        arr = (Patch * len(patches))(*patches)
+        self._check(self.L.s2r_set_patch_bank(self.h, arr, len(patches)))
+
+    @property
+    def patch_bank_size(self):
+        return self.L.s2r_patch_bank_size(self.h)
+
+    def program_change(self, program):
+        self._check(self.L.s2r_program_change(self.h, int(program)))
 
     def get_patch(self):
         p = Patch()

@@ -74,6 +74,14 @@ class Pair:
         self.cpu.note_off(note)
         self.gpu.note_off(note)
 
+    def set_bank(self, patches):
+        self.gpu.set_patch_bank(patches)
+        self.cpu.set_bank([oracle_cfg_from_patch(p) for p in patches])
+
+    def program_change(self, program):
+        self.gpu.program_change(program)
+        self.cpu.program_change(program)
+
     def render_voices(self, frames, sr=48000):
         return self.gpu.render_voices(frames, sr), self.cpu.render_voices(frames, sr, threads=self.threads)
 

@@ -588,3 +588,112 @@ def test_dsp_filters_full_size_linearity_free_properties():
         pv = b.render_voices(256)
         assert_bits_equal(pv[:2048], ora.render_voices(256, threads=8), "first 2048 voices, buffer %d" % k)
         assert_bits_equal(mix, s2o.mix_tree(pv, a.block_voices, 1), "mix vs tree over GPU rows, buffer %d" % k)
+
+
+# ---------------------------------------------------------------------------------------------
+# patch bank: per-voice patches selected by program change
+# ---------------------------------------------------------------------------------------------
+def _bank():
+    b = []
+    for i, (osc, filt, fm) in enumerate([(s2.OSC_SAW, s2.FILT_ONEPOLE, 0.0), (s2.OSC_SQUARE, s2.FILT_LP2, 1.5),
+                                         (s2.OSC_TRIANGLE, s2.FILT_HP1, 0.0), (s2.OSC_SINE, s2.FILT_BP2, -2.0),
+                                         (s2.OSC_SINE, s2.FILT_ONEPOLE, 3.0), (s2.OSC_SAW, s2.FILT_HP2, 0.0),
+                                         (s2.OSC_SQUARE, s2.FILT_LP1, 0.5)]):
+        p = make_patch(osc_kind=osc, lpf_kind=filt, mod_env_to_osc_freq=fm, noise=0.05 * i, osc_gain=1.0 - 0.1 * i,
+                       lpf_freq=300.0 + 250.0 * i, mod_env_to_lpf_freq=4.0 - i, lpf_damping=0.5 + 0.2 * i, lpf_q=1.0 + 0.5 * i)
+        p.amp_env.attack_ms = 3.0 + 10.0 * i
+        p.amp_env.release_ms = 20.0 + 30.0 * i
+        p.mod_env.attack_ms = 2.0 * i
+        p.mod_env.decay_ms = 30.0 + 20.0 * i
+        p.mod_env.sustain = 0.1 * i
+        p.mod_env.release_ms = 15.0 * i
+        b.append(p)
+    return b
+
+
+@pytest.mark.parametrize("frames", [512, 1000])
+def test_patch_bank_per_voice(frames):
+    """every voice renders with the patch its note_on's program selected: all oscillator kinds and
+    all six filters side by side in one wavefront, with stealing, releases and ragged fills"""
+    bank = _bank()
+    pr = Pair(200, max_frames=1024)
+    pr.set_bank(bank)
+    rng = np.random.RandomState(11)
+    held = []
+    for k in range(6):
+        for _ in range(60):
+            pr.program_change(int(rng.randint(len(bank))))
+            n = int(rng.randint(30, 100)); pr.note_on(n); held.append(n)
+        for _ in range(15):
+            pr.note_off(held.pop(int(rng.randint(len(held)))))
+        g, o = pr.render_voices(frames)
+        assert_bits_equal(g, o, "bank, %d frames, block %d" % (frames, k))
+    st = pr.gpu.export_state()
+    for v in range(200):
+        if pr.cpu.voice(v).has_current:
+            assert st["program"][v] == pr.cpu.voice(v).program
+
+
+def test_patch_bank_mix_checkpoint_and_shrinking_bank():
+    bank = _bank()
+    pr = Pair(300, block_voices=128, max_frames=512)
+    pr.set_bank(bank)
+    for v in range(260):
+        pr.program_change(v % len(bank))
+        pr.note_on(30 + (v * 5) % 70)
+    g, o, pv = pr.sample(512)
+    assert_bits_equal(g, o, "bank mix")
+    pr.gpu.import_state(pr.gpu.export_state())               # the program index travels with the checkpoint
+    g, o, pv = pr.sample(500)
+    assert_bits_equal(g, o, "bank mix after checkpoint round trip")
+    pr.set_bank(bank[:3])                                    # voices started with programs 3..6 fall back to patch 0
+    g, o, pv = pr.sample(512)
+    assert_bits_equal(g, o, "bank shrunk to 3")
+    pr.set_bank(bank[:1])                                    # bank of one: back on the tuned single-patch kernel
+    g, o, pv = pr.sample(512)
+    assert_bits_equal(g, o, "bank of one")
+    with pytest.raises(s2.S2rError):
+        pr.gpu.program_change(1)
+
+
+def test_patch_bank_timed_events_with_program_changes():
+    """program changes inside a timed event batch: each timed note_on carries the program current at
+    its place in the stream"""
+    bank = _bank()
+    voices = 64
+    pr = Pair(voices, max_frames=1024)
+    pr.set_bank(bank)
+    rng = np.random.RandomState(3)
+    held = []
+    for b in range(5):
+        frames = 1024 if b != 2 else 1000
+        n_ev = int(rng.randint(5, 50))
+        times = np.sort(rng.randint(0, (frames + 15) // 16, n_ev)) * 16
+        rows = []
+        for t in times:
+            if rng.randint(0, 2):
+                rows.append((2, int(rng.randint(len(bank))), int(t), 0.0))
+            on = (not held) or rng.randint(0, 3) > 0
+            if on:
+                note = int(rng.randint(40, 90)); held.append(note)
+            else:
+                note = held.pop(int(rng.randint(len(held))))
+            rows.append((1 if on else 0, note, int(t), 1.0))
+        ev = np.array(rows, dtype=s2.NOTE_EVENT_DTYPE)
+        pr.gpu.note_events(ev)
+        g = pr.gpu.sample(np.empty(frames, dtype=np.float32))
+        pv = np.zeros((voices, frames), dtype=np.float32)
+        k = 0
+        for c in range(0, frames, 16):
+            while k < len(ev) and ev["frame"][k] == c:
+                if ev["kind"][k] == 2:
+                    pr.cpu.program_change(int(ev["note"][k]))
+                elif ev["kind"][k] == 1:
+                    pr.cpu.note_on(int(ev["note"][k]))
+                else:
+                    pr.cpu.note_off(int(ev["note"][k]))
+                k += 1
+            n = min(16, frames - c)
+            pv[:, c:c + n] = pr.cpu.render_voices(n)
+        assert k == len(ev)
+        assert_bits_equal(g, s2o.mix_tree(pv, pr.block_voices, 1), "bank + timed events, buffer %d" % b)
