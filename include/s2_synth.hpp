@@ -52,6 +52,9 @@ class Synth {
     Synth(Synth &&o) noexcept : h_(o.h_) { o.h_ = nullptr; }
 
     void load_patch(const std::string &synth2_text) { check(s2r_load_patch(h_, synth2_text.data(), synth2_text.size())); }
+    // multi-timbral extension: a bank of patches, the current program picks the one a note_on uses
+    void set_patch_bank(const s2r_patch *patches, uint32_t n) { check(s2r_set_patch_bank(h_, patches, n)); }
+    void program_change(uint32_t program) { check(s2r_program_change(h_, program)); }
     void note_on(Note note, Velocity velocity) { check(s2r_note_on(h_, note.v, velocity.v.v)); }     // synth.rs:61-70
     void note_off(Note note) { check(s2r_note_off(h_, note.v)); }                                    // synth.rs:72-80
     // Synth::sample(&mut [f32], SampleRateKhz), synth.rs:154-169

@@ -59,6 +59,7 @@ pub mod ffi {
         pub fn s2r_create(cfg: *const S2rConfig, out: *mut *mut S2rSynth) -> c_int;
         pub fn s2r_destroy(s: *mut S2rSynth);
         pub fn s2r_load_patch(s: *mut S2rSynth, text: *const c_char, len: usize) -> c_int;
+        pub fn s2r_program_change(s: *mut S2rSynth, program: u32) -> c_int;
         pub fn s2r_note_on(s: *mut S2rSynth, note: u8, velocity: f32) -> c_int;
         pub fn s2r_note_off(s: *mut S2rSynth, note: u8) -> c_int;
         pub fn s2r_fill(s: *mut S2rSynth, mono_out: *mut f32, frames: usize, sample_rate_hz: u32) -> c_int;
@@ -130,6 +131,14 @@ pub mod synth {
                 fail(std::ptr::null(), rc);
             }
             Synth { handle }
+        }
+
+        /// Multi-timbral extension: the patch (bank index) the following note_ons use.
+        pub fn program_change(&mut self, program: u32) {
+            let rc = unsafe { ffi::s2r_program_change(self.handle, program) };
+            if rc != 0 {
+                fail(self.handle, rc);
+            }
         }
 
         /// example.synth2 text (the reference has no loader; an empty body is default_config())
