@@ -77,7 +77,10 @@ typedef enum {
     S2R_FILT_HP1 = 2,              /* dsp_filters.rs:60-80      FirstOrderHighPassFilter */
     S2R_FILT_LP2 = 3,              /* dsp_filters.rs:99-130     SecondOrderLowPassFilter */
     S2R_FILT_HP2 = 4,              /* dsp_filters.rs:149-180    SecondOrderHighPassFilter */
-    S2R_FILT_BP2 = 5               /* dsp_filters.rs:199-230    SecondOrderBandPassFilter (center = the cutoff) */
+    S2R_FILT_BP2 = 5,              /* dsp_filters.rs:199-230    SecondOrderBandPassFilter (center = the cutoff) */
+    /* build-defined (the reference only names an SVF, notes.md:63): trapezoidal state-variable
+     * filter at the modulated cutoff, resonance lpf_q (> 0); DESIGN.md 4.6 gives the op sequence */
+    S2R_FILT_SVF_LP = 6, S2R_FILT_SVF_BP = 7, S2R_FILT_SVF_HP = 8
 } s2r_filter_kind;
 
 typedef struct {

@@ -276,6 +276,26 @@ float s2o_dsp_filter_process(int kind, float *x1p, float *x2p, float *y1p, float
         *x1p = x; *y1p = y;
         return y;
     }
+    if (kind >= S2O_FILT_SVF_LP) {
+        /* BUILD-DEFINED (self-oracle): trapezoidal state-variable filter.  The
+         * definition is this sequence of separately rounded f32 operations; x1/x2 hold the two
+         * integrator states. */
+        float q = damping_factor;
+        float fc = fminf(cutoff_freq, 0.49f * sample_rate);     /* below Nyquist: g > 0, unconditionally stable */
+        float g = tanf(PI * fc / sample_rate);
+        float k = 1.0f / q;
+        float a1 = 1.0f / (1.0f + g * (g + k));
+        float a2 = g * a1;
+        float a3 = g * a2;
+        float v3 = x - x2;
+        float v1 = a1 * x1 + a2 * v3;
+        float v2 = x2 + a2 * x1 + a3 * v3;
+        *x1p = 2.0f * v1 - x1;
+        *x2p = 2.0f * v2 - x2;
+        if (kind == S2O_FILT_SVF_LP) return v2;
+        if (kind == S2O_FILT_SVF_BP) return v1;
+        return x - k * v1 - v2;
+    }
     if (kind == S2O_FILT_BP2) {                                  /* theta_center, quality_factor */
         float quality_factor = damping_factor;
         float tq = tanf(theta_cutoff / (2.0f * quality_factor));
@@ -303,7 +323,7 @@ float s2o_dsp_filter_process(int kind, float *x1p, float *x2p, float *y1p, float
 static float layer_filter(const s2o_layer_cfg *c, s2o_layer_state *st, uint32_t sr, float freq, float input) {
     if (c->lpf_kind == S2O_FILT_ONEPOLE) return s2o_lpf_process(&st->lpf_last, sr, freq, input);
     return s2o_dsp_filter_process(c->lpf_kind, &st->x1, &st->x2, &st->y1, &st->y2, sr, freq,
-                                  c->lpf_kind == S2O_FILT_BP2 ? c->lpf_q : c->lpf_damping, input);
+                                  c->lpf_kind >= S2O_FILT_BP2 ? c->lpf_q : c->lpf_damping, input);
 }
 
 /* ------------------------------------------------------------------ oscillators.rs */

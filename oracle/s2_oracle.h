@@ -51,7 +51,10 @@ typedef struct {
     float lpf_q;                 /* SecondOrderBandPassFilter.quality_factor, Unipolar<10> */
 } s2o_layer_cfg;
 
-enum { S2O_FILT_ONEPOLE = 0, S2O_FILT_LP1 = 1, S2O_FILT_HP1 = 2, S2O_FILT_LP2 = 3, S2O_FILT_HP2 = 4, S2O_FILT_BP2 = 5 };
+enum { S2O_FILT_ONEPOLE = 0, S2O_FILT_LP1 = 1, S2O_FILT_HP1 = 2, S2O_FILT_LP2 = 3, S2O_FILT_HP2 = 4, S2O_FILT_BP2 = 5,
+       /* build-defined state-variable filter (no counterpart in the reference, notes.md:63 only names
+        * it): trapezoidal SVF, low / band / high outputs; `shape` = lpf_q */
+       S2O_FILT_SVF_LP = 6, S2O_FILT_SVF_BP = 7, S2O_FILT_SVF_HP = 8 };
 
 /* state.rs:10-21, oscillators.rs:402-406, filters.rs:5-7 */
 typedef struct {

@@ -228,6 +228,8 @@ int check_fill(s2r_synth *s, size_t frames, uint32_t sample_rate) {
         if (pt.lpf_kind == S2R_FILT_BP2 &&
             !(pt.lpf_q > 0.0f && num_max / (double)sample_rate / (2.0 * (double)pt.lpf_q) < 3.4028234e38))
             return set_err(s, S2R_ERR_PATCH_RANGE, "patch %zu: lpf.kind bp2 needs lpf.q > 0 (tan(theta / (2 q)) must stay finite)", k);
+        if (pt.lpf_kind >= S2R_FILT_SVF_LP && !(pt.lpf_q >= 0x1p-100f))
+            return set_err(s, S2R_ERR_PATCH_RANGE, "patch %zu: the state-variable filter needs lpf.q > 0 (k = 1 / q)", k);
     }
     return S2R_OK;
 }
@@ -241,7 +243,7 @@ S2rRenderParams make_params(s2r_synth *s, size_t frames, uint32_t sample_rate) {
     p.amt_osc = s->bank[0].mod_env_to_osc_freq;
     p.amt_lpf = s->bank[0].mod_env_to_lpf_freq;
     p.lpf_kind = s->bank[0].lpf_kind;
-    p.lpf_damping = s->bank[0].lpf_kind == S2R_FILT_BP2 ? s->bank[0].lpf_q : s->bank[0].lpf_damping;
+    p.lpf_damping = s->bank[0].lpf_kind >= S2R_FILT_BP2 ? s->bank[0].lpf_q : s->bank[0].lpf_damping;
     p.amp = resolve_env(s->bank[0].amp_env, sample_rate);
     p.mod = resolve_env(s->bank[0].mod_env, sample_rate);
     p.sr = (float)sample_rate;
@@ -284,7 +286,7 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
             S2rBankEntry &e = host[k];
             e.osc_kind = pt.osc_kind; e.osc_gain = pt.osc_gain; e.noise_level = pt.noise; e.lpf_freq = pt.lpf_freq;
             e.amt_osc = pt.mod_env_to_osc_freq; e.amt_lpf = pt.mod_env_to_lpf_freq; e.lpf_kind = pt.lpf_kind;
-            e.lpf_shape = pt.lpf_kind == S2R_FILT_BP2 ? pt.lpf_q : pt.lpf_damping;
+            e.lpf_shape = pt.lpf_kind >= S2R_FILT_BP2 ? pt.lpf_q : pt.lpf_damping;
             e.amp = resolve_env(pt.amp_env, sample_rate);
             e.mod = resolve_env(pt.mod_env, sample_rate);
         }

@@ -455,12 +455,24 @@ struct Filt2 { float x1, x2, y1, y2; };
 // dsp_filters.rs:25-45 (LP1), :60-80 (HP1), :99-130 (LP2), :149-180 (HP2), :199-230 (BP2): one step at cutoff f.
 // That file has no `fma` switch: every operation is rounded separately, in Rust's evaluation
 // order; sin/cos are the libm routines (s2r_sinf/s2r_cosf, bit-exact for every finite theta).
-struct FiltCoef { float alpha, beta, gamma; };
+struct FiltCoef { float alpha, beta, gamma, k; };
 
 __device__ __forceinline__ FiltCoef dsp_filter_coef(int kind, float damping, float sr, float cutoff) {
     const float theta = 2.0f * 3.14159274101257324f * cutoff / sr;           // 2.0 * PI * cutoff_freq / sample_rate
-    const float cs = s2r_cosf(theta);
     FiltCoef c;
+    c.k = 0.0f;
+    if (kind >= S2R_FILT_SVF_LP) {
+        // build-defined trapezoidal SVF (oracle/s2_oracle.c s2o_dsp_filter_process):
+        // alpha, beta, gamma hold a1, a2, a3; damping == q
+        const float fcl = __builtin_fminf(cutoff, 0.49f * sr);  // below Nyquist: g > 0, unconditionally stable
+        const float g = s2r_tanf(3.14159274101257324f * fcl / sr);
+        c.k = 1.0f / damping;
+        c.alpha = 1.0f / (1.0f + g * (g + c.k));
+        c.beta = g * c.alpha;
+        c.gamma = g * c.beta;
+        return c;
+    }
+    const float cs = s2r_cosf(theta);
     if (kind == S2R_FILT_BP2) {                                  // dsp_filters.rs:204-209; damping == quality_factor
         const float tq = s2r_tanf(theta / (2.0f * damping));
         c.beta = 0.5f * ((1.0f - tq) / (1.0f + tq));
@@ -484,6 +496,14 @@ __device__ __forceinline__ FiltCoef dsp_filter_coef(int kind, float damping, flo
 
 __device__ __forceinline__ float dsp_filter_apply(int kind, const FiltCoef &c, float x, Filt2 &f) {
     float y;
+    if (kind >= S2R_FILT_SVF_LP) {                               // x1, x2: the two integrator states
+        const float v3 = x - f.x2;
+        const float v1 = c.alpha * f.x1 + c.beta * v3;
+        const float v2 = f.x2 + c.beta * f.x1 + c.gamma * v3;
+        f.x1 = 2.0f * v1 - f.x1;
+        f.x2 = 2.0f * v2 - f.x2;
+        return kind == S2R_FILT_SVF_LP ? v2 : kind == S2R_FILT_SVF_BP ? v1 : x - c.k * v1 - v2;
+    }
     if (kind == S2R_FILT_LP1 || kind == S2R_FILT_HP1) {
         const float xs = (kind == S2R_FILT_LP1) ? x + f.x1 : x - f.x1;
         y = c.alpha * xs + c.gamma * f.y1;
@@ -1056,7 +1076,7 @@ __global__ void __launch_bounds__(1024) s2r_render_general_kernel(const S2rRende
     uint32_t mod_key = 0xffffffffu;          // bits of the mod value `k`, `xc`, `fc` were computed for (a NaN: never equal)
     OscK k = make_osck_any<OSC>(lp.osc_kind, lp.sr / r.pitch);
     float xc = 0.0f;                         // one-pole coefficient exp(-2 pi f / sr), filters.rs:21
-    FiltCoef fc; fc.alpha = fc.beta = fc.gamma = 0.0f;
+    FiltCoef fc; fc.alpha = fc.beta = fc.gamma = fc.k = 0.0f;
     if (TEV && in_range) {
         ev_idx = p.voice_ev_head[vi];
         if (ev_idx >= 0) { ev_frame = p.tev[ev_idx].frame; p.voice_ev_head[vi] = -1; }

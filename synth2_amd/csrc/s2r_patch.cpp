@@ -9,7 +9,7 @@
 //           | mod_env.attack | mod_env.decay | mod_env.sustain | mod_env.release
 //           | mod_env_to_osc_freq | mod_env_to_lpf_freq
 //   VALUE  := number | square | saw | triangle | sine        (kind names only for osc.kind)
-//           | onepole | lp1 | hp1 | lp2 | hp2 | bp2           (kind names only for lpf.kind)
+//           | onepole | lp1 | hp1 | lp2 | hp2 | bp2 | svf_lp | svf_bp | svf_hp   (only for lpf.kind)
 //
 // Units follow static_config.rs: *.attack/decay/release in ms (Ms), lpf.freq in Hz,
 // gains/levels/sustain Unipolar<1>, the two modulation amounts Bipolar<10>.
@@ -92,7 +92,7 @@ int s2r_validate_patch(const s2r_patch *p, std::string *err) {
     }
     if (!in_range(p->mod_env_to_osc_freq, -10.0f, 10.0f)) return fail(err, S2R_ERR_PATCH_RANGE, "mod_env_to_osc_freq outside Bipolar<10> [-10,10]");
     if (!in_range(p->mod_env_to_lpf_freq, -10.0f, 10.0f)) return fail(err, S2R_ERR_PATCH_RANGE, "mod_env_to_lpf_freq outside Bipolar<10> [-10,10]");
-    if (p->lpf_kind < S2R_FILT_ONEPOLE || p->lpf_kind > S2R_FILT_BP2) return fail(err, S2R_ERR_PATCH_RANGE, "lpf.kind out of range");
+    if (p->lpf_kind < S2R_FILT_ONEPOLE || p->lpf_kind > S2R_FILT_SVF_HP) return fail(err, S2R_ERR_PATCH_RANGE, "lpf.kind out of range");
     if (!in_range(p->lpf_damping, 0.0f, 10.0f)) return fail(err, S2R_ERR_PATCH_RANGE, "lpf.damping outside Unipolar<10> [0,10]");
     if (!in_range(p->lpf_q, 0.0f, 10.0f)) return fail(err, S2R_ERR_PATCH_RANGE, "lpf.q outside Unipolar<10> [0,10]");
     return S2R_OK;
@@ -133,6 +133,9 @@ int s2r_parse_patch(const char *text, size_t len, s2r_patch *out, std::string *n
                 else if (kind == "lp2") p.lpf_kind = S2R_FILT_LP2;
                 else if (kind == "hp2") p.lpf_kind = S2R_FILT_HP2;
                 else if (kind == "bp2") p.lpf_kind = S2R_FILT_BP2;
+                else if (kind == "svf_lp") p.lpf_kind = S2R_FILT_SVF_LP;
+                else if (kind == "svf_bp") p.lpf_kind = S2R_FILT_SVF_BP;
+                else if (kind == "svf_hp") p.lpf_kind = S2R_FILT_SVF_HP;
                 else return fail(err, S2R_ERR_PATCH_SYNTAX, at("unknown filter kind " + kind));
             } else if (lx.number(&num)) {
                 p.lpf_kind = (int32_t)num;

@@ -55,6 +55,7 @@ class Patch(C.Structure):
 
 # s2r_filter_kind: filters.rs one-pole (the reference's live path) and dsp_filters.rs:25-180
 FILT_ONEPOLE, FILT_LP1, FILT_HP1, FILT_LP2, FILT_HP2, FILT_BP2 = 0, 1, 2, 3, 4, 5
+FILT_SVF_LP, FILT_SVF_BP, FILT_SVF_HP = 6, 7, 8      # build-defined state-variable filter
 
 
 class Config(C.Structure):

@@ -428,7 +428,8 @@ def test_timed_event_errors():
 # ---------------------------------------------------------------------------------------------
 # dsp_filters.rs filters as the layer's filter (lpf.kind != onepole)
 # ---------------------------------------------------------------------------------------------
-DSP_KINDS = [s2.FILT_LP1, s2.FILT_HP1, s2.FILT_LP2, s2.FILT_HP2, s2.FILT_BP2]
+DSP_KINDS = [s2.FILT_LP1, s2.FILT_HP1, s2.FILT_LP2, s2.FILT_HP2, s2.FILT_BP2,
+             s2.FILT_SVF_LP, s2.FILT_SVF_BP, s2.FILT_SVF_HP]
 
 
 @pytest.mark.parametrize("kind", DSP_KINDS)
@@ -491,7 +492,22 @@ def test_dsp_filter_cutoff_range_and_damping_extremes():
             with np.errstate(all="ignore"):
                 g, o = pr.render_voices(256)
             assert_bits_equal(g, o, "q %g block %d" % (q, k))
+    for kind in (s2.FILT_SVF_LP, s2.FILT_SVF_HP):   # SVF: tan(pi f / sr) far past Nyquist, extreme resonance
+        for q in (0.05, 10.0):
+            patch = make_patch(lpf_kind=kind, lpf_freq=20000.0, mod_env_to_lpf_freq=10.0, lpf_q=q)
+            patch.mod_env.decay_ms = 20.0
+            pr = Pair(16, patch)
+            for v in range(12):
+                pr.note_on(36 + 5 * v)
+            for k in range(3):
+                with np.errstate(all="ignore"):
+                    g, o = pr.render_voices(256)
+                assert_bits_equal(g, o, "svf %d q %g block %d" % (kind, q, k))
     s = s2.Synth(8, max_frames=256)
+    s.set_patch(make_patch(lpf_kind=s2.FILT_SVF_BP, lpf_q=0.0))
+    with pytest.raises(s2.S2rError) as e:
+        s.sample(np.empty(256, dtype=np.float32), 48000)
+    assert e.value.status == -5
     s.set_patch(make_patch(lpf_kind=s2.FILT_BP2, lpf_q=0.0))
     with pytest.raises(s2.S2rError) as e:
         s.sample(np.empty(256, dtype=np.float32), 48000)
@@ -528,7 +544,7 @@ def test_dsp_filter_state_survives_patch_switches_and_checkpoints():
         assert_bits_equal(g, o, "lp2 resumed %d" % k)
 
 
-@pytest.mark.parametrize("kind", [s2.FILT_LP2, s2.FILT_HP1, s2.FILT_BP2])
+@pytest.mark.parametrize("kind", [s2.FILT_LP2, s2.FILT_HP1, s2.FILT_BP2, s2.FILT_SVF_LP])
 def test_dsp_filters_with_timed_events(kind):
     """timed events (16-frame boundaries inside one launch) under the dsp filters"""
     voices = 100
@@ -697,3 +713,21 @@ def test_patch_bank_timed_events_with_program_changes():
             pv[:, c:c + n] = pr.cpu.render_voices(n)
         assert k == len(ev)
         assert_bits_equal(g, s2o.mix_tree(pv, pr.block_voices, 1), "bank + timed events, buffer %d" % b)
+
+
+@pytest.mark.parametrize("kind", [s2.FILT_SVF_LP, s2.FILT_LP2, s2.FILT_ONEPOLE])
+def test_config4_shape_192khz(kind):
+    """BASELINE config [4]'s shape (4x oversampled rate, resonant filter) as a parity case: the path
+    at sample_rate = 192 000 — every rate-dependent constant (Ms::as_samples, periods, filter
+    coefficients) changes.  Decimation back to 48 kHz is the caller's (out of scope)."""
+    patch = make_patch(osc_kind=s2.OSC_TRIANGLE, lpf_kind=kind, lpf_freq=2500.0, mod_env_to_lpf_freq=3.0, lpf_q=2.0,
+                       lpf_damping=0.5, noise=0.02)
+    pr = Pair(512, patch, max_frames=1024)
+    for v in range(400):
+        pr.note_on(24 + (v * 7) % 96)
+    for k in range(4):
+        g, o, pv = pr.sample(1024, sr=192000)
+        assert_bits_equal(g, o, "192 kHz, filter %d, buffer %d" % (kind, k))
+        if k == 1:
+            for n in range(24, 120, 5):
+                pr.note_off(n)

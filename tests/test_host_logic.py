@@ -78,7 +78,8 @@ def test_patch_full_grammar():
     d = s2.parse_patch("synth x { }")
     assert d.lpf_kind == s2.FILT_ONEPOLE and d.lpf_damping == np.float32(2.0 ** 0.5)
     assert d.lpf_q == 3.0
-    for kind, code in (("onepole", 0), ("lp1", 1), ("hp1", 2), ("lp2", 3), ("hp2", 4), ("bp2", 5)):
+    for kind, code in (("onepole", 0), ("lp1", 1), ("hp1", 2), ("lp2", 3), ("hp2", 4), ("bp2", 5),
+                       ("svf_lp", 6), ("svf_bp", 7), ("svf_hp", 8)):
         q = s2.parse_patch("synth x { lpf.kind = %s; lpf.damping = 0.25; lpf.q = 1.5 }" % kind)
         assert q.lpf_kind == code and q.lpf_damping == 0.25 and q.lpf_q == 1.5
 
@@ -96,7 +97,7 @@ def test_patch_full_grammar():
     ("synth x { lpf.freq = nan }", -5),
     ("synth x { osc.kind = 7 }", -5),
     ("synth x { lpf.kind = bandpass }", -4),
-    ("synth x { lpf.kind = 6 }", -5),
+    ("synth x { lpf.kind = 9 }", -5),
     ("synth x { lpf.q = 11 }", -5),                   # Unipolar<10>, dsp_filters.rs:195
     ("synth x { lpf.damping = 10.5 }", -5),           # Unipolar<10>, dsp_filters.rs:96
 ])

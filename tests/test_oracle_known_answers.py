@@ -285,7 +285,7 @@ def test_dsp_filters_restatement_properties():
     L = s2o.lib()
     L.s2o_dsp_filter_process.restype = C.c_float
     L.s2o_dsp_filter_process.argtypes = [C.c_int] + [C.POINTER(C.c_float)] * 4 + [C.c_uint32, C.c_float, C.c_float, C.c_float]
-    for kind, dc in ((1, 1.0), (2, 0.0), (3, 1.0), (4, 0.0), (5, 0.0)):
+    for kind, dc in ((1, 1.0), (2, 0.0), (3, 1.0), (4, 0.0), (5, 0.0), (6, 1.0), (7, 0.0), (8, 0.0)):
         st = [C.c_float(0.0) for _ in range(4)]
         y = 0.0
         for i in range(4000):
