@@ -14,7 +14,12 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libs2r.so")
 SOURCES = ["s2r_kernels.hip", "s2r_host.cpp", "s2r_patch.cpp"]
 HEADERS = ["s2r_device.h", "s2r_math.h", "s2r_patch.h", "s2r_voices.h"]
+# -amdgpu-sched-strategy=max-ilp: the render kernels run one wavefront per SIMD (64 k voices =
+# 1024 waves), so nothing hides a dependent instruction's latency except independent work of the
+# same wave; the default (occupancy-driven) scheduler lines the recurrences up back to back
+# (0.086 -> measured below).  Scheduling only: the arithmetic is untouched.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+         "-mllvm", "-amdgpu-sched-strategy=max-ilp",
          "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
 

@@ -11,6 +11,7 @@
 // /root/reference/components/s2_lib/src/); this file must be compiled with
 // -ffp-contract=off and without fast-math.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "s2r_device.h"
 #include "s2r_math.h"
 
@@ -45,6 +46,7 @@ constexpr int kP = 4;              // frames whose closed-form work one lane car
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef int i4 __attribute__((ext_vector_type(4)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef unsigned short us4 __attribute__((ext_vector_type(4)));
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long ul4 __attribute__((ext_vector_type(4)));
 
@@ -212,8 +214,10 @@ __device__ float adsr_scalar(const S2rEnv &e, float t, float release_offset) {
 // hashnoise.rs:33-51 (x16) == :14-27 (scalar): stateless noise at one frame offset
 __device__ __forceinline__ float hash_noise(uint32_t seed_rot, float t) {
     const uint32_t off = s2r_f32_as_u32(t);                     // offset.cast::<u32>()
-    const uint32_t h = (seed_rot ^ off) * 0x9e3779b9u;          // hash_word_x16, :57-68
-    const float value = (float)(h & 0xffffu);                   // cast::<u16>() then ::<f32>()
+    // hash_word_x16, :57-68, then cast::<u16>(): the low 16 bits of (seed_rot ^ off) * 0x9e3779b9
+    // depend only on the low 16 bits of both factors
+    const uint16_t h = (uint16_t)((uint16_t)(seed_rot ^ off) * (uint16_t)0x79b9u);
+    const float value = (float)h;                               // cast::<f32>()
     // value / u16_max: integers 0..65535 are inside the exhaustively verified window
     const float q = s2r_div_const_nocheck(value, 65535.0f, 0x1.0001p-16f);
     return __builtin_fmaf(q, 2.0f, -1.0f);                      // (q * 2) is exact, then - 1
@@ -341,8 +345,10 @@ __device__ __forceinline__ OscK4 make_osck4(f4 period) {
 __device__ __forceinline__ f4 hash_noise4(uint32_t seed_rot, f4 t) {
     u4 off;
     off.x = s2r_f32_as_u32(t.x); off.y = s2r_f32_as_u32(t.y); off.z = s2r_f32_as_u32(t.z); off.w = s2r_f32_as_u32(t.w);
-    const u4 h = (off ^ seed_rot) * 0x9e3779b9u;
-    const f4 value = __builtin_convertvector(h & 0xffffu, f4);
+    // only the low 16 bits of the product are used (cast::<u16>()), and they depend only on the low
+    // 16 bits of the factors: a full-rate 16-bit multiply instead of the quarter-rate 32-bit one
+    const us4 h = __builtin_convertvector(off ^ seed_rot, us4) * (unsigned short)0x79b9u;
+    const f4 value = __builtin_convertvector(h, f4);
     const f4 q = div_const_nocheck4(value, 65535.0f, 0x1.0001p-16f);
     return vfma(q, splat(2.0f), splat(-1.0f));
 }
@@ -673,8 +679,16 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
     for (int q = 0; q < 4; ++q) {
         const u4 ou = (u4)(o_chunk + 4u * q) + (u4){0u, 1u, 2u, 3u};
         const f4 t = __builtin_convertvector(ou, f4);
+#if defined(S2R_ABL_AMP)
+        amp[q] = splat(ea.y0);
+#else
         amp[q] = splat(ea.slope) * (t - splat(ea.base)) + splat(ea.y0);
+#endif
+#if defined(S2R_ABL_NOISE)
+        nz[q] = t;
+#else
         nz[q] = hash_noise4(r.seed_rot, t) + splat(p.noise_level);
+#endif
         if (SRC == 0) xq[q] = splat(fc.xc);
         if (SRC == 2) {
             const f4 mod = splat(em.slope) * (t - splat(em.base)) + splat(em.y0);
@@ -691,9 +705,17 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
         for (int j = 0; j < 4; ++j) {
             const float ph = r.phase;
             const float nx = ph + k.inv_period;                  // oscillators.rs:377-381; nx >= 0
+#if defined(S2R_ABL_PHASE)
+            r.phase = nx;
+#else
             r.phase = nx - __builtin_truncf(nx);                 //   fmodf(nx, 1) for nx >= 0
+#endif
             const float off = k.period * ph;                     // fma(period, ph, +0) with a product >= +0
+#if defined(S2R_ABL_SEL)
+            const float x = off;
+#else
             const float x = (off == k.period) ? 0.0f : off;      // fmodf(off, period) on [0, period]
+#endif
             float osc;
             if (OSC == S2R_OSC_SAW) osc = __builtin_fmaf(k.a, x, 1.0f);
             else if (OSC == S2R_OSC_SQUARE) osc = x < k.a ? 1.0f : -1.0f;
@@ -710,8 +732,14 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
             const float y = __builtin_fmaf(a0[j], s, xq[q][j] * r.last);
             r.last = y;
             float out = y * amp[q][j];
+#if !defined(S2R_ABL_LIVE)
             out = live ? out : 0.0f;
+#endif
+#if defined(S2R_ABL_TILE)
+            if (q == 3 && j == 3) tile_col[0] = out;
+#else
             tile_col[(4 * q + j) * tile_stride] = out;
+#endif
             if (pv_dst) pv_dst[4 * q + j] = out;
         }
     }
@@ -874,21 +902,43 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
             for (uint32_t c16 = 0; c16 < n_x16; c16 += kChunk) {
                 if (TEV) apply_events_at(sc0 + c16);
                 const uint32_t o_chunk = r.offset + sc0 + c16;
-                // one wave-uniform decision per 16 frames: nobody reaches an envelope threshold in here
-                if (fast_ok && __ballot(!((float)(o_chunk + (kChunk - 1)) < thr_min)) == 0ull) {
-                    float *tcol = tile + col;
-                    float *pvd = (PV && pv_lane) ? p.per_voice + pv_base + sc0 + c16 : nullptr;
-                    const f4 *sq = stream + (size_t)((sc0 + c16) / kP) * 64u;
-                    if (have_stream) chunk_fast<OSC, 1>(p, r, ea, em, fc, k_const, o_chunk, sq, sT, sSin, live, tcol, VW + 1, pvd);
-                    else if (!p.no_flat_shortcut && __ballot(live && em.slope != 0.0f) == 0ull)
-                        chunk_fast<OSC, 0>(p, r, ea, em, fc, k_const, o_chunk, sq, sT, sSin, live, tcol, VW + 1, pvd);
-                    else chunk_fast<OSC, 2>(p, r, ea, em, fc, k_const, o_chunk, sq, sT, sSin, live, tcol, VW + 1, pvd);
-                    if (have_stream) {                       // keep the general path's one-ahead prefetch coherent
-                        const uint32_t qn = (sc0 + c16 + kChunk) / kP + sub;
-                        if (qn < x16_frames / kP) xc_next = stream[(size_t)qn * 64u];
+                if (fast_ok) {
+                    // How many 16-frame chunks can run branch-free from here?  Offsets only grow and the
+                    // active stages' thresholds stay put on this path, so if the LAST frame of a run is below
+                    // every lane's next threshold, every earlier frame is too: one wave-uniform decision per
+                    // run (up to the rest of the super-chunk) instead of several per chunk — with one wave per
+                    // SIMD every VALU->scalar decision and taken branch is a bubble nothing else fills.
+                    const uint32_t left = (n_x16 - c16) / kChunk;
+                    auto clear_for = [&](uint32_t n) {
+                        return __ballot(!((float)(o_chunk + n * kChunk - 1u) < thr_min)) == 0ull;
+                    };
+                    uint32_t run = 0;
+                    if (TEV) run = clear_for(1u) ? 1u : 0u;      // events may land on any chunk boundary
+                    else if (clear_for(left)) run = left;
+                    else if (left > 4u && clear_for(4u)) run = 4u;
+                    else if (clear_for(1u)) run = 1u;
+                    if (run) {
+                        float *tcol = tile + col;
+                        auto run_chunks = [&](auto src_tag) {
+                            constexpr int SRC = decltype(src_tag)::value;
+                            for (uint32_t i = 0; i < run; ++i) {
+                                const uint32_t f0 = c16 + i * kChunk;            // frame inside the super-chunk
+                                float *pvd = (PV && pv_lane) ? p.per_voice + pv_base + sc0 + f0 : nullptr;
+                                const f4 *sq = stream + (size_t)((sc0 + f0) / kP) * 64u;
+                                chunk_fast<OSC, SRC>(p, r, ea, em, fc, k_const, o_chunk + i * kChunk, sq, sT, sSin, live, tcol, VW + 1, pvd);
+                                reduce_chunk(f0, kChunk);
+                            }
+                        };
+                        if (have_stream) run_chunks(std::integral_constant<int, 1>{});
+                        else if (!p.no_flat_shortcut && __ballot(live && em.slope != 0.0f) == 0ull) run_chunks(std::integral_constant<int, 0>{});
+                        else run_chunks(std::integral_constant<int, 2>{});
+                        c16 += (run - 1u) * kChunk;
+                        if (have_stream) {                       // keep the general path's one-ahead prefetch coherent
+                            const uint32_t qn = (sc0 + c16 + kChunk) / kP + sub;
+                            if (qn < x16_frames / kP) xc_next = stream[(size_t)qn * 64u];
+                        }
+                        continue;
                     }
-                    reduce_chunk(c16, kChunk);
-                    continue;
                 }
                 for (uint32_t g = c16; g < c16 + kChunk; g += G) {
                     // closed-form work of frames sc0+g+4*sub .. +3 on this lane

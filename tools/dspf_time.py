@@ -5,7 +5,7 @@ import numpy as np
 import synth2_amd as s2
 
 V = int(os.environ.get("V", 65536))
-for kind in (0, 1, 2, 3, 4, 5, 6, 8):
+for kind in [int(k) for k in os.environ.get("KINDS", "0,1,2,3,4,5,6,8").split(",")]:
     s = s2.Synth(V, max_frames=1024)
     p = s2.default_patch(); p.lpf_kind = kind
     s.set_patch(p)
