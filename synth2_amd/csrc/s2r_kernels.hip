@@ -774,7 +774,9 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
     constexpr uint32_t GW = VW / 16;                             // 16-voice groups per wave
     const uint32_t n_groups = n_waves * GW;
     float *const sW = s_dyn;                                     // [2][n_groups][kSuper]
-    float *const tile = s_dyn + 2 * n_groups * kSuper + wave * (kChunk * (VW + 1));
+    // two tiles per wave: the branch-free runs fill one while the previous chunk's is being added up
+    constexpr uint32_t kTile = kChunk * (VW + 1);
+    float *const tile = s_dyn + 2 * n_groups * kSuper + wave * (2 * kTile);
     const uint32_t sub = tid & (L - 1);                          // which quadruple of the group this lane prepares
     const uint32_t block_voices = blockDim.x / L;
     const uint32_t vi = blockIdx.x * block_voices + tid / L;
@@ -918,16 +920,34 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
                     else if (left > 4u && clear_for(4u)) run = 4u;
                     else if (clear_for(1u)) run = 1u;
                     if (run) {
-                        float *tcol = tile + col;
+                        // Software pipeline: chunk i lands in tile (i & 1); the 16 loads and the serial adds of
+                        // chunk i-1's transpose-and-add are issued BEFORE chunk i's arithmetic and its group sum is
+                        // stored after it, so their latency overlaps work instead of idling the wave's only SIMD.
+                        run = (uint32_t)__builtin_amdgcn_readfirstlane((int)run);
+                        const uint32_t rf = lane & 15u, rgrp = lane >> 4;
+                        const bool r_on = L == 1 || rgrp < GW;
+                        auto tile_sum = [&](uint32_t b) {
+                            const float *src = tile + b * kTile + rf * (VW + 1) + (r_on ? rgrp : 0u) * 16u;
+                            float acc = src[0];
+#pragma unroll
+                            for (int q = 1; q < 16; ++q) acc += src[q];
+                            return acc;
+                        };
+                        float *const sw_row = sW + (buf * n_groups + wave * GW + (r_on ? rgrp : 0u)) * kSuper + rf;
                         auto run_chunks = [&](auto src_tag) {
                             constexpr int SRC = decltype(src_tag)::value;
                             for (uint32_t i = 0; i < run; ++i) {
                                 const uint32_t f0 = c16 + i * kChunk;            // frame inside the super-chunk
+                                float prev = 0.0f;
+                                if (i) prev = tile_sum((i - 1u) & 1u);
                                 float *pvd = (PV && pv_lane) ? p.per_voice + pv_base + sc0 + f0 : nullptr;
                                 const f4 *sq = stream + (size_t)((sc0 + f0) / kP) * 64u;
-                                chunk_fast<OSC, SRC>(p, r, ea, em, fc, k_const, o_chunk + i * kChunk, sq, sT, sSin, live, tcol, VW + 1, pvd);
-                                reduce_chunk(f0, kChunk);
+                                chunk_fast<OSC, SRC>(p, r, ea, em, fc, k_const, o_chunk + i * kChunk, sq, sT, sSin, live,
+                                                     tile + (i & 1u) * kTile + col, VW + 1, pvd);
+                                if (i && r_on) sw_row[f0 - kChunk] = prev;
                             }
+                            const float last = tile_sum((run - 1u) & 1u);
+                            if (r_on) sw_row[c16 + (run - 1u) * kChunk] = last;
                         };
                         if (have_stream) run_chunks(std::integral_constant<int, 1>{});
                         else if (!p.no_flat_shortcut && __ballot(live && em.slope != 0.0f) == 0ull) run_chunks(std::integral_constant<int, 0>{});
@@ -1347,8 +1367,9 @@ hipError_t launch_l(const S2rRenderParams &p0, uint32_t block_voices, uint32_t l
     const uint32_t grid = (p.n_voices + block_voices - 1) / block_voices;
     const dim3 block(block_voices * lanes);
     const uint32_t n_waves = block_voices * lanes / 64, vw = 64 / lanes, n_groups = n_waves * (vw / 16);
-    p.super_frames = n_groups <= 16 ? kSuperMax : 64u;           // keeps the staging under ~100 KiB of LDS
-    const size_t lds = sizeof(float) * ((size_t)2 * n_groups * p.super_frames + (size_t)n_waves * kChunk * (vw + 1));
+    // keeps the staging (group sums + two transpose tiles per wave) under the 160 KiB of LDS
+    p.super_frames = n_groups <= 16 ? kSuperMax : (n_groups <= 32 ? 64u : 32u);
+    const size_t lds = sizeof(float) * ((size_t)2 * n_groups * p.super_frames + (size_t)n_waves * 2 * kChunk * (vw + 1));
     // the launch bound is the register budget: 256-thread workgroups (one wave per SIMD) may use
     // the whole file, which the 4-frame vector code wants; bigger workgroups get what is left
     const uint32_t threads = block_voices * lanes;
