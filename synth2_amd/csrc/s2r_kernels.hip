@@ -714,7 +714,11 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
 #if defined(S2R_ABL_SEL)
             const float x = off;
 #else
-            const float x = (off == k.period) ? 0.0f : off;      // fmodf(off, period) on [0, period]
+            // fmodf(off, period) on [0, period] (off == period -> 0) without a compare/select pair, which
+            // costs a single wave ~4x a plain op: both are non-negative floats, so bits(off) - bits(period)
+            // is negative exactly when off < period
+            const int32_t keep = ((int32_t)s2r_f2u(off) - (int32_t)s2r_f2u(k.period)) >> 31;
+            const float x = s2r_u2f(s2r_f2u(off) & (uint32_t)keep);
 #endif
             float osc;
             if (OSC == S2R_OSC_SAW) osc = __builtin_fmaf(k.a, x, 1.0f);
