@@ -700,23 +700,26 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const f4 a0 = splat(1.0f) - xq[q];                       // filters.rs:23
+        // filters.rs:23.  A lane without a started voice must put +0.0 into the mix (synth.rs:178 skips
+        // it): with a0 = 0 and last = 0 its y is 0*s + x*0 = +0 for every finite s and x >= 0, and
+        // (+0) * (amp = +0) = +0 — two selects per quad instead of one per frame
+        f4 a0 = splat(1.0f) - xq[q];
+        f4 ampq = amp[q];
+        if (!live) { a0 = splat(0.0f); ampq = splat(0.0f); }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float ph = r.phase;
-            const float nx = ph + k.inv_period;                  // oscillators.rs:377-381; nx >= 0
-#if defined(S2R_ABL_PHASE)
-            r.phase = nx;
-#else
-            r.phase = nx - __builtin_truncf(nx);                 //   fmodf(nx, 1) for nx >= 0
-#endif
+            const float nx = ph + k.inv_period;                  // oscillators.rs:377-381; 0 <= nx < 2
+            // fmodf(nx, 1) for nx >= 0 is its fractional part, which is exact; v_fract_f32 returns
+            // min(nx - floor(nx), 0x1.fffffep-1) and the clamp cannot bind for nx < 2^23
+            r.phase = __builtin_amdgcn_fractf(nx);
             const float off = k.period * ph;                     // fma(period, ph, +0) with a product >= +0
 #if defined(S2R_ABL_SEL)
             const float x = off;
 #else
-            // fmodf(off, period) on [0, period] (off == period -> 0) without a compare/select pair, which
-            // costs a single wave ~4x a plain op: both are non-negative floats, so bits(off) - bits(period)
-            // is negative exactly when off < period
+            // fmodf(off, period) on [0, period] (off == period -> 0): both are non-negative floats, so
+            // bits(off) - bits(period) is negative exactly when off < period (the compiler turns this into an
+            // integer compare + select on an SGPR pair, cheaper here than the float compare through VCC)
             const int32_t keep = ((int32_t)s2r_f2u(off) - (int32_t)s2r_f2u(k.period)) >> 31;
             const float x = s2r_u2f(s2r_f2u(off) & (uint32_t)keep);
 #endif
@@ -735,10 +738,7 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
             const float s = (osc + p.osc_gain) + nz[q][j];
             const float y = __builtin_fmaf(a0[j], s, xq[q][j] * r.last);
             r.last = y;
-            float out = y * amp[q][j];
-#if !defined(S2R_ABL_LIVE)
-            out = live ? out : 0.0f;
-#endif
+            const float out = y * ampq[j];
 #if defined(S2R_ABL_TILE)
             if (q == 3 && j == 3) tile_col[0] = out;
 #else
