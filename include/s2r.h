@@ -212,9 +212,10 @@ int s2r_set_timing(s2r_synth *s, int enabled);
  * Turning it off makes every frame pay the full pow/exp chain (bench.py's
  * `value_all_voices_modulating` leg). */
 int s2r_set_flat_shortcut(s2r_synth *s, int enabled);
-/* Measurement knob (default on): 64-voice groups whose mod envelope moves during a fill get
- * their LPF coefficients computed ahead of the render kernel by a GPU-wide pass (DESIGN.md
- * 4.4) instead of in-lane.  Same bits either way. */
+/* Measurement knob (default 1): 64-voice groups whose mod envelope moves during a fill get
+ * their LPF coefficients computed ahead of the render kernel instead of in-lane.
+ * 0: off; 1: on, and a fill with few untimed events applies them in the classification launch
+ * (events in the kernel arguments); 2: on, always with the separate events kernel.  Same bits. */
 int s2r_set_coeff_stream(s2r_synth *s, int enabled);
 float s2r_last_render_ms(s2r_synth *s);
 const char *s2r_last_error(const s2r_synth *s);             /* never NULL */

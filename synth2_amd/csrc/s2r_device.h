@@ -123,6 +123,18 @@ struct S2rTimedEvent {
 };
 #define S2R_TEV_FIRST 0x100u
 
+// Events + classification in one launch: the fill's folded note events ride in
+// the kernel arguments (no trip to host memory); every 64-voice group applies the ones that hit
+// it and classifies itself on the result.
+#define S2R_PREP_MAX_EVENTS 288u
+struct S2rPrepParams {
+    S2rRenderParams p;
+    uint32_t n_events;
+    uint32_t _pad;
+    uint32_t ev[3 * S2R_PREP_MAX_EVENTS];   // voice, S2rVoiceEvent.flags, pitch bits
+};
+static_assert(sizeof(S2rPrepParams) <= 4096, "kernel arguments are limited to 4 KiB");
+
 struct S2rMixParams {
     const float *block_partials;  // [n_blocks][frames_stride]
     uint32_t n_blocks;
@@ -136,6 +148,7 @@ struct S2rMixParams {
 };
 
 hipError_t s2r_launch_coeff(const S2rRenderParams &p, hipStream_t stream);   // classify + coefficient pass
+hipError_t s2r_launch_prep(const S2rPrepParams &a, hipStream_t stream);      // events + classify in one launch, then the coefficient pass
 hipError_t s2r_launch_render(const S2rRenderParams &p, uint32_t block_voices, uint32_t lanes_per_voice, hipStream_t stream);
 hipError_t s2r_launch_mix(const S2rMixParams &p, hipStream_t stream);
 hipError_t s2r_launch_events(const S2rVoiceArrays &v, const S2rVoiceEvent *dev_events, uint32_t n, hipStream_t stream);

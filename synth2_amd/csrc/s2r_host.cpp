@@ -130,7 +130,7 @@ struct s2r_synth {
     float *per_voice_dev = nullptr; size_t per_voice_cap = 0;
     // coefficient stream (s2r_kernels.hip)
     int32_t *group_slot = nullptr; uint32_t *slot_group = nullptr; uint32_t *coeff_count = nullptr; float *coeff = nullptr;
-    uint32_t coeff_capacity = 0, coeff_parity = 0; bool use_coeff = true;
+    uint32_t coeff_capacity = 0, coeff_parity = 0; bool use_coeff = true, use_prep = true;
     float pitch_table[256];
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool timing = false, timed = false, no_flat_shortcut = false;
@@ -273,10 +273,20 @@ S2rRenderParams make_params(s2r_synth *s, size_t frames, uint32_t sample_rate) {
 // events -> render -> (mix) on `stream`; the partial or final mix lands in `dev_out`
 int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t stream, float *dev_out,
                  bool root_add, bool stereo, float *per_voice_dev) {
+    // The common case — a one-pole patch without oscillator FM, a handful of untimed events without
+    // seed overrides — is prepared by two launches (events + classification with the events in the
+    // kernel arguments, then the coefficient pass) instead of three.
+    bool one_launch = s->use_prep && s->use_coeff && !s->no_flat_shortcut && s->coeff != nullptr && s->bank.size() == 1 &&
+                      s->bank[0].mod_env_to_osc_freq == 0.0f && s->bank[0].lpf_kind == S2R_FILT_ONEPOLE &&
+                      frames >= 16 && s->tpending.empty() && s->pending.size() <= S2R_PREP_MAX_EVENTS;
+    if (one_launch)
+        for (const S2rVoiceEvent &e : s->pending) if (e.seed != 0u) { one_launch = false; break; }
     EventSlot *timed_slot = nullptr;
     const S2rTimedEvent *tev_dev = nullptr;
-    int rc = flush_events(s, stream, &timed_slot, &tev_dev);
-    if (rc != S2R_OK) return rc;
+    if (!one_launch) {
+        int rc = flush_events(s, stream, &timed_slot, &tev_dev);
+        if (rc != S2R_OK) return rc;
+    }
     if (s->bank.size() > 1 && (s->bank_dirty || s->bank_rate != sample_rate)) {
         // resolve every patch for this sample rate (Ms::as_samples, units.rs:44-53) and replace the
         // device copy; rare (bank edits, rate changes), so a synchronous hand-over is fine
@@ -298,7 +308,21 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
     p.per_voice = per_voice_dev;
     p.tev = tev_dev;
     p.voice_ev_head = s->voice_ev_head;
-    if (p.use_coeff && frames >= 16) {
+    if (one_launch) {
+        static thread_local S2rPrepParams a;         // 4 KiB of kernel arguments, copied by the launch
+        a.p = p;
+        a.p.use_coeff = 1;
+        a.n_events = (uint32_t)s->pending.size();
+        for (uint32_t i = 0; i < a.n_events; i++) {
+            const S2rVoiceEvent &e = s->pending[i];
+            a.ev[3u * i] = e.voice; a.ev[3u * i + 1u] = e.flags; a.ev[3u * i + 2u] = s2r_f2u(e.pitch);
+        }
+        S2R_HIP(s, s2r_launch_prep(a, stream));
+        s->coeff_parity ^= 1u;
+        p.use_coeff = 1;
+        for (const S2rVoiceEvent &e : s->pending) s->pending_slot[e.voice] = -1;
+        s->pending.clear();
+    } else if (p.use_coeff && frames >= 16) {
         S2R_HIP(s, s2r_launch_coeff(p, stream));
         s->coeff_parity ^= 1u;
     } else {
@@ -484,7 +508,7 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
         // coefficient stream: room for half of the 64-voice groups (beyond that the in-lane path is
         // at least as good); [slot][max_frames/4][64] float4
         const uint32_t n_groups64 = (shard_voices + 63u) / 64u;
-        s->coeff_capacity = n_groups64 > 1 ? n_groups64 / 2 : 1;
+        s->coeff_capacity = n_groups64;          // a slot for every group: the stream never overflows
         // one entry per 64 lanes of the PADDED voice range: the render kernel's padding waves look
         // their (non-existent) group up too and must find -1
         const size_t n_slots_padded = s->padded_voices / 64u + 1u;
@@ -789,6 +813,7 @@ int s2r_set_flat_shortcut(s2r_synth *s, int enabled) {
 int s2r_set_coeff_stream(s2r_synth *s, int enabled) {
     if (!s) return S2R_ERR_INVALID;
     s->use_coeff = enabled != 0;
+    s->use_prep = enabled != 2;              // 2: coefficient stream through the separate kernels only
     return S2R_OK;
 }
 

@@ -652,6 +652,84 @@ __global__ void __launch_bounds__(256) s2r_coeff_kernel(const S2rRenderParams p)
 }
 
 // ---------------------------------------------------------------------------------------
+// Events + classification in one launch for the common case (few untimed events, one-pole patch
+// without oscillator FM): one 64-lane workgroup per 64-voice group.  The fill's note events — the
+// host folds them to at most one record per voice — ride in the kernel arguments; the group
+// picks out the ones that hit it (what s2r_events_kernel does through mapped host memory),
+// writes the touched voices back, and classifies itself on the post-event state exactly like
+// s2r_classify_kernel.  The coefficient pass follows as its own launch: it spreads the FEW moving
+// groups over the whole chip, which a per-group launch shape cannot (measured: 20 us in-group
+// vs 7 us).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) s2r_prep_kernel(const S2rPrepParams a) {
+    const S2rRenderParams &p = a.p;
+    const uint32_t group = blockIdx.x, lane = threadIdx.x;
+    const uint32_t vi = group * 64u + lane;
+    const bool in_range = vi < p.n_voices;
+    if (group == 0 && lane == 0) p.coeff_count[p.coeff_parity ^ 1u] = 0u;       // ready for the next fill
+    uint32_t flags = in_range ? p.v.flags[vi] : 0u;
+    uint32_t offset = in_range ? p.v.offset[vi] : 0u;
+    uint32_t release = in_range ? p.v.release[vi] : 0u;
+    // ---- the fill's note events (synth.rs:61-80): 64 records per step, one per lane; the few that
+    //      hit this group are handed to their lane ----
+    uint32_t my_flags = 0u, my_pitch = 0u;
+    for (uint32_t base = 0; base < a.n_events; base += 64u) {
+        const uint32_t i = base + lane;
+        const bool have = i < a.n_events;
+        const uint32_t ev_voice = have ? a.ev[3u * i] : 0xffffffffu;
+        const uint32_t ev_flags = have ? a.ev[3u * i + 1u] : 0u;
+        const uint32_t ev_pitch = have ? a.ev[3u * i + 2u] : 0u;
+        uint64_t hits = __ballot(have && (ev_voice >> 6) == group);
+        while (hits) {                                           // wave-uniform
+            const int src = __builtin_ctzll(hits);
+            hits &= hits - 1ull;
+            const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)ev_voice, src);
+            const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)ev_flags, src);
+            const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane((int)ev_pitch, src);
+            if ((v & 63u) == lane) { my_flags = f; my_pitch = pb; }
+        }
+    }
+    const bool restart = (my_flags & S2R_EV_RESTART) != 0u;
+    if (restart) {                                               // *voice = Voice { .. }, synth.rs:63-69
+        flags = S2R_VF_STARTED | ((my_flags & S2R_EV_RELEASE) ? S2R_VF_RELEASED : 0u);
+        offset = 0u; release = 0u;
+    } else if ((my_flags & S2R_EV_RELEASE) && (flags & S2R_VF_STARTED) && !(flags & S2R_VF_RELEASED)) {   // synth.rs:74-75
+        release = offset; flags |= S2R_VF_RELEASED;
+    }
+    if (my_flags != 0u) {
+        if (restart) {
+            p.v.pitch[vi] = s2r_u2f(my_pitch);
+            p.v.offset[vi] = 0u;
+            p.v.phase[vi] = 0.0f;
+            p.v.lpf_last[vi] = 0.0f;
+            p.v.fx1[vi] = 0.0f; p.v.fx2[vi] = 0.0f; p.v.fy1[vi] = 0.0f; p.v.fy2[vi] = 0.0f;
+            p.v.seed[vi] = 0u;                                   // this path carries no seed overrides
+            p.v.program[vi] = my_flags >> S2R_EV_PROGRAM_SHIFT;
+        }
+        p.v.release[vi] = release;
+        p.v.flags[vi] = flags;
+    }
+    // ---- does any mod envelope of the group move during this fill? (as s2r_classify_kernel) ----
+    bool moving = false;
+    if (flags & S2R_VF_STARTED) {
+        const float rel_f = (flags & S2R_VF_RELEASED) ? (float)release : 4294967296.0f;
+        const float ro_m = __builtin_fmaxf(rel_f, p.mod.sus_off), end_m = ro_m + p.mod.R;
+        const EnvRun e0 = env_stage_at(p.mod, ro_m, end_m, (float)offset);
+        const float t_last = (float)(offset + (p.frames - 1u));
+        moving = !(e0.slope == 0.0f && t_last < e0.thr);
+    }
+    const bool any = __ballot(moving) != 0ull;
+    if (lane == 0) {
+        int32_t slot = -1;
+        if (any) {
+            const uint32_t sidx = atomicAdd(&p.coeff_count[p.coeff_parity], 1u);
+            if (sidx < p.coeff_capacity) { slot = (int32_t)sidx; p.slot_group[sidx] = group; }
+        }
+        p.group_slot_w[group] = slot;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // The branch-free 16-frame chunk.  Measured (tools/ablate.sh): with the rare branches (envelope
 // stage change, fmodf slow path, coefficient-source selection) inside the per-quad loop the
 // SAME executed work takes almost twice as long — every one is a basic-block boundary the
@@ -1425,6 +1503,15 @@ hipError_t s2r_launch_coeff(const S2rRenderParams &p, hipStream_t stream) {
     hipLaunchKernelGGL(s2r_classify_kernel, dim3(n_groups64), dim3(64), 0, stream, p);
     if (p.fast_div_sr) hipLaunchKernelGGL(s2r_coeff_kernel<true>, dim3(2048), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(s2r_coeff_kernel<false>, dim3(2048), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t s2r_launch_prep(const S2rPrepParams &a, hipStream_t stream) {
+    if (a.p.n_voices == 0 || a.p.frames < 16u || !a.p.use_coeff) return hipErrorInvalidValue;
+    const uint32_t n_groups64 = (a.p.n_voices + 63u) / 64u;
+    hipLaunchKernelGGL(s2r_prep_kernel, dim3(n_groups64), dim3(64), 0, stream, a);
+    if (a.p.fast_div_sr) hipLaunchKernelGGL(s2r_coeff_kernel<true>, dim3(2048), dim3(256), 0, stream, a.p);
+    else hipLaunchKernelGGL(s2r_coeff_kernel<false>, dim3(2048), dim3(256), 0, stream, a.p);
     return hipGetLastError();
 }
 

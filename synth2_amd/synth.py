@@ -353,7 +353,9 @@ class Synth:
         self._check(self.L.s2r_set_flat_shortcut(self.h, 1 if enabled else 0))
 
     def set_coeff_stream(self, enabled=True):
-        self._check(self.L.s2r_set_coeff_stream(self.h, 1 if enabled else 0))
+        """False/0: coefficients in-lane; True/1: ahead-of-time stream (events applied by the classification launch
+        when the fill allows it); 2: stream through the separate events/classify/coefficient kernels only"""
+        self._check(self.L.s2r_set_coeff_stream(self.h, int(enabled)))
 
     def set_timing(self, enabled=True):
         self._check(self.L.s2r_set_timing(self.h, 1 if enabled else 0))

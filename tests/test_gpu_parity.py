@@ -76,17 +76,16 @@ def test_c2_1024_voices_blocks_of_256(lanes):
 
 
 @pytest.mark.parametrize("lanes", [1, 2, 4])
-@pytest.mark.parametrize("stream", [True, False])
+@pytest.mark.parametrize("stream", [1, 2, 0])
 def test_coefficient_stream_is_bit_neutral(stream, lanes):
     """64-voice groups with a moving mod envelope get their LPF coefficients from the ahead-of-time
     pass; with it off they are computed in-lane.  Mixed population: some groups fully flat, some
     partly moving, some restarted mid-run, ragged fills (tail frames bypass the stream)."""
     V = 1024
     pr = Pair(V, lanes=lanes, max_frames=1024)
-    if not stream:
-        pr.gpu.set_coeff_stream(False)
+    pr.gpu.set_coeff_stream(stream)      # 1: one preparation launch where possible, 2: separate kernels, 0: in-lane
     for v in range(V):
-        pr.note_on(36 + v % 61)
+        pr.note_on(36 + v % 61)          # 1024 events: more than one launch carries -> separate kernels
     for b, n in enumerate([1024, 1024, 512, 1000, 1024, 16, 1024, 1024, 1024, 1024, 1024, 1024]):
         if b in (3, 5, 8, 10):
             for k in range(40):              # restart the 40 oldest voices: their groups start moving again
@@ -98,16 +97,28 @@ def test_coefficient_stream_is_bit_neutral(stream, lanes):
         assert_bits_equal(g, o, "stream=%s lanes=%d buffer %d" % (stream, lanes, b))
 
 
-def test_coefficient_stream_overflow_falls_back():
-    """more moving groups than the stream holds (capacity = half the groups): everything is
-    computed in-lane, same bits"""
+@pytest.mark.parametrize("mode", [1, 2])
+def test_coefficient_stream_every_group_moving(mode):
+    """every group moving at once (the stream has a slot per group), events arriving in batches on
+    both sides of what one preparation launch carries (288), releases folded onto restarts"""
     V = 512
     pr = Pair(V)
+    pr.gpu.set_coeff_stream(mode)
+    rng = np.random.RandomState(mode)
+    for b in range(6):
+        n_on = [288, 100, 289, 0, 17, 300][b]
+        for k in range(n_on):
+            pr.note_on(36 + int(rng.randint(0, 61)))
+        for k in range(n_on // 5):
+            pr.note_off(36 + int(rng.randint(0, 61)))     # some land on voices restarted in the same batch
+        g, o, _pv = pr.sample(1024 if b != 3 else 1000)
+        assert_bits_equal(g, o, "mode %d buffer %d" % (mode, b))
+    st = pr.gpu.export_state()
     for v in range(V):
-        pr.note_on(36 + v % 61)          # all 8 groups moving for the first 9600 frames
-    for b in range(3):
-        g, o, _pv = pr.sample(1024)
-        assert_bits_equal(g, o, "overflow buffer %d" % b)
+        cv = pr.cpu.voice(v)
+        assert bool(st["started"][v]) == bool(cv.has_current) and bool(st["released"][v]) == bool(cv.has_release)
+        if cv.has_current:
+            assert st["current_frame_offset"][v] == cv.current_frame_offset
 
 
 @pytest.mark.parametrize("fm", [0.0, -2.0])
