@@ -1225,6 +1225,8 @@ __global__ void __launch_bounds__(1024) s2r_render_general_kernel(const S2rRende
     uint32_t ev_frame = 0xffffffffu;
     bool ev_dirty = false;
     uint32_t seed_now = seed;
+    EnvRun ea = env_stage_at(lp.amp, r.ro_a, r.end_a, 0.0f), em = env_stage_at(lp.mod, r.ro_m, r.end_m, 0.0f);
+    float thr_min = -__builtin_inff();       // forces the cascade on this lane's first frame
     uint32_t mod_key = 0xffffffffu;          // bits of the mod value `k`, `xc`, `fc` were computed for (a NaN: never equal)
     OscK k = make_osck_any<OSC>(lp.osc_kind, lp.sr / r.pitch);
     float xc = 0.0f;                         // one-pole coefficient exp(-2 pi f / sr), filters.rs:21
@@ -1276,6 +1278,19 @@ __global__ void __launch_bounds__(1024) s2r_render_general_kernel(const S2rRende
             ev_frame = ev_idx >= 0 ? p.tev[ev_idx].frame : 0xffffffffu;
         }
         set_release_thresholds();
+        thr_min = -__builtin_inff();                             // re-run the envelope cascade
+    };
+
+    // everything below `mod` that depends on it alone (and on the voice's pitch) is kept while no lane's
+    // mod-envelope value changes
+    auto refresh = [&](float mod) {
+        if (__ballot(s2r_f2u(mod) != mod_key) == 0ull) return;
+        const float f_osc = s2r_pow2_sleef_core(mod * lp.amt_osc) * r.pitch;     // process.rs:146-147,231-250
+        const float f_lpf = s2r_pow2_sleef_core(mod * lp.amt_lpf) * lp.lpf_freq; // process.rs:148-152
+        k = make_osck_any<OSC>(lp.osc_kind, lp.sr / f_osc);                      // units.rs:32-42
+        if (lp.lpf_kind == S2R_FILT_ONEPOLE) xc = lpf_coeff<false, LanePatch>(lp, f_lpf, sT);
+        else fc = dsp_filter_coef(lp.lpf_kind, lp.lpf_damping, lp.sr, f_lpf);
+        mod_key = s2r_f2u(mod);
     };
 
     for (uint32_t sc0 = 0; sc0 < p.frames; sc0 += kSuper) {
@@ -1284,19 +1299,24 @@ __global__ void __launch_bounds__(1024) s2r_render_general_kernel(const S2rRende
         if (wave_live) {
             for (uint32_t c16 = 0; c16 < n_x16; c16 += kChunk) {
                 if (TEV) apply_events_at(sc0 + c16);
+                const bool calm = __ballot(!((float)(r.offset + sc0 + c16 + (kChunk - 1u)) < thr_min)) == 0ull;
+                // every lane's mod envelope sits in a zero-slope stage for the whole chunk: its value (0 * (t -
+                // base) + y0, the same bits on every frame) is looked at once instead of per frame
+                const bool flat = calm && __ballot(em.slope != 0.0f) == 0ull;
+                if (flat) refresh(env_value(em, (float)(r.offset + sc0 + c16)));
                 for (uint32_t j = 0; j < kChunk; ++j) {          // one frame of sample_voice_x16, process.rs:306-379
                     const uint32_t oi = r.offset + sc0 + c16 + j;            // wrapping u32 add (process.rs:213-219)
                     const float t = (float)oi;
-                    const float amp = env_value(env_stage_at(lp.amp, r.ro_a, r.end_a, t), t);    // process.rs:144
-                    const float mod = env_value(env_stage_at(lp.mod, r.ro_m, r.end_m, t), t);    // process.rs:145
-                    if (__ballot(s2r_f2u(mod) != mod_key) != 0ull) {
-                        const float f_osc = s2r_pow2_sleef_core(mod * lp.amt_osc) * r.pitch;     // process.rs:146-147,231-250
-                        const float f_lpf = s2r_pow2_sleef_core(mod * lp.amt_lpf) * lp.lpf_freq; // process.rs:148-152
-                        k = make_osck_any<OSC>(lp.osc_kind, lp.sr / f_osc);                      // units.rs:32-42
-                        if (lp.lpf_kind == S2R_FILT_ONEPOLE) xc = lpf_coeff<false, LanePatch>(lp, f_lpf, sT);
-                        else fc = dsp_filter_coef(lp.lpf_kind, lp.lpf_damping, lp.sr, f_lpf);
-                        mod_key = s2r_f2u(mod);
+                    // the active stages' lines stay valid until t reaches the earlier of their thresholds
+                    // (EnvRun, above); `calm`: no lane gets there inside this chunk, so nobody even looks
+                    if (!calm && !(t < thr_min)) {
+                        ea = env_stage_at(lp.amp, r.ro_a, r.end_a, t);
+                        em = env_stage_at(lp.mod, r.ro_m, r.end_m, t);
+                        thr_min = __builtin_fminf(ea.thr, em.thr);
                     }
+                    const float amp = env_value(ea, t);                                           // process.rs:144
+                    const float mod = env_value(em, t);                                           // process.rs:145
+                    if (!flat) refresh(mod);
                     const float nz = hash_noise(r.seed_rot, t) + lp.noise_level;                 // process.rs:347-356 (ADD)
                     const float ph = r.phase;                                                    // oscillators.rs:391-400
                     r.phase = s2r_fmod1(ph + k.inv_period);
