@@ -42,14 +42,26 @@ def main():
             out["dispatch"]["phases_avg_ns"] = {"warmup": avg(0, w), "timed_steps": avg(w, w + k),
                                                 "kernel_ms_launches": avg(w + k, w + k + m),
                                                 "kernel_ms_all_modulating_launches": avg(w + k + m, w + k + 2 * m)}
+    # PMC passes: one row per dispatch and counter; the same launch order as the trace, so the same
+    # slices.  `pmc_avg_per_dispatch` is the TIMED-STEPS phase (steady state); the warm-up launches,
+    # where every group streams coefficients, are reported separately.
+    w = int(os.environ.get("S2R_PROF_WARMUP", "4")); k = int(os.environ.get("S2R_PROF_STEPS", "16"))
     counters = defaultdict(list)
     for sub in ("pmc1", "pmc2", "pmc_fetch", "pmc_write"):
         for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
-            for r in csv.DictReader(open(f)):
-                if want in r.get("Kernel_Name", ""):
-                    counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    out["pmc_avg_per_dispatch"] = {k: sum(v) / len(v) for k, v in sorted(counters.items())}
-    out["pmc_dispatches"] = {k: len(v) for k, v in sorted(counters.items())}
+            rows = [r for r in csv.DictReader(open(f)) if want in r.get("Kernel_Name", "")]
+            rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+            per = defaultdict(list)
+            for r in rows:
+                per[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            for name, vals in per.items():
+                counters[name] = vals
+    def mean(v):
+        return sum(v) / len(v) if v else None
+    out["pmc_avg_per_dispatch"] = {n: mean(v[w:w + k]) for n, v in sorted(counters.items())}
+    out["pmc_avg_first_launches"] = {n: mean(v[:min(w, 8)]) for n, v in sorted(counters.items())}
+    out["pmc_dispatches"] = {n: len(v) for n, v in sorted(counters.items())}
+    out["pmc_phase"] = "dispatches %d..%d of the render kernel (bench.py's timed steps)" % (w, w + k - 1)
     json.dump(out, sys.stdout, indent=1)
     print()
 
