@@ -902,14 +902,17 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
         }
     }
 
-    // envelope stage registers; a threshold of -inf forces the cascade on this lane's first frame
-    EnvRun ea = env_stage_at(p.amp, r.ro_a, r.end_a, 0.0f);
-    EnvRun em = env_stage_at(p.mod, r.ro_m, r.end_m, 0.0f);
-    float thr_min = -__builtin_inff();
+    // envelope stage registers: the cascade for the fill's first frame, run here once so that the first
+    // chunk can already take the branch-free path (a timed event or a stage boundary resets thr_min to
+    // -inf, which sends the next frame through the cascade again)
+    EnvRun ea = env_stage_at(p.amp, r.ro_a, r.end_a, (float)r.offset);
+    EnvRun em = env_stage_at(p.mod, r.ro_m, r.end_m, (float)r.offset);
+    float thr_min = __builtin_fminf(ea.thr, em.thr);
     FlatCache fc;
     fc.xc = 0.0f; fc.k = k_const;
 
     __syncthreads();
+    fc = refresh_flat<OSC, FM>(p, r, em, sT, fc);                // needs the exp2 table in LDS
 
     const bool wave_live = __ballot(live || ev_idx >= 0) != 0ull;
     const uint32_t x16_frames = p.frames & ~(uint32_t)(kChunk - 1);      // frames in full 16-chunks
