@@ -3,9 +3,10 @@
 // One voice per lane.  Per-voice recurrence state (phase, LPF history, frame offset) is
 // loaded coalesced from the SoA arrays in HBM into registers, the frames of the fill are
 // walked serially (phase accumulation and the one-pole LPF are recurrences over time), and
-// the cross-voice mixdown is a wave64 DPP reduction -> LDS across the waves of a workgroup
-// -> one partial row per workgroup in HBM -> a second tiny kernel that adds the rows in a
-// fixed order.  No MFMA: this is a scalar-per-voice recurrence.
+// the cross-voice mixdown is an LDS transpose-and-add per wave (16 voices in index order, the
+// reference's own order) -> LDS across the waves of a workgroup -> one partial row per
+// workgroup in HBM -> a second tiny kernel that adds the rows in a fixed order.
+// No MFMA: this is a scalar-per-voice recurrence.
 //
 // Everything arithmetic follows the reference op for op (citations relative to
 // /root/reference/components/s2_lib/src/); this file must be compiled with
@@ -14,20 +15,6 @@
 #include <type_traits>
 #include "s2r_device.h"
 #include "s2r_math.h"
-
-#if defined(S2R_ABLATE_RECUR)
-#define S2R_RECUR(OSC, p, r, c1, k1, sSin) ((c1.amp + c1.xc) + c1.nz)
-#else
-#define S2R_RECUR(OSC, p, r, c1, k1, sSin) recur_x16<OSC>(p, r, c1, k1, sSin)
-#endif
-// development-only ablation switches (tools/ablate.sh); never defined in the product build
-#if defined(S2R_ABLATE_MIX)
-#define S2R_ABLATE_MIX_BEGIN { asm volatile("" :: "v"(out4.x), "v"(out4.y), "v"(out4.z), "v"(out4.w)); } if (false) {
-#define S2R_ABLATE_MIX_END }
-#else
-#define S2R_ABLATE_MIX_BEGIN
-#define S2R_ABLATE_MIX_END
-#endif
 
 namespace {
 
@@ -248,11 +235,7 @@ __device__ __forceinline__ float osc_value(const OscK &k, float off, const float
     // offset % period: `off` itself while 0 <= off < period (one unsigned compare on the bit
     // patterns, see s2r_fmod_period); the exact library fmodf only if some lane of the wave needs it
     float x = off;
-#if defined(S2R_ABLATE_COLD)
-    const bool slow = false;
-#else
     const bool slow = !(s2r_f2u(off) < s2r_f2u(k.period) && k.period > 0.0f);
-#endif
     if (__builtin_expect(__ballot(slow) != 0ull, 0)) { if (slow) x = ::fmodf(off, k.period); }
     if (OSC == S2R_OSC_SAW) {
         return __builtin_fmaf(k.a, x, 1.0f);
@@ -386,11 +369,7 @@ __device__ __forceinline__ void closed_form_x4(const S2rRenderParams &p, const V
     f4 amp = splat(ea.slope) * (t - splat(ea.base)) + splat(ea.y0);           // process.rs:144
     f4 mod = splat(em.slope) * (t - splat(em.base)) + splat(em.y0);           // process.rs:145
     bool moving = p.no_flat_shortcut != 0;
-#if defined(S2R_ABLATE_COLD)
-    const bool cold = false;
-#else
     const bool cold = !(t.w < thr_min);
-#endif
     if (__builtin_expect(__ballot(cold) != 0ull, 0)) {      // wave-uniform branch: no exec juggling when nobody is cold
         if (cold) {
             // an envelope stage ends inside these four frames: walk them one by one
@@ -412,14 +391,7 @@ __device__ __forceinline__ void closed_form_x4(const S2rRenderParams &p, const V
         }
     }
     cf.amp = amp;
-#if defined(S2R_ABLATE_NOISE)
-    cf.nz = t;
-#else
     cf.nz = hash_noise4(r.seed_rot, t) + splat(p.noise_level);   // process.rs:347-356 (ADD)
-#endif
-#if defined(S2R_ABLATE_FORCEFLAT)
-    cf.xc = splat(fc.xc); return;
-#endif
     if (have_stream) {             // wave-uniform: this 64-voice group's coefficients were computed ahead
         cf.xc = stream_xc;
         return;
@@ -730,7 +702,7 @@ __global__ void __launch_bounds__(64) s2r_prep_kernel(const S2rPrepParams a) {
 }
 
 // ---------------------------------------------------------------------------------------
-// The branch-free 16-frame chunk.  Measured (tools/ablate.sh): with the rare branches (envelope
+// The branch-free 16-frame chunk.  Measured (ablated builds): with the rare branches (envelope
 // stage change, fmodf slow path, coefficient-source selection) inside the per-quad loop the
 // SAME executed work takes almost twice as long — every one is a basic-block boundary the
 // scheduler cannot move work across, and a taken branch is an instruction-fetch bubble for the
@@ -757,16 +729,8 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
     for (int q = 0; q < 4; ++q) {
         const u4 ou = (u4)(o_chunk + 4u * q) + (u4){0u, 1u, 2u, 3u};
         const f4 t = __builtin_convertvector(ou, f4);
-#if defined(S2R_ABL_AMP)
-        amp[q] = splat(ea.y0);
-#else
         amp[q] = splat(ea.slope) * (t - splat(ea.base)) + splat(ea.y0);
-#endif
-#if defined(S2R_ABL_NOISE)
-        nz[q] = t;
-#else
         nz[q] = hash_noise4(r.seed_rot, t) + splat(p.noise_level);
-#endif
         if (SRC == 0) xq[q] = splat(fc.xc);
         if (SRC == 2) {
             const f4 mod = splat(em.slope) * (t - splat(em.base)) + splat(em.y0);
@@ -792,15 +756,11 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
             // min(nx - floor(nx), 0x1.fffffep-1) and the clamp cannot bind for nx < 2^23
             r.phase = __builtin_amdgcn_fractf(nx);
             const float off = k.period * ph;                     // fma(period, ph, +0) with a product >= +0
-#if defined(S2R_ABL_SEL)
-            const float x = off;
-#else
             // fmodf(off, period) on [0, period] (off == period -> 0): both are non-negative floats, so
             // bits(off) - bits(period) is negative exactly when off < period (the compiler turns this into an
             // integer compare + select on an SGPR pair, cheaper here than the float compare through VCC)
             const int32_t keep = ((int32_t)s2r_f2u(off) - (int32_t)s2r_f2u(k.period)) >> 31;
             const float x = s2r_u2f(s2r_f2u(off) & (uint32_t)keep);
-#endif
             float osc;
             if (OSC == S2R_OSC_SAW) osc = __builtin_fmaf(k.a, x, 1.0f);
             else if (OSC == S2R_OSC_SQUARE) osc = x < k.a ? 1.0f : -1.0f;
@@ -817,11 +777,7 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
             const float y = __builtin_fmaf(a0[j], s, xq[q][j] * r.last);
             r.last = y;
             const float out = y * ampq[j];
-#if defined(S2R_ABL_TILE)
-            if (q == 3 && j == 3) tile_col[0] = out;
-#else
             tile_col[(4 * q + j) * tile_stride] = out;
-#endif
             if (pv_dst) pv_dst[4 * q + j] = out;
         }
     }
@@ -1077,17 +1033,15 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
                             OscK k1 = k_const;                                                   \
                             if (FM) { k1.period = k4.period[j]; k1.inv_period = k4.inv_period[j]; \
                                       k1.a = k4.a[j]; k1.b = k4.b[j]; k1.c = k4.c[j]; }          \
-                            const float o = S2R_RECUR(OSC, p, r, c1, k1, sSin);                  \
+                            const float o = recur_x16<OSC>(p, r, c1, k1, sSin);                  \
                             out4[j] = live ? o : 0.0f;                                           \
                         }                                                                        \
                         if (PV) { if (pv_lane) {                                        \
                             float *dst = p.per_voice + pv_base + sc0 + g + kP * Q;               \
                             dst[0] = out4.x; dst[1] = out4.y; dst[2] = out4.z; dst[3] = out4.w; } } \
-                        S2R_ABLATE_MIX_BEGIN                                                     \
                         float *trow = tile + ((g + kP * Q) & 15u) * (VW + 1) + col;              \
                         trow[0 * (VW + 1)] = out4.x; trow[1 * (VW + 1)] = out4.y;                \
                         trow[2 * (VW + 1)] = out4.z; trow[3 * (VW + 1)] = out4.w;                \
-                        S2R_ABLATE_MIX_END                                                       \
                     }
                     S2R_QUAD(0) S2R_QUAD(1) S2R_QUAD(2) S2R_QUAD(3)
 #undef S2R_QUAD
@@ -1109,12 +1063,8 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
                 sW[(buf * n_groups + wave * GW + i / kSuper) * kSuper + (i % kSuper)] = 0.0f;
             if (PV) { if (pv_lane) for (uint32_t i = 0; i < n_sc; ++i) p.per_voice[pv_base + sc0 + i] = 0.0f; }
         }
-#if defined(S2R_ABLATE_BARRIER)
-        if (false) {
-#else
         __syncthreads();
         for (uint32_t f = tid; f < n_sc; f += blockDim.x) {
-#endif
             // the block's 16-voice group sums, in group (= voice index) order
             float acc = sW[(buf * n_groups + 0) * kSuper + f];
             for (uint32_t gq = 1; gq < n_groups; ++gq) acc += sW[(buf * n_groups + gq) * kSuper + f];
