@@ -1,6 +1,6 @@
 // s2r_voices.h — host-side voice pool: the allocation and release policy of
 // s2_lib::try3::synth::Synth (synth.rs:61-120) for a pool of any size, in O(log V) per event
-// instead of the reference's O(V) scans (binary heaps, lazy deletion), with identical choices:
+// instead of the reference's O(V) scans (a bucket queue and per-note bitmaps), with identical choices:
 //
 //   next_voice (synth.rs:101-120): the voice with the greatest current_frame_offset, an idle
 //     voice counting as u32::MAX, first index on ties (strict `>`).  All started voices
@@ -26,9 +26,43 @@ struct S2rHostVoice {
     bool started = false;
     bool released = false;
     float velocity = 0.0f;
-    uint32_t gen = 0;              // bumped by every note_on: invalidates stale heap entries
     uint64_t start_clock = 0;      // pool clock (frames) at note_on
     uint64_t release_clock = 0;    // pool clock at note_off
+};
+
+// A set of voice indices with "greatest member" in three word operations: a bitmap and two
+// levels of summary bits (one bit per 64-bit word below).  Every rank of an N-GPU run simulates the
+// WHOLE pool's events, so note_off's "last active voice holding this note" is on its critical path.
+class S2rIndexSet {
+  public:
+    void init(uint32_t n) {
+        l0_.assign(((size_t)n + 63) / 64, 0);
+        l1_.assign((l0_.size() + 63) / 64, 0);
+        l2_.assign((l1_.size() + 63) / 64, 0);
+    }
+    bool ready() const { return !l0_.empty(); }
+    void set(uint32_t i) {
+        l0_[i >> 6] |= 1ull << (i & 63);
+        l1_[i >> 12] |= 1ull << ((i >> 6) & 63);
+        l2_[i >> 18] |= 1ull << ((i >> 12) & 63);
+    }
+    void clear(uint32_t i) {
+        if ((l0_[i >> 6] &= ~(1ull << (i & 63))) != 0) return;
+        if ((l1_[i >> 12] &= ~(1ull << ((i >> 6) & 63))) != 0) return;
+        l2_[i >> 18] &= ~(1ull << ((i >> 12) & 63));
+    }
+    // greatest member or -1
+    int64_t last() const {
+        for (size_t w2 = l2_.size(); w2-- > 0;) {
+            if (!l2_[w2]) continue;
+            const size_t w1 = (w2 << 6) + (63 - (size_t)__builtin_clzll(l2_[w2]));
+            const size_t w0 = (w1 << 6) + (63 - (size_t)__builtin_clzll(l1_[w1]));
+            return (int64_t)((w0 << 6) + (63 - (size_t)__builtin_clzll(l0_[w0])));
+        }
+        return -1;
+    }
+  private:
+    std::vector<uint64_t> l0_, l1_, l2_;
 };
 
 class S2rVoicePool {
@@ -53,33 +87,29 @@ class S2rVoicePool {
             // the chosen voice is always the queue's minimum, so it never holds stale entries
             i = started_front().second;
             started_pop();
-            S2rHostVoice &old = voices_[i];
-            if (!old.released) active_valid_[old.note]--;      // its active_ entry goes stale (gen bump)
+            const S2rHostVoice &old = voices_[i];
+            if (!old.released) active_[old.note].clear(i);     // stolen while still held
         }
         S2rHostVoice &v = voices_[i];
         v.note = note; v.velocity = velocity;
         v.started = true; v.released = false;
-        v.gen++;
         v.start_clock = now_; v.release_clock = 0;
         started_push(now_, i);
-        push_active(note, i, v.gen);
+        mark_active(note, i);
         return i;
     }
 
     // synth.rs:72-96; returns the released index or -1 when no active voice holds `note`
     int64_t note_off(uint8_t note) {
-        ActiveHeap &a = active_[note];
-        while (!a.empty()) {
-            const uint32_t i = a.top().first, g = a.top().second;
-            a.pop();
-            S2rHostVoice &v = voices_[i];
-            if (v.gen != g || !v.started || v.released || v.note != note) continue;   // stale
-            v.released = true;
-            v.release_clock = now_;
-            active_valid_[note]--;
-            return i;
-        }
-        return -1;
+        S2rIndexSet &a = active_[note];
+        if (!a.ready()) return -1;
+        const int64_t i = a.last();
+        if (i < 0) return -1;
+        a.clear((uint32_t)i);
+        S2rHostVoice &v = voices_[(size_t)i];
+        v.released = true;
+        v.release_clock = now_;
+        return i;
     }
 
     // every started voice's offset grows by `frames` (synth.rs:197)
@@ -126,12 +156,12 @@ class S2rVoicePool {
         idle_.clear(); idle_head_ = 0;
         buckets_.clear();
         std::vector<std::pair<uint64_t, uint32_t>> all;
-        for (int n = 0; n < 256; n++) { active_[n] = ActiveHeap(); active_valid_[n] = 0; }
+        for (int n = 0; n < 256; n++) active_[n] = S2rIndexSet();
         for (uint32_t i = 0; i < voices_.size(); i++) {
             const S2rHostVoice &v = voices_[i];
             if (!v.started) { idle_.push_back(i); continue; }
             all.push_back({v.start_clock, i});
-            if (!v.released) push_active(v.note, i, v.gen);
+            if (!v.released) mark_active(v.note, i);
         }
         std::sort(all.begin(), all.end());
         for (const auto &e : all) started_push(e.first, e.second);
@@ -139,13 +169,11 @@ class S2rVoicePool {
 
   private:
     struct Pending { uint32_t i, offset, release_offset; };
-    typedef std::priority_queue<std::pair<uint32_t, uint32_t>> ActiveHeap;   // max (index, gen)
 
     // Started voices ordered by (start_clock, index).  The pool clock never goes back, so keys
     // arrive in non-decreasing clock order: a deque of per-clock buckets, each an index list that
     // is sorted lazily when it reaches the front.  pop-min and push are O(1) amortised (one
-    // std::sort per bucket), against two ~19-level heap operations on a half-million-entry heap —
-    // every rank of an N-GPU run simulates the WHOLE pool's events, so this is on its critical path.
+    // std::sort per bucket), against two ~19-level heap operations on a half-million-entry heap.
     struct Bucket {
         uint64_t clock;
         std::vector<uint32_t> idx;
@@ -175,28 +203,18 @@ class S2rVoicePool {
         b.idx.push_back(i);
     }
 
-    void push_active(uint8_t note, uint32_t i, uint32_t gen) {
-        ActiveHeap &a = active_[note];
-        a.push({i, gen});
-        active_valid_[note]++;
-        // stale entries (voices stolen while still held) are dropped lazily; compact when they dominate
-        if (a.size() > 2 * (size_t)active_valid_[note] + 1024) {
-            ActiveHeap fresh;
-            while (!a.empty()) {
-                const auto e = a.top(); a.pop();
-                const S2rHostVoice &v = voices_[e.first];
-                if (v.gen == e.second && v.started && !v.released && v.note == note) fresh.push(e);
-            }
-            a.swap(fresh);
-        }
+    // active = started and not yet released; one index set per note, created on first use
+    void mark_active(uint8_t note, uint32_t i) {
+        S2rIndexSet &a = active_[note];
+        if (!a.ready()) a.init((uint32_t)voices_.size());
+        a.set(i);
     }
 
     std::vector<S2rHostVoice> voices_;
     std::vector<uint32_t> idle_;        // ascending; consumed from idle_head_ (voices never go idle again)
     size_t idle_head_ = 0;
     mutable std::deque<Bucket> buckets_;   // one entry per started voice
-    ActiveHeap active_[256];
-    uint32_t active_valid_[256] = {};
+    S2rIndexSet active_[256];
     std::vector<Pending> pending_;
     uint64_t pending_min_clock_ = 0;
     uint64_t now_ = 0;
