@@ -228,7 +228,7 @@ const char *s2r_status_string(int status);
 int s2r_parse_patch_text(const char *text, size_t len, s2r_patch *out, char *err_buf, size_t err_cap);
 
 /* The voice-allocation / release policy of Synth (synth.rs:61-120) for a pool of any size,
- * O(log V) per event, without rendering.  Offsets advance by s2r_voice_pool_advance. */
+ * O(1) per event, without rendering.  Offsets advance by s2r_voice_pool_advance. */
 typedef struct s2r_voice_pool s2r_voice_pool;
 s2r_voice_pool *s2r_voice_pool_create(uint32_t total_voices);
 void s2r_voice_pool_destroy(s2r_voice_pool *p);

@@ -874,8 +874,10 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
     const uint32_t x16_frames = p.frames & ~(uint32_t)(kChunk - 1);      // frames in full 16-chunks
     // preconditions of the branch-free chunk that hold for the whole fill once they hold at its start
     // (phase' = fmodf(phase + 1/period, 1) stays in [0,1) for a positive period)
-    const bool fast_ok = L == 1 && !FM &&
-        __ballot(!(k_const.period > 0.0f && k_const.period < __builtin_inff() && r.phase >= 0.0f && r.phase < 1.0f)) == 0ull;
+    // Under oscillator FM the period constants are per-frame values — except while every lane's mod envelope
+    // is flat, when they are the ones cached at stage entry (fc.k): that case is checked per run.
+    const bool fast_ok = L == 1 && __ballot(!(r.phase >= 0.0f && r.phase < 1.0f)) == 0ull &&
+        (FM || __ballot(!(k_const.period > 0.0f && k_const.period < __builtin_inff())) == 0ull);
     // coefficient stream for this wave's 64-voice group, if one was prepared (wave-uniform)
     int32_t slot = -1;
     if (!FM && p.use_coeff && p.coeff_count[p.coeff_parity] <= p.coeff_capacity)
@@ -960,6 +962,11 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
                     else if (clear_for(left)) run = left;
                     else if (left > 4u && clear_for(4u)) run = 4u;
                     else if (clear_for(1u)) run = 1u;
+                    if (FM && run) {
+                        const bool fm_flat = !p.no_flat_shortcut &&
+                            __ballot(em.slope != 0.0f || !(fc.k.period > 0.0f && fc.k.period < __builtin_inff())) == 0ull;
+                        if (!fm_flat) run = 0;
+                    }
                     if (run) {
                         // Software pipeline: chunk i lands in tile (i & 1); the 16 loads and the serial adds of
                         // chunk i-1's transpose-and-add are issued BEFORE chunk i's arithmetic and its group sum is
@@ -983,14 +990,15 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
                                 if (i) prev = tile_sum((i - 1u) & 1u);
                                 float *pvd = (PV && pv_lane) ? p.per_voice + pv_base + sc0 + f0 : nullptr;
                                 const f4 *sq = stream + (size_t)((sc0 + f0) / kP) * 64u;
-                                chunk_fast<OSC, SRC>(p, r, ea, em, fc, k_const, o_chunk + i * kChunk, sq, sT, sSin, live,
+                                chunk_fast<OSC, SRC>(p, r, ea, em, fc, FM ? fc.k : k_const, o_chunk + i * kChunk, sq, sT, sSin, live,
                                                      tile + (i & 1u) * kTile + col, VW + 1, pvd);
                                 if (i && r_on) sw_row[f0 - kChunk] = prev;
                             }
                             const float last = tile_sum((run - 1u) & 1u);
                             if (r_on) sw_row[c16 + (run - 1u) * kChunk] = last;
                         };
-                        if (have_stream) run_chunks(std::integral_constant<int, 1>{});
+                        if (FM) run_chunks(std::integral_constant<int, 0>{});        // flat everywhere (checked above)
+                        else if (have_stream) run_chunks(std::integral_constant<int, 1>{});
                         else if (!p.no_flat_shortcut && __ballot(live && em.slope != 0.0f) == 0ull) run_chunks(std::integral_constant<int, 0>{});
                         else run_chunks(std::integral_constant<int, 2>{});
                         c16 += (run - 1u) * kChunk;

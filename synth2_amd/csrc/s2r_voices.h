@@ -1,5 +1,5 @@
 // s2r_voices.h — host-side voice pool: the allocation and release policy of
-// s2_lib::try3::synth::Synth (synth.rs:61-120) for a pool of any size, in O(log V) per event
+// s2_lib::try3::synth::Synth (synth.rs:61-120) for a pool of any size, in O(1) per event
 // instead of the reference's O(V) scans (a bucket queue and per-note bitmaps), with identical choices:
 //
 //   next_voice (synth.rs:101-120): the voice with the greatest current_frame_offset, an idle

@@ -742,3 +742,27 @@ def test_config4_shape_192khz(kind):
         if k == 1:
             for n in range(24, 120, 5):
                 pr.note_off(n)
+
+
+@pytest.mark.parametrize("osc", [s2.OSC_SQUARE, s2.OSC_SAW, s2.OSC_TRIANGLE, s2.OSC_SINE])
+def test_fm_patch_after_the_mod_envelope_settles(osc):
+    """oscillator FM with the mod envelope in a flat stage (sustain at 0.4, later the end stage): the
+    period constants are the ones cached at stage entry and the wave takes the branch-free chunks;
+    short envelope times so that attack, decay, sustain, release and end all fall inside the run"""
+    patch = make_patch(osc_kind=osc, mod_env_to_osc_freq=2.75, mod_env_to_lpf_freq=5.0, noise=0.1)
+    patch.mod_env.attack_ms = 3.0
+    patch.mod_env.decay_ms = 12.0
+    patch.mod_env.sustain = 0.4
+    patch.mod_env.release_ms = 20.0
+    pr = Pair(192, patch, max_frames=1024)
+    for v in range(150):
+        pr.note_on(28 + (v * 5) % 80)
+    for k in range(8):
+        g, o = pr.render_voices(1024 if k != 5 else 1000)
+        assert_bits_equal(g, o, "fm settled, osc %d, buffer %d" % (osc, k))
+        if k == 2:
+            for n in range(28, 108, 3):
+                pr.note_off(n)
+        if k == 4:
+            for v in range(20):
+                pr.note_on(40 + v)          # steals the oldest voices: their groups move again
