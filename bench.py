@@ -108,11 +108,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal on a one-GPU box (S2R_BENCH_BACKEND=gloo S2R_BENCH_SHARE_GPU=1): the ranks share the card and
+    # the 4 KiB partial rows travel through the host over gloo.  Everything but the RCCL collective itself is
+    # the code an N-GPU run executes; the numbers of such a run mean nothing.
+    backend = os.environ.get("S2R_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if os.environ.get("S2R_BENCH_SHARE_GPU") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     vpg = args.voices_per_gpu
     total = vpg * world
@@ -157,7 +165,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())

@@ -90,6 +90,14 @@ class ShardedSynth:
         if self._pending is not None:
             self._finish(self._pending)
             self._pending = None
+        if self.device.type == "cuda" and dist.get_backend() == "gloo":
+            # rehearsal of the multi-rank flow without RCCL (ranks sharing one card): the rows go through the host
+            host = part[:frames].cpu()
+            rows = torch.empty((self.world, frames), dtype=torch.float32)
+            dist.all_gather_into_tensor(rows.view(-1), host)
+            self.gathered[slot][:, :frames] = rows.to(self.device)
+            self._finish((None, slot, frames))
+            return
         if frames == self.max_frames:
             work = dist.all_gather_into_tensor(self.gathered[slot].view(-1), part, async_op=self.overlap)
         else:
