@@ -766,3 +766,28 @@ def test_fm_patch_after_the_mod_envelope_settles(osc):
         if k == 4:
             for v in range(20):
                 pr.note_on(40 + v)          # steals the oldest voices: their groups move again
+
+
+@pytest.mark.parametrize("base", [(1 << 24) - 700, (1 << 25) + 3, (1 << 28) + 99, (1 << 31) - 1500, (1 << 32) - 9000])
+def test_very_old_voices_on_the_branch_free_path(base):
+    """voices that have been sounding for minutes to a day: offsets where u32 -> f32 rounds (the
+    envelope time, the noise's `offset.cast::<u32>()` of the ROUNDED float, the "last frame of the run"
+    test of the branch-free runs), sustained and released, with noise on"""
+    patch = make_patch(noise=0.3)
+    pr = Pair(70, patch, max_frames=1024)
+    for v in range(70):
+        pr.note_on(30 + v)
+    pr.sample(256)
+    st = pr.gpu.export_state()
+    for v in range(70):
+        off = base + 37 * v
+        st["current_frame_offset"][v] = off
+        pr.cpu.voice(v).current_frame_offset = off
+        if v % 3 == 0:                                   # released long ago or just now
+            rel = off - (5 if v % 2 else 4000 + v)
+            st["released"][v] = 1; st["release_frame_offset"][v] = rel
+            pr.cpu.voice(v).has_release = 1; pr.cpu.voice(v).release_frame_offset = rel
+    pr.gpu.import_state(st)
+    for k in range(4):
+        g, o = pr.render_voices(1024 if k != 2 else 1000)
+        assert_bits_equal(g, o, "offsets from %d, buffer %d" % (base, k))
