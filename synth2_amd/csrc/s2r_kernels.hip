@@ -724,6 +724,9 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
 #pragma unroll
         for (int q = 0; q < 4; ++q) xq[q] = stream_q[(size_t)q * 64u];      // 4 coalesced 16-byte loads, used last
     }
+    // a lane without a started voice: see a0 / ampq below.  Its filter history must be 0 for that (frames
+    // of the general path, which selects per frame instead, leave a running value in it)
+    if (!live) r.last = 0.0f;
     f4 amp[4], nz[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {

@@ -1,0 +1,106 @@
+"""Differential fuzzing of the HIP path against the oracle: random patches (every oscillator, every
+filter, degenerate envelope times, both modulation amounts), random pools / workgroup sizes / lanes
+per voice, random note traffic — untimed, timed at 16-frame boundaries, program changes over a patch
+bank — and ragged fill sizes.  Bit-exact mix (through the documented tree) on every buffer.
+Deterministic: the seeds are fixed; a failure names its seed."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import Pair, assert_bits_equal, make_patch, oracle_cfg_from_patch
+from oracle import s2o
+import synth2_amd as s2
+
+pytestmark = pytest.mark.gpu
+
+
+def random_patch(rng):
+    def ms():
+        r = rng.rand()
+        return 0.0 if r < 0.15 else float(rng.choice([0.5, 3.0, 20.0, 100.0, 250.0])) * float(rng.uniform(0.5, 1.5))
+    p = make_patch(osc_kind=int(rng.randint(0, 4)), osc_gain=float(rng.choice([0.0, 0.3, 1.0])),
+                   noise=float(rng.choice([0.0, 0.0, 0.2, 1.0])),
+                   lpf_freq=float(np.exp(rng.uniform(np.log(20.0), np.log(20000.0)))),
+                   mod_env_to_osc_freq=float(rng.choice([0.0, 0.0, 0.0, 1.5, -3.0, 10.0])),
+                   mod_env_to_lpf_freq=float(rng.choice([0.0, 10.0, 4.0, -6.0])),
+                   lpf_kind=int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8])),
+                   lpf_damping=float(rng.choice([0.2, 1.41421354, 3.0])), lpf_q=float(rng.choice([0.3, 3.0, 9.0])))
+    for env in (p.amp_env, p.mod_env):
+        env.attack_ms, env.decay_ms, env.release_ms = ms(), ms(), ms()
+        env.sustain = float(rng.choice([0.0, 0.5, 1.0, 0.123]))
+    return p
+
+
+# S2R_FUZZ_SEEDS=N widens the sweep, S2R_FUZZ_BASE moves it.  History: seed 293 found idle voices' rows coming
+# out as -0.0 after a general-path chunk; 2 x 1500 seeds run clean since
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("S2R_FUZZ_SEEDS", "40")))))
+def test_fuzz(seed):
+    rng = np.random.RandomState(int(os.environ.get("S2R_FUZZ_BASE", "1000")) + seed)
+    voices = int(rng.choice([8, 70, 300, 1000]))
+    block = int(rng.choice([0, 64, 128, 256, 512]))
+    lanes = int(rng.choice([0, 1, 1, 2, 4]))
+    if lanes == 2 and block > 256:
+        block = 256
+    if lanes == 4 and block > 256:
+        block = 256
+    groups = int(rng.choice([0, 0, 2, 3]))
+    max_frames = 1024
+    bank = [random_patch(rng) for _ in range(int(rng.choice([1, 1, 1, 2, 5])))]
+    pr = Pair(voices, bank[0], max_frames=max_frames, block_voices=block, mix_groups=groups, lanes=lanes)
+    if len(bank) > 1:
+        pr.set_bank(bank)
+    pr.gpu.set_coeff_stream(int(rng.choice([1, 1, 2, 0])))
+    sr = int(rng.choice([48000, 48000, 44100, 96000, 22050, 12345]))
+    held = []
+    what = "seed %d: %d voices, block %d, lanes %d, groups %d, %d patches, sr %d" % (seed, voices, block, lanes, groups, len(bank), sr)
+    for b in range(7):
+        frames = int(rng.choice([1024, 1024, 1000, 512, 256, 100, 17, 16]))
+        timed = len(bank) >= 1 and rng.rand() < 0.35 and frames >= 32
+        n_ev = int(rng.randint(0, 30)) if b else int(rng.randint(voices // 2, voices + 5))
+        if timed:
+            times = np.sort(rng.randint(0, frames // 16, n_ev)) * 16
+            rows = []
+            for t in times:
+                if len(bank) > 1 and rng.rand() < 0.3:
+                    rows.append((2, int(rng.randint(len(bank))), int(t), 0.0))
+                on = (not held) or rng.rand() < 0.6
+                if on:
+                    note = int(rng.randint(20, 110)); held.append(note)
+                else:
+                    note = held.pop(int(rng.randint(len(held))))
+                rows.append((1 if on else 0, note, int(t), 1.0))
+            ev = np.array(rows, dtype=s2.NOTE_EVENT_DTYPE) if rows else np.zeros(0, dtype=s2.NOTE_EVENT_DTYPE)
+            pr.gpu.note_events(ev)
+            g = pr.gpu.sample(np.empty(frames, dtype=np.float32), sr)
+            pv = np.zeros((voices, frames), dtype=np.float32)
+            k = 0
+            for c in range(0, frames, 16):
+                while k < len(ev) and ev["frame"][k] == c:
+                    if ev["kind"][k] == 2:
+                        pr.cpu.program_change(int(ev["note"][k]))
+                    elif ev["kind"][k] == 1:
+                        pr.cpu.note_on(int(ev["note"][k]))
+                    else:
+                        pr.cpu.note_off(int(ev["note"][k]))
+                    k += 1
+                n = min(16, frames - c)
+                with np.errstate(all="ignore"):
+                    pv[:, c:c + n] = pr.cpu.render_voices(n, sr)
+            assert k == len(ev)
+            o = s2o.mix_tree(pv, pr.block_voices, pr.groups)
+            assert_bits_equal(g, o, what + ", buffer %d (%d frames, timed events)" % (b, frames))
+        else:
+            for _ in range(n_ev):
+                if len(bank) > 1 and rng.rand() < 0.3:
+                    pr.program_change(int(rng.randint(len(bank))))
+                if (not held) or rng.rand() < 0.6:
+                    note = int(rng.randint(20, 110)); held.append(note); pr.note_on(note)
+                else:
+                    pr.note_off(held.pop(int(rng.randint(len(held)))))
+            with np.errstate(all="ignore"):
+                if rng.rand() < 0.3:
+                    g, o = pr.render_voices(frames, sr)
+                else:
+                    g, o, _pv = pr.sample(frames, sr)
+            assert_bits_equal(g, o, what + ", buffer %d (%d frames)" % (b, frames))
