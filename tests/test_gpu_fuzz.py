@@ -47,7 +47,8 @@ def test_fuzz(seed):
     groups = int(rng.choice([0, 0, 2, 3]))
     max_frames = 1024
     bank = [random_patch(rng) for _ in range(int(rng.choice([1, 1, 1, 2, 5])))]
-    pr = Pair(voices, bank[0], max_frames=max_frames, block_voices=block, mix_groups=groups, lanes=lanes)
+    seeds = rng.randint(0, 2 ** 31, voices).astype(np.uint64) if rng.rand() < 0.15 else None   # NoiseState.seed overrides
+    pr = Pair(voices, bank[0], max_frames=max_frames, block_voices=block, mix_groups=groups, lanes=lanes, seeds=seeds)
     if len(bank) > 1:
         pr.set_bank(bank)
     pr.gpu.set_coeff_stream(int(rng.choice([1, 1, 2, 0])))
@@ -55,6 +56,11 @@ def test_fuzz(seed):
     held = []
     what = "seed %d: %d voices, block %d, lanes %d, groups %d, %d patches, sr %d" % (seed, voices, block, lanes, groups, len(bank), sr)
     for b in range(7):
+        if b and rng.rand() < 0.15:                      # checkpoint round trip between two buffers
+            pr.gpu.import_state(pr.gpu.export_state())
+        if b and len(bank) == 1 and rng.rand() < 0.15:   # the patch is swapped under sounding voices
+            bank = [random_patch(rng)]
+            pr.gpu.set_patch(bank[0]); pr.cpu.config = oracle_cfg_from_patch(bank[0])
         frames = int(rng.choice([1024, 1024, 1000, 512, 256, 100, 17, 16]))
         timed = len(bank) >= 1 and rng.rand() < 0.35 and frames >= 32
         n_ev = int(rng.randint(0, 30)) if b else int(rng.randint(voices // 2, voices + 5))
@@ -80,7 +86,10 @@ def test_fuzz(seed):
                     if ev["kind"][k] == 2:
                         pr.cpu.program_change(int(ev["note"][k]))
                     elif ev["kind"][k] == 1:
+                        vi = pr.cpu.next_voice_index()
                         pr.cpu.note_on(int(ev["note"][k]))
+                        if pr.seeds is not None:
+                            pr.cpu.set_seed(vi, int(pr.seeds[vi]))
                     else:
                         pr.cpu.note_off(int(ev["note"][k]))
                     k += 1
