@@ -113,3 +113,68 @@ def test_fuzz(seed):
                 else:
                     g, o, _pv = pr.sample(frames, sr)
             assert_bits_equal(g, o, what + ", buffer %d (%d frames)" % (b, frames))
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("S2R_FUZZ_SEEDS", "40")) // 4)))
+def test_fuzz_shards(seed):
+    """the multi-GPU path on one card: R shard handles over the same pool, fed the same random traffic
+    (untimed, timed, program changes), their partial rows checked one by one against the oracle's shard
+    tree and their rank-ordered sum against the oracle's whole-pool tree with R groups"""
+    import torch
+    rng = np.random.RandomState(int(os.environ.get("S2R_FUZZ_BASE", "1000")) * 7 + seed)
+    ranks = int(rng.choice([2, 3, 4]))
+    block = int(rng.choice([64, 128, 256]))
+    per = block * int(rng.choice([1, 2, 3]))
+    voices = per * ranks
+    bank = [random_patch(rng) for _ in range(int(rng.choice([1, 1, 3])))]
+    ora = s2o.OracleSynth(voices)
+    ora.set_bank([oracle_cfg_from_patch(p) for p in bank])
+    sh = [s2.Synth(voices, max_frames=1024, shard_begin=r * per, shard_voices=per, block_voices=block) for r in range(ranks)]
+    for s in sh:
+        s.set_patch_bank(bank)
+    st = torch.cuda.current_stream().cuda_stream
+    held = []
+    for b in range(5):
+        frames = int(rng.choice([1024, 1000, 256, 48]))
+        timed = b > 0 and rng.rand() < 0.4
+        n_ev = int(rng.randint(0, 40)) if b else int(rng.randint(voices // 2, voices + 5))
+        times = np.sort(rng.randint(0, frames // 16, n_ev)) * 16 if timed else np.zeros(n_ev, dtype=np.int64)
+        rows = []
+        for t in times:
+            if len(bank) > 1 and rng.rand() < 0.3:
+                rows.append((2, int(rng.randint(len(bank))), int(t), 0.0))
+            on = (not held) or rng.rand() < 0.6
+            if on:
+                note = int(rng.randint(20, 110)); held.append(note)
+            else:
+                note = held.pop(int(rng.randint(len(held))))
+            rows.append((1 if on else 0, note, int(t), 1.0))
+        ev = np.array(rows, dtype=s2.NOTE_EVENT_DTYPE) if rows else np.zeros(0, dtype=s2.NOTE_EVENT_DTYPE)
+        part = torch.empty((ranks, frames), dtype=torch.float32, device="cuda")
+        out = torch.empty(frames, dtype=torch.float32, device="cuda")
+        for r, s in enumerate(sh):
+            s.note_events(ev)                                  # every rank sees the whole stream
+            s.fill_device(part[r].data_ptr(), frames, SR, st)
+        s2.sum_partials_device(part.data_ptr(), ranks, frames, out.data_ptr(), st)
+        torch.cuda.synchronize()
+        pv = np.zeros((voices, frames), dtype=np.float32)
+        k = 0
+        for c in range(0, frames, 16):
+            while k < len(ev) and ev["frame"][k] == c:
+                if ev["kind"][k] == 2:
+                    ora.program_change(int(ev["note"][k]))
+                elif ev["kind"][k] == 1:
+                    ora.note_on(int(ev["note"][k]))
+                else:
+                    ora.note_off(int(ev["note"][k]))
+                k += 1
+            n = min(16, frames - c)
+            with np.errstate(all="ignore"):
+                pv[:, c:c + n] = ora.render_voices(n, SR)
+        what = "shard seed %d: %d ranks x %d voices, block %d, buffer %d (%d frames%s)" % (seed, ranks, per, block, b, frames, ", timed" if timed else "")
+        for r in range(ranks):
+            assert_bits_equal(part[r].cpu().numpy(), s2o.mix_tree_partial(pv[r * per:(r + 1) * per], block), what + ", partial of rank %d" % r)
+        assert_bits_equal(out.cpu().numpy(), s2o.mix_tree(pv, block, ranks), what + ", combined")
+
+
+SR = 48000
