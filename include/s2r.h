@@ -224,6 +224,15 @@ const char *s2r_status_string(int status);
 /* ---- host-only helpers: usable without a device (front-ends that route events to shards,
  * CPU-only tests of the host logic) ---- */
 
+/* The wire format of the reference's (disabled) websocket audio server, one text frame per buffer:
+ * serde_json::to_string(&Vec<f32>) (threads.rs:303-305; BUFFER_SIZE = 4096 frames, 32 kHz mono,
+ * threads.rs:6,263; consumer www/streamer.js:82-90).  Writes a NUL-terminated JSON array into `out`
+ * and returns its length; when `out` is NULL or `cap` is below the worst case (3 + 16 n) it writes
+ * nothing and returns the capacity to provide.  Host-only. */
+#define S2R_STREAM_FRAMES 4096u
+#define S2R_STREAM_RATE_HZ 32000u
+size_t s2r_stream_frame_json(const float *samples, size_t n, char *out, size_t cap);
+
 /* The .synth2 parser on its own; err_buf (may be NULL) receives a message on failure. */
 int s2r_parse_patch_text(const char *text, size_t len, s2r_patch *out, char *err_buf, size_t err_cap);
 

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libs2r.so")
-SOURCES = ["s2r_kernels.hip", "s2r_host.cpp", "s2r_patch.cpp"]
+SOURCES = ["s2r_kernels.hip", "s2r_host.cpp", "s2r_patch.cpp", "s2r_stream.cpp"]
 HEADERS = ["s2r_device.h", "s2r_math.h", "s2r_patch.h", "s2r_voices.h"]
 # -amdgpu-sched-strategy=max-ilp: the render kernels run one wavefront per SIMD (64 k voices =
 # 1024 waves), so nothing hides a dependent instruction's latency except independent work of the

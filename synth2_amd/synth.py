@@ -128,6 +128,7 @@ def load_library():
         "s2r_load_patch": (C.c_int, [H, C.c_char_p, C.c_size_t]),
         "s2r_set_patch": (C.c_int, [H, C.POINTER(Patch)]),
         "s2r_get_patch": (C.c_int, [H, C.POINTER(Patch)]),
+        "s2r_stream_frame_json": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t]),
         "s2r_set_patch_bank": (C.c_int, [H, C.POINTER(Patch), C.c_uint32]),
         "s2r_patch_bank_size": (C.c_uint32, [H]),
         "s2r_program_change": (C.c_int, [H, C.c_uint32]),
@@ -188,6 +189,17 @@ def parse_patch(text):
     if rc != S2R_OK:
         raise S2rError(rc, err.value.decode())
     return p
+
+
+def stream_frame_json(samples):
+    """one buffer as the text frame of the reference's websocket audio server (threads.rs:303-305):
+    serde_json's rendering of a Vec<f32> (host only, no device needed)"""
+    L = load_library()
+    a = np.ascontiguousarray(samples, dtype=np.float32)
+    cap = 3 + 16 * a.size
+    buf = C.create_string_buffer(cap)
+    n = L.s2r_stream_frame_json(a.ctypes.data_as(C.c_void_p), a.size, buf, cap)
+    return buf.raw[:n].decode("ascii")
 
 
 class VoicePool:

@@ -156,3 +156,48 @@ def test_voice_pool_many_steals_of_a_held_note_stays_bounded():
         pool.note_on(60)
         pool.advance(16)
     assert pool.note_off(60) in (0, 1, 2, 3)
+
+
+def _serde_f32(v):
+    """serde_json's rendering of one f32, restated independently of the C++ (digits from numpy's
+    shortest-round-trip printer, layout by ryu's format32 rules)"""
+    v = np.float32(v)
+    if not np.isfinite(v):
+        return "null"
+    sign = "-" if np.signbit(v) else ""
+    v = abs(v)
+    if v == 0:
+        return sign + "0.0"
+    sci = np.format_float_scientific(v, unique=True, trim="-", exp_digits=1)     # d.ddde-7 / de+12
+    mant, exp = sci.split("e")
+    digits = mant.replace(".", "")
+    n, k = len(digits), int(exp) - (len(digits) - 1)
+    kk = n + k
+    if 0 <= k and kk <= 13:
+        return sign + digits + "0" * k + ".0"
+    if 0 < kk <= 13:
+        return sign + digits[:kk] + "." + digits[kk:]
+    if -6 < kk <= 0:
+        return sign + "0." + "0" * (-kk) + digits
+    return sign + digits[0] + ("." + digits[1:] if n > 1 else "") + "e" + str(kk - 1)
+
+
+def test_stream_frame_json_is_serde_json_for_vec_f32():
+    """threads.rs:303-305 `serde_json::to_string(&buffer32)`: layout rules, null for non-finite values,
+    and — the property the consumer (www/streamer.js JSON.parse) needs — every number reads back as
+    the same f32"""
+    import json
+    edge = np.array([0.0, -0.0, 1.0, -1.5, 0.1, 1e-7, 1.5e-7, 123456.78, 1e13, 1e12, 9999999e6, 16777216.0, 3.4028235e38,
+                     1e-45, 1.17549435e-38, 0.001234, 1e-5, 1e-6, 0.30000001192092896, np.nan, np.inf, -np.inf], dtype=np.float32)
+    assert s2.stream_frame_json(edge[:8]) == "[0.0,-0.0,1.0,-1.5,0.1,1e-7,1.5e-7,123456.78]"
+    rng = np.random.RandomState(5)
+    bits = rng.randint(0, 2 ** 32, 60000, dtype=np.uint64).astype(np.uint32)
+    audio = (rng.standard_normal(4096) * 0.3).astype(np.float32)           # what a frame really holds
+    for x in (edge, bits.view(np.float32), audio):
+        text = s2.stream_frame_json(x)
+        assert text == "[" + ",".join(_serde_f32(v) for v in x) + "]"
+        back = np.array([np.nan if v is None else v for v in json.loads(text)], dtype=np.float32)
+        fin = np.isfinite(x)
+        assert np.array_equal(back[fin].view(np.uint32), x[fin].view(np.uint32))
+        assert np.all(np.isnan(back[~fin]))
+    assert s2.stream_frame_json(np.zeros(0, dtype=np.float32)) == "[]"
