@@ -98,8 +98,8 @@ typedef struct {
     uint32_t mix_groups;           /* >= 1: second-level grouping of the block partials so a
                                       1-GPU run reproduces the G-GPU summation order; 0 => 1 */
     uint32_t lanes_per_voice;      /* 1, 2 or 4 GPU lanes cooperating on one voice (a pure
-                                      scheduling knob: results are bit-identical); 0 => auto
-                                      from the shard size */
+                                      scheduling knob: results are bit-identical); 0 => 1,
+                                      the fastest at every pool size */
 } s2r_config;
 
 /* One voice's complete state, for checkpoint/resume and tests.

@@ -445,11 +445,12 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
     s->padded_voices = s->n_blocks * bv;
     s->mix_groups = cfg->mix_groups ? cfg->mix_groups : 1u;
     {
-        // lanes per voice: below one wave per SIMD (64 k voices at one lane per voice are exactly
-        // one wave on each of the 1024 SIMDs) spread a voice over 2 or 4 lanes to fill the chip;
-        // above that the 4-frame ILP of a single lane is the faster way (measured)
+        // lanes per voice: one.  Spreading a voice over 2 or 4 lanes (more waves for small pools) was
+        // the faster shape before the 4-frame vectors and the branch-free runs, which exist for one lane
+        // per voice only; since then L = 1 wins at every pool size (1024 voices x 1024 frames: 0.064 ms
+        // against 0.175 ms at L = 4).  2 and 4 remain as a bit-identical knob.
         uint32_t l = cfg->lanes_per_voice;
-        if (l == 0) l = shard_voices >= 65536u ? 1u : (shard_voices >= 32768u ? 2u : 4u);
+        if (l == 0) l = 1u;
         while (l > 1 && (bv * l > 1024u || (l == 2 && bv > 256u))) l >>= 1;
         if (l != 1 && l != 2 && l != 4) { delete s; return S2R_ERR_INVALID; }
         s->lanes = l;
