@@ -214,8 +214,10 @@ int s2r_set_timing(s2r_synth *s, int enabled);
 int s2r_set_flat_shortcut(s2r_synth *s, int enabled);
 /* Measurement knob (default 1): 64-voice groups whose mod envelope moves during a fill get
  * their LPF coefficients computed ahead of the render kernel instead of in-lane.
- * 0: off; 1: on, and a fill with few untimed events applies them in the classification launch
- * (events in the kernel arguments); 2: on, always with the separate events kernel.  Same bits. */
+ * 0: off; 1: on (for fills of >= 128 frames over shards of >= 1024 voices — shorter or smaller
+ * work is quicker without the extra launches), and a fill with few untimed events applies them in
+ * the classification launch (events in the kernel arguments); 2: like 1 but always with the separate
+ * events kernel; 3 / 4: like 1 / 2 for every fill size and shard size (tests).  Same bits. */
 int s2r_set_coeff_stream(s2r_synth *s, int enabled);
 float s2r_last_render_ms(s2r_synth *s);
 const char *s2r_last_error(const s2r_synth *s);             /* never NULL */

@@ -130,7 +130,7 @@ struct s2r_synth {
     float *per_voice_dev = nullptr; size_t per_voice_cap = 0;
     // coefficient stream (s2r_kernels.hip)
     int32_t *group_slot = nullptr; uint32_t *slot_group = nullptr; uint32_t *coeff_count = nullptr; float *coeff = nullptr;
-    uint32_t coeff_capacity = 0, coeff_parity = 0; bool use_coeff = true, use_prep = true;
+    uint32_t coeff_capacity = 0, coeff_parity = 0; bool use_coeff = true, use_prep = true, force_stream = false;
     float pitch_table[256];
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool timing = false, timed = false, no_flat_shortcut = false;
@@ -234,6 +234,16 @@ int check_fill(s2r_synth *s, size_t frames, uint32_t sample_rate) {
     return S2R_OK;
 }
 
+// The coefficient stream (and with it the classification launch) pays when a fill has many chunks
+// and the shard many waves; a 16-frame fill of a handful of voices — s2_bin's own call pattern,
+// main.rs:138-143 — is quicker without the two extra launches (28 -> 22 us per call).  Only where it is
+// defined: one-pole patch, no oscillator FM, the flat-envelope logic enabled.
+bool stream_wanted(const s2r_synth *s, size_t frames) {
+    return s->use_coeff && !s->no_flat_shortcut && s->coeff != nullptr && s->bank.size() == 1 &&
+           s->bank[0].mod_env_to_osc_freq == 0.0f && s->bank[0].lpf_kind == S2R_FILT_ONEPOLE &&
+           (s->force_stream || (frames >= 128 && s->shard_voices >= 1024u));
+}
+
 S2rRenderParams make_params(s2r_synth *s, size_t frames, uint32_t sample_rate) {
     S2rRenderParams p{};
     p.osc_kind = s->bank[0].osc_kind;
@@ -260,8 +270,7 @@ S2rRenderParams make_params(s2r_synth *s, size_t frames, uint32_t sample_rate) {
     p.per_voice = nullptr;
     p.sin_table = s->sin_dev;
     // stream only where it is defined: no oscillator FM, the flat-envelope logic enabled
-    p.use_coeff = (s->use_coeff && !s->no_flat_shortcut && s->bank[0].mod_env_to_osc_freq == 0.0f && s->coeff != nullptr &&
-                   s->bank[0].lpf_kind == S2R_FILT_ONEPOLE && s->bank.size() == 1) ? 1 : 0;
+    p.use_coeff = stream_wanted(s, frames) ? 1 : 0;
     p.bank = s->bank_dev;
     p.bank_size = (uint32_t)s->bank.size();
     p.group_slot = s->group_slot; p.group_slot_w = s->group_slot; p.slot_group = s->slot_group;
@@ -276,9 +285,8 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
     // The common case — a one-pole patch without oscillator FM, a handful of untimed events without
     // seed overrides — is prepared by two launches (events + classification with the events in the
     // kernel arguments, then the coefficient pass) instead of three.
-    bool one_launch = s->use_prep && s->use_coeff && !s->no_flat_shortcut && s->coeff != nullptr && s->bank.size() == 1 &&
-                      s->bank[0].mod_env_to_osc_freq == 0.0f && s->bank[0].lpf_kind == S2R_FILT_ONEPOLE &&
-                      frames >= 16 && s->tpending.empty() && s->pending.size() <= S2R_PREP_MAX_EVENTS;
+    bool one_launch = s->use_prep && stream_wanted(s, frames) && frames >= 16 && s->tpending.empty() &&
+                      s->pending.size() <= S2R_PREP_MAX_EVENTS;
     if (one_launch)
         for (const S2rVoiceEvent &e : s->pending) if (e.seed != 0u) { one_launch = false; break; }
     EventSlot *timed_slot = nullptr;
@@ -814,7 +822,8 @@ int s2r_set_flat_shortcut(s2r_synth *s, int enabled) {
 int s2r_set_coeff_stream(s2r_synth *s, int enabled) {
     if (!s) return S2R_ERR_INVALID;
     s->use_coeff = enabled != 0;
-    s->use_prep = enabled != 2;              // 2: coefficient stream through the separate kernels only
+    s->use_prep = enabled != 2 && enabled != 4;   // 2, 4: coefficient stream through the separate kernels only
+    s->force_stream = enabled >= 3;               // 3, 4: also for short fills and small shards (tests)
     return S2R_OK;
 }
 

@@ -365,8 +365,9 @@ class Synth:
         self._check(self.L.s2r_set_flat_shortcut(self.h, 1 if enabled else 0))
 
     def set_coeff_stream(self, enabled=True):
-        """False/0: coefficients in-lane; True/1: ahead-of-time stream (events applied by the classification launch
-        when the fill allows it); 2: stream through the separate events/classify/coefficient kernels only"""
+        """False/0: coefficients in-lane; True/1: ahead-of-time stream for long fills over big shards (events applied
+        by the classification launch when the fill allows it); 2: same through the separate kernels only;
+        3 / 4: like 1 / 2 for every fill and shard size"""
         self._check(self.L.s2r_set_coeff_stream(self.h, int(enabled)))
 
     def set_timing(self, enabled=True):

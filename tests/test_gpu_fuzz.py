@@ -51,7 +51,7 @@ def test_fuzz(seed):
     pr = Pair(voices, bank[0], max_frames=max_frames, block_voices=block, mix_groups=groups, lanes=lanes, seeds=seeds)
     if len(bank) > 1:
         pr.set_bank(bank)
-    pr.gpu.set_coeff_stream(int(rng.choice([1, 1, 2, 0])))
+    pr.gpu.set_coeff_stream(int(rng.choice([1, 3, 3, 4, 0])))
     sr = int(rng.choice([48000, 48000, 44100, 96000, 22050, 12345]))
     held = []
     what = "seed %d: %d voices, block %d, lanes %d, groups %d, %d patches, sr %d" % (seed, voices, block, lanes, groups, len(bank), sr)

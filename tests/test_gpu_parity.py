@@ -76,14 +76,14 @@ def test_c2_1024_voices_blocks_of_256(lanes):
 
 
 @pytest.mark.parametrize("lanes", [1, 2, 4])
-@pytest.mark.parametrize("stream", [1, 2, 0])
+@pytest.mark.parametrize("stream", [3, 4, 1, 0])
 def test_coefficient_stream_is_bit_neutral(stream, lanes):
     """64-voice groups with a moving mod envelope get their LPF coefficients from the ahead-of-time
     pass; with it off they are computed in-lane.  Mixed population: some groups fully flat, some
     partly moving, some restarted mid-run, ragged fills (tail frames bypass the stream)."""
     V = 1024
     pr = Pair(V, lanes=lanes, max_frames=1024)
-    pr.gpu.set_coeff_stream(stream)      # 1: one preparation launch where possible, 2: separate kernels, 0: in-lane
+    pr.gpu.set_coeff_stream(stream)      # 3: events in the classification launch where possible, 4: separate kernels, 1: default policy, 0: in-lane
     for v in range(V):
         pr.note_on(36 + v % 61)          # 1024 events: more than one launch carries -> separate kernels
     for b, n in enumerate([1024, 1024, 512, 1000, 1024, 16, 1024, 1024, 1024, 1024, 1024, 1024]):
@@ -97,7 +97,7 @@ def test_coefficient_stream_is_bit_neutral(stream, lanes):
         assert_bits_equal(g, o, "stream=%s lanes=%d buffer %d" % (stream, lanes, b))
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [3, 4])
 def test_coefficient_stream_every_group_moving(mode):
     """every group moving at once (the stream has a slot per group), events arriving in batches on
     both sides of what one preparation launch carries (288), releases folded onto restarts"""
