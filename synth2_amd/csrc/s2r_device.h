@@ -74,6 +74,9 @@ struct S2rRenderParams {
     uint32_t super_frames;  // frames between two cross-wave combines (set by the launcher)
     S2rVoiceArrays v;
     float *block_partials;   // [n_blocks][frames_stride]
+    float *direct_out;       // single-workgroup shard with the root add: the final mix, written by the render
+                             // kernel itself ((+0.0) + the block's sum, what s2r_mix_kernel computes for one row)
+    int32_t direct_stereo;   // interleaved L,R
     float *per_voice;        // [n_voices][frames] or nullptr (mix-disabled debug/parity path)
     const float *sin_table;  // 1024 floats (tables.rs)
     // coefficient stream: LPF coefficients of the 64-voice groups whose mod

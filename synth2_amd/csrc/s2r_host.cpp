@@ -125,7 +125,8 @@ struct s2r_synth {
     void *voice_mem = nullptr;
     float *block_partials = nullptr;
     float *out_dev = nullptr;
-    float *out_host = nullptr;                   // pinned, 2*max_frames
+    float *out_host = nullptr;                   // pinned and device-mapped, 2*max_frames
+    float *out_host_dev = nullptr;               // the device's view of out_host
     float *sin_dev = nullptr;
     float *per_voice_dev = nullptr; size_t per_voice_cap = 0;
     // coefficient stream (s2r_kernels.hip)
@@ -336,6 +337,9 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
     } else {
         p.use_coeff = 0;       // nothing was prepared for this fill
     }
+    // a shard of one workgroup needs no mix launch: its only partial row, root-added, is the output
+    const bool direct = dev_out != nullptr && root_add && s->n_blocks == 1;
+    if (direct) { p.direct_out = dev_out; p.direct_stereo = stereo ? 1 : 0; }
     if (s->timing) S2R_HIP(s, hipEventRecord(s->t0, stream));      // brackets the render kernel alone
     S2R_HIP(s, s2r_launch_render(p, s->block_voices, s->lanes, stream));
     if (s->timing) { S2R_HIP(s, hipEventRecord(s->t1, stream)); s->timed = true; }
@@ -343,7 +347,7 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
         S2R_HIP(s, hipEventRecord(timed_slot->done, stream));
         timed_slot->in_flight = true;
     }
-    if (dev_out) {
+    if (dev_out && !direct) {
         S2rMixParams m{};
         m.block_partials = s->block_partials;
         m.n_blocks = s->n_blocks;
@@ -367,10 +371,11 @@ int fill_host(s2r_synth *s, float *out, size_t frames, uint32_t sample_rate, boo
     if (frames == 0) return S2R_OK;
     if (!out) return set_err(s, S2R_ERR_INVALID, "null output buffer");
     S2R_HIP(s, hipSetDevice(s->device));
-    rc = enqueue_fill(s, frames, sample_rate, s->stream, s->out_dev, true, stereo, nullptr);
+    // the last kernel of the fill writes the few KiB of output straight into mapped host memory: no copy
+    // command between the launch and the wait
+    rc = enqueue_fill(s, frames, sample_rate, s->stream, s->out_host_dev, true, stereo, nullptr);
     if (rc != S2R_OK) return rc;
     const size_t n = frames * (stereo ? 2 : 1);
-    S2R_HIP(s, hipMemcpyAsync(s->out_host, s->out_dev, n * sizeof(float), hipMemcpyDeviceToHost, s->stream));
     S2R_HIP(s, hipStreamSynchronize(s->stream));
     std::memcpy(out, s->out_host, n * sizeof(float));
     return S2R_OK;
@@ -501,7 +506,8 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
     CREATE_HIP(hipMalloc((void **)&s->bank_dev, S2R_MAX_BANK * sizeof(S2rBankEntry)));
     CREATE_HIP(hipMalloc((void **)&s->block_partials, (size_t)s->n_blocks * cfg->max_frames * sizeof(float)));
     CREATE_HIP(hipMalloc((void **)&s->out_dev, (size_t)2 * cfg->max_frames * sizeof(float)));
-    CREATE_HIP(hipHostMalloc((void **)&s->out_host, (size_t)2 * cfg->max_frames * sizeof(float), hipHostMallocDefault));
+    CREATE_HIP(hipHostMalloc((void **)&s->out_host, (size_t)2 * cfg->max_frames * sizeof(float), hipHostMallocMapped));
+    CREATE_HIP(hipHostGetDevicePointer((void **)&s->out_host_dev, s->out_host, 0));
     s->tev_capacity = shard_voices < 4096u ? 4096u : shard_voices;
     s->tlast.assign(shard_voices, -1);
     for (EventSlot &sl : s->slots) {

@@ -1080,6 +1080,11 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
             float acc = sW[(buf * n_groups + 0) * kSuper + f];
             for (uint32_t gq = 1; gq < n_groups; ++gq) acc += sW[(buf * n_groups + gq) * kSuper + f];
             bp[sc0 + f] = acc;
+            if (p.direct_out) {                                  // one workgroup: this IS the mix
+                const float total = 0.0f + acc;                  // accum = splat(0.0), synth.rs:176
+                if (p.direct_stereo) { p.direct_out[2u * (sc0 + f)] = total; p.direct_out[2u * (sc0 + f) + 1u] = total; }
+                else p.direct_out[sc0 + f] = total;
+            }
         }
         buf ^= 1u;
     }
@@ -1318,6 +1323,11 @@ __global__ void __launch_bounds__(1024) s2r_render_general_kernel(const S2rRende
             float acc = sW[(buf * n_groups + 0) * kSuper + f];
             for (uint32_t gq = 1; gq < n_groups; ++gq) acc += sW[(buf * n_groups + gq) * kSuper + f];
             bp[sc0 + f] = acc;
+            if (p.direct_out) {                                  // one workgroup: this IS the mix
+                const float total = 0.0f + acc;                  // accum = splat(0.0), synth.rs:176
+                if (p.direct_stereo) { p.direct_out[2u * (sc0 + f)] = total; p.direct_out[2u * (sc0 + f) + 1u] = total; }
+                else p.direct_out[sc0 + f] = total;
+            }
         }
         buf ^= 1u;
     }
