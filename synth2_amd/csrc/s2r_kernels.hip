@@ -179,7 +179,7 @@ __device__ __forceinline__ float line_fma(float rise, float run, float x, float 
 }
 
 // envelopes.rs:21-150 Adsr::sample (scalar tail path)
-__device__ float adsr_scalar(const S2rEnv &e, float t, float release_offset) {
+__device__ __forceinline__ float adsr_scalar(const S2rEnv &e, float t, float release_offset) {
     const float decay_offset = e.A, sustain_offset = e.sus_off;
     const float end_offset = release_offset + e.R;
     const bool in_release = t >= release_offset && t < end_offset;
@@ -488,10 +488,11 @@ __device__ __forceinline__ float dsp_filter_apply(int kind, const FiltCoef &c, f
         f.x1 = x; f.y1 = y;
         return y;
     }
-    const float xs = (kind == S2R_FILT_LP2) ? (x + 2.0f * f.x1 + f.x2)
-                   : (kind == S2R_FILT_HP2) ? (x - 2.0f * f.x1 + f.x2) : (x - f.x2);      // BP2: dsp_filters.rs:217-221
-    y = 2.0f * (c.alpha * xs + c.gamma * f.y1 - c.beta * f.y2);
-    f.x2 = f.x1; f.x1 = x; f.y2 = f.y1; f.y1 = y;
+    const float px1 = f.x1, px2 = f.x2, py1 = f.y1, py2 = f.y2;
+    const float xs = (kind == S2R_FILT_LP2) ? (x + 2.0f * px1 + px2)
+                   : (kind == S2R_FILT_HP2) ? (x - 2.0f * px1 + px2) : (x - px2);         // BP2: dsp_filters.rs:217-221
+    y = 2.0f * (c.alpha * xs + c.gamma * py1 - c.beta * py2);
+    f.x2 = px1; f.x1 = x; f.y2 = py1; f.y1 = y;
     return y;
 }
 
@@ -503,7 +504,7 @@ __device__ __forceinline__ float dsp_filter_step(int kind, float damping, float 
 // One frame of process_layer (scalar "sisd" path: process.rs:101-135,252-304).  DSPF: the layer's
 // filter is one of dsp_filters.rs (state in *f2) instead of the one-pole of filters.rs.
 template <int OSC, bool DSPF = false, class P = S2rRenderParams>
-__device__ float frame_sisd(const P &p, VoiceRegs &r, uint32_t oi,
+__device__ __forceinline__ float frame_sisd(const P &p, VoiceRegs &r, uint32_t oi,
                             const uint64_t *sT, const float *sSin, Filt2 *f2 = nullptr) {
     const float t = (float)oi;
     const float rel = r.released ? (float)r.release_u : 4294967296.0f;   // envelopes.rs:35
@@ -714,11 +715,14 @@ __global__ void __launch_bounds__(64) s2r_prep_kernel(const S2rPrepParams a) {
 //   off == period, where it is +0); no oscillator FM.
 //   SRC: 0 = every voice flat (constant coefficient), 1 = coefficient stream, 2 = compute in-lane.
 // ---------------------------------------------------------------------------------------
-template <int OSC, int SRC>
+//   FILT != 0 (general kernel, flat stages only): the layer's filter is dsp_filters.rs' / the SVF with the
+//   constant coefficients `fcoef`, state in *f2, instead of the one-pole.
+template <int OSC, int SRC, int FILT = 0>
 __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &r, const EnvRun &ea, const EnvRun &em,
                                            const FlatCache &fc, const OscK &k, uint32_t o_chunk, const f4 *stream_q,
                                            const uint64_t *sT, const float *sSin, bool live, float *tile_col,
-                                           uint32_t tile_stride, float *pv_dst) {
+                                           uint32_t tile_stride, float *pv_dst,
+                                           const FiltCoef *fcoef = nullptr, Filt2 *f2 = nullptr) {
     f4 xq[4];
     if (SRC == 1) {
 #pragma unroll
@@ -777,9 +781,16 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
                 osc = __builtin_fmaf((s2 - s1) / 1.0f, tv - (float)i1, s1);
             }
             const float s = (osc + p.osc_gain) + nz[q][j];
-            const float y = __builtin_fmaf(a0[j], s, xq[q][j] * r.last);
-            r.last = y;
-            const float out = y * ampq[j];
+            float out;
+            if (FILT == 0) {
+                const float y = __builtin_fmaf(a0[j], s, xq[q][j] * r.last);
+                r.last = y;
+                out = y * ampq[j];
+            } else {
+                // (a dead lane's filter state may run away on its made-up input: select per frame here)
+                const float y = dsp_filter_apply(FILT, *fcoef, s, *f2);
+                out = live ? y * amp[q][j] : 0.0f;
+            }
             tile_col[(4 * q + j) * tile_stride] = out;
             if (pv_dst) pv_dst[4 * q + j] = out;
         }
@@ -1138,8 +1149,8 @@ __device__ __forceinline__ LanePatch lane_patch_from_bank(const S2rBankEntry *ba
     return lp;
 }
 
-template <int OSC, bool BANK>
-__global__ void __launch_bounds__(1024) s2r_render_general_kernel(const S2rRenderParams p) {
+template <int OSC, bool BANK, int MAXT>
+__global__ void __launch_bounds__(MAXT) s2r_render_general_kernel(const S2rRenderParams p) {
     const uint32_t kSuper = p.super_frames;
     const bool PV = p.per_voice != nullptr, TEV = p.tev != nullptr;          // wave-uniform
     __shared__ uint64_t sT[S2R_EXP2F_N];
@@ -1273,6 +1284,47 @@ __global__ void __launch_bounds__(1024) s2r_render_general_kernel(const S2rRende
                 // base) + y0, the same bits on every frame) is looked at once instead of per frame
                 const bool flat = calm && __ballot(em.slope != 0.0f) == 0ull;
                 if (flat) refresh(env_value(em, (float)(r.offset + sc0 + c16)));
+                if (!BANK && flat) {
+                    // One patch, every lane's mod envelope flat: oscillator constants and filter coefficients are
+                    // constants of the run, so the branch-free chunk of the one-pole kernel applies with this
+                    // patch's filter in its recurrence.  Same run rule: the LAST frame of the run is below every
+                    // lane's next threshold.
+                    const uint32_t left = (n_x16 - c16) / kChunk;
+                    const uint32_t o_chunk = r.offset + sc0 + c16;
+                    auto clear_for = [&](uint32_t n) {
+                        return __ballot(!((float)(o_chunk + n * kChunk - 1u) < thr_min)) == 0ull;
+                    };
+                    uint32_t run = 1u;                           // `calm` already covers this chunk
+                    if (!TEV) { if (clear_for(left)) run = left; else if (left > 4u && clear_for(4u)) run = 4u; }
+                    if (__ballot(!(k.period > 0.0f && k.period < __builtin_inff() && r.phase >= 0.0f && r.phase < 1.0f)) != 0ull) run = 0u;
+                    if (run) {
+                        run = (uint32_t)__builtin_amdgcn_readfirstlane((int)run);
+                        FlatCache fcx; fcx.xc = xc; fcx.k = k;
+                        auto run_chunks = [&](auto filt_tag) {
+                            constexpr int FILT = decltype(filt_tag)::value;
+                            for (uint32_t i = 0; i < run; ++i) {
+                                const uint32_t f0 = c16 + i * kChunk;
+                                float *pvd = (PV && in_range) ? p.per_voice + pv_base + sc0 + f0 : nullptr;
+                                chunk_fast<(OSC == S2R_OSC_ANY ? 0 : OSC), 0, FILT>(p, r, ea, em, fcx, k, o_chunk + i * kChunk, nullptr, sT, sSin,
+                                                                                 live, tile + lane, VW + 1, pvd, &fc, &f2);
+                                reduce_chunk(f0, kChunk);
+                            }
+                        };
+                        switch (lp.lpf_kind) {                   // wave-uniform: the patch is a kernel argument here
+                        case S2R_FILT_LP1: run_chunks(std::integral_constant<int, S2R_FILT_LP1>{}); break;
+                        case S2R_FILT_HP1: run_chunks(std::integral_constant<int, S2R_FILT_HP1>{}); break;
+                        case S2R_FILT_LP2: run_chunks(std::integral_constant<int, S2R_FILT_LP2>{}); break;
+                        case S2R_FILT_HP2: run_chunks(std::integral_constant<int, S2R_FILT_HP2>{}); break;
+                        case S2R_FILT_BP2: run_chunks(std::integral_constant<int, S2R_FILT_BP2>{}); break;
+                        case S2R_FILT_SVF_LP: run_chunks(std::integral_constant<int, S2R_FILT_SVF_LP>{}); break;
+                        case S2R_FILT_SVF_BP: run_chunks(std::integral_constant<int, S2R_FILT_SVF_BP>{}); break;
+                        case S2R_FILT_SVF_HP: run_chunks(std::integral_constant<int, S2R_FILT_SVF_HP>{}); break;
+                        default: run_chunks(std::integral_constant<int, S2R_FILT_ONEPOLE>{}); break;
+                        }
+                        c16 += (run - 1u) * kChunk;
+                        continue;
+                    }
+                }
                 for (uint32_t j = 0; j < kChunk; ++j) {          // one frame of sample_voice_x16, process.rs:306-379
                     const uint32_t oi = r.offset + sc0 + c16 + j;            // wrapping u32 add (process.rs:213-219)
                     const float t = (float)oi;
@@ -1471,7 +1523,9 @@ hipError_t launch_general(const S2rRenderParams &p0, uint32_t block_voices, hipS
     const uint32_t n_waves = block_voices / 64, n_groups = n_waves * 4;
     p.super_frames = n_groups <= 16 ? kSuperMax : 64u;
     const size_t lds = sizeof(float) * ((size_t)2 * n_groups * p.super_frames + (size_t)n_waves * kChunk * 65);
-    hipLaunchKernelGGL((s2r_render_general_kernel<OSC, BANK>), dim3(grid), dim3(block_voices), lds, stream, p);
+    // the launch bound is the register budget (as for s2r_render_kernel): up to 256 threads get the whole file
+    if (block_voices <= 256) hipLaunchKernelGGL((s2r_render_general_kernel<OSC, BANK, 256>), dim3(grid), dim3(block_voices), lds, stream, p);
+    else hipLaunchKernelGGL((s2r_render_general_kernel<OSC, BANK, 1024>), dim3(grid), dim3(block_voices), lds, stream, p);
     return hipGetLastError();
 }
 

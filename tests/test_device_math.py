@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_device_math_matches_host_math(tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     exe = str(tmp_path / "dev_math_check")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
                            "-Wno-unused-value", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "synth2_amd", "csrc"),
                            os.path.join(ROOT, "tests", "native", "dev_math_check.hip"), "-o", exe])
     out = subprocess.run([exe, "257"], capture_output=True, text=True, timeout=900)
