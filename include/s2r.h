@@ -175,6 +175,13 @@ int s2r_fill(s2r_synth *s, float *mono_out, size_t frames, uint32_t sample_rate_
  * done on device: interleaved L,R with L == R. */
 int s2r_fill_stereo(s2r_synth *s, float *interleaved_lr_out, size_t frames, uint32_t sample_rate_hz);
 
+/* BUILD-DEFINED 4x oversampling (the reference has none; BASELINE config [4]): renders 4 * frames at
+ * 4 * sample_rate_hz through the same path and decimates the mix by a 63-tap windowed sinc whose history
+ * carries over from call to call (DESIGN.md 4.9 gives taps and arithmetic).  4 * frames must not exceed
+ * max_frames.  Voices' offsets, envelopes and filters all run at the oversampled rate. */
+#define S2R_OVERSAMPLE 4u
+int s2r_fill_oversampled(s2r_synth *s, float *mono_out, size_t frames, uint32_t sample_rate_hz);
+
 /* Multi-GPU building block: renders this shard and leaves its PARTIAL mix (no root add) in
  * `dev_partial_out` (device memory, `frames` floats) on `hip_stream` (a hipStream_t, may
  * be NULL) without synchronising.  Partials of all shards are then combined in rank order

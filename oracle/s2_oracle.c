@@ -252,6 +252,29 @@ float s2o_lpf_process(float *last, uint32_t sample_rate_u, float freq, float inp
     return out;
 }
 
+/* ------------------------------------------------------------------ build-defined 4x decimator */
+
+void s2o_decim4_taps(float *h) {
+    const double PI = 3.14159265358979323846, fc = 0.115;
+    double d[S2O_DECIM_TAPS], sum = 0.0;
+    for (int k = 0; k < S2O_DECIM_TAPS; k++) {
+        const double t = (double)(k - (S2O_DECIM_TAPS - 1) / 2);
+        const double ideal = t == 0.0 ? 2.0 * fc : sin(2.0 * PI * fc * t) / (PI * t);
+        const double w = 0.42 - 0.5 * cos(2.0 * PI * k / (S2O_DECIM_TAPS - 1)) + 0.08 * cos(4.0 * PI * k / (S2O_DECIM_TAPS - 1));
+        d[k] = ideal * w;
+        sum += d[k];
+    }
+    for (int k = 0; k < S2O_DECIM_TAPS; k++) h[k] = (float)(d[k] / sum);
+}
+
+void s2o_decimate4(const float *x, size_t n_out, const float *h, float *out) {
+    for (size_t n = 0; n < n_out; n++) {
+        float acc = 0.0f;
+        for (int k = 0; k < S2O_DECIM_TAPS; k++) acc = acc + h[k] * x[4 * n + (size_t)k];   /* x[0] is sample 4n-62 of the stream */
+        out[n] = acc;
+    }
+}
+
 /* ------------------------------------------------------------------ dsp_filters.rs */
 
 /* dsp_filters.rs:25-45 (LP1), :60-80 (HP1), :99-130 (LP2), :149-180 (HP2), :199-230 (BP2).  No

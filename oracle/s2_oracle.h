@@ -150,6 +150,14 @@ float s2o_lpf_process(float *last, uint32_t sample_rate, float freq, float input
 void s2o_modulate_freq_unipolar_x16(float freq, const float mod[16], float amount, float out[16]); /* process.rs:231-250 */
 float s2o_modulate_freq_unipolar(float freq, float mod, float amount);          /* process.rs:221-229 */
 float s2o_sleef_powf(float x, float y);                                         /* sleef::Sleef::pow */
+/* BUILD-DEFINED 4x oversampling (no counterpart in the reference; BASELINE config [4]): the path is rendered at
+ * 4 x the output rate and decimated by a 63-tap Blackman-windowed sinc (cutoff 0.115 cycles per input sample),
+ * taps computed in double and rounded to f32, each output = the taps applied in index order, product and sum
+ * rounded separately, over input samples 4n-62 .. 4n (62 samples of history precede the block). */
+#define S2O_DECIM_TAPS 63
+void s2o_decim4_taps(float *h63);
+void s2o_decimate4(const float *x_with_history, size_t n_out, const float *h63, float *out);
+
 /* dsp_filters.rs:25-230: one step of the first/second-order filters (kind = S2O_FILT_*);
  * `shape` is damping_factor for LP2/HP2, quality_factor for BP2, unused by LP1/HP1 */
 float s2o_dsp_filter_process(int kind, float *x1, float *x2, float *y1, float *y2,

@@ -111,6 +111,8 @@ def lib():
     L.s2o_modulate_freq_unipolar.argtypes = [C.c_float, C.c_float, C.c_float]
     L.s2o_sleef_powf.restype = C.c_float
     L.s2o_sleef_powf.argtypes = [C.c_float, C.c_float]
+    L.s2o_decim4_taps.argtypes = [_f32p]
+    L.s2o_decimate4.argtypes = [_f32p, C.c_size_t, _f32p, _f32p]
     _lib = L
     return L
 
@@ -189,6 +191,24 @@ class OracleSynth:
     @property
     def panicked(self):
         return bool(self.p.contents.panicked)
+
+
+def decim4_taps():
+    L = lib()
+    h = np.zeros(63, dtype=np.float32)
+    L.s2o_decim4_taps(_fp(h))
+    return h
+
+
+def decimate4(x_with_history, n_out):
+    """x_with_history: 62 samples of history followed by 4*n_out new samples"""
+    L = lib()
+    x = np.ascontiguousarray(x_with_history, dtype=np.float32)
+    assert x.size == 62 + 4 * n_out
+    h = decim4_taps()
+    out = np.zeros(n_out, dtype=np.float32)
+    L.s2o_decimate4(_fp(x), n_out, _fp(h), _fp(out))
+    return out
 
 
 def mix_sequential(per_voice):

@@ -127,6 +127,7 @@ struct s2r_synth {
     float *out_dev = nullptr;
     float *out_host = nullptr;                   // pinned and device-mapped, 2*max_frames
     float *out_host_dev = nullptr;               // the device's view of out_host
+    float *os_buf = nullptr, *os_taps = nullptr; // 4x oversampling: [62 history + max_frames] mix at 4x rate, 63 taps
     float *sin_dev = nullptr;
     float *per_voice_dev = nullptr; size_t per_voice_cap = 0;
     // coefficient stream (s2r_kernels.hip)
@@ -392,6 +393,8 @@ void release_all(s2r_synth *s) {
     }
     if (s->voice_mem) (void)hipFree(s->voice_mem);
     if (s->bank_dev) (void)hipFree(s->bank_dev);
+    if (s->os_buf) (void)hipFree(s->os_buf);
+    if (s->os_taps) (void)hipFree(s->os_taps);
     if (s->block_partials) (void)hipFree(s->block_partials);
     if (s->out_dev) (void)hipFree(s->out_dev);
     if (s->out_host) (void)hipHostFree(s->out_host);
@@ -690,6 +693,41 @@ int s2r_fill(s2r_synth *s, float *mono_out, size_t frames, uint32_t sample_rate_
 
 int s2r_fill_stereo(s2r_synth *s, float *interleaved_lr_out, size_t frames, uint32_t sample_rate_hz) {
     return fill_host(s, interleaved_lr_out, frames, sample_rate_hz, true);
+}
+
+int s2r_fill_oversampled(s2r_synth *s, float *mono_out, size_t frames, uint32_t sample_rate_hz) {
+    if (!s) return S2R_ERR_INVALID;
+    if (sample_rate_hz > 0xffffffffu / S2R_OVERSAMPLE) return set_err(s, S2R_ERR_INVALID, "sample rate too high to oversample");
+    const size_t os_frames = frames * S2R_OVERSAMPLE;
+    int rc = check_fill(s, os_frames, sample_rate_hz * S2R_OVERSAMPLE);
+    if (rc != S2R_OK) return rc;
+    if (frames == 0) return S2R_OK;
+    if (!mono_out) return set_err(s, S2R_ERR_INVALID, "null output buffer");
+    S2R_HIP(s, hipSetDevice(s->device));
+    constexpr uint32_t kTaps = 63;
+    if (!s->os_buf) {
+        // Blackman-windowed sinc, cutoff 0.115 cycles per input sample, unit DC gain; double arithmetic, rounded once
+        double d[kTaps], sum = 0.0;
+        const double PI = 3.14159265358979323846, fc = 0.115;
+        for (uint32_t k = 0; k < kTaps; k++) {
+            const double t = (double)((int)k - (int)(kTaps - 1) / 2);
+            const double ideal = t == 0.0 ? 2.0 * fc : std::sin(2.0 * PI * fc * t) / (PI * t);
+            const double w = 0.42 - 0.5 * std::cos(2.0 * PI * k / (kTaps - 1)) + 0.08 * std::cos(4.0 * PI * k / (kTaps - 1));
+            d[k] = ideal * w; sum += d[k];
+        }
+        float h[kTaps];
+        for (uint32_t k = 0; k < kTaps; k++) h[k] = (float)(d[k] / sum);
+        S2R_HIP(s, hipMalloc((void **)&s->os_taps, sizeof h));
+        S2R_HIP(s, hipMemcpy(s->os_taps, h, sizeof h, hipMemcpyHostToDevice));
+        S2R_HIP(s, hipMalloc((void **)&s->os_buf, ((size_t)(kTaps - 1) + s->cfg.max_frames) * sizeof(float)));
+        S2R_HIP(s, hipMemsetAsync(s->os_buf, 0, ((size_t)(kTaps - 1) + s->cfg.max_frames) * sizeof(float), s->stream));
+    }
+    rc = enqueue_fill(s, os_frames, sample_rate_hz * S2R_OVERSAMPLE, s->stream, s->os_buf + (kTaps - 1), true, false, nullptr);
+    if (rc != S2R_OK) return rc;
+    S2R_HIP(s, s2r_launch_decimate4(s->os_buf, s->os_taps, (uint32_t)frames, s->out_host_dev, s->stream));
+    S2R_HIP(s, hipStreamSynchronize(s->stream));
+    std::memcpy(mono_out, s->out_host, frames * sizeof(float));
+    return S2R_OK;
 }
 
 int s2r_fill_device(s2r_synth *s, float *dev_partial_out, size_t frames, uint32_t sample_rate_hz, void *hip_stream) {

@@ -1456,6 +1456,24 @@ __global__ void s2r_sum_rows_kernel(const float *rows, uint32_t n_rows, uint32_t
     out[f] = total;
 }
 
+// build-defined 4x decimator: out[n] = sum over k of h[k] * x[4n + k], taps in index order,
+// product and sum rounded separately
+constexpr int kDecimTaps = 63;
+__global__ void s2r_decimate4_kernel(const float *x, const float *h, uint32_t n_out, float *out) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_out) return;
+    float acc = 0.0f;
+    for (int k = 0; k < kDecimTaps; ++k) acc = acc + h[k] * x[4u * n + (uint32_t)k];
+    out[n] = acc;
+}
+__global__ void s2r_decimate4_history_kernel(float *x, uint32_t n_out) {
+    const uint32_t i = threadIdx.x;                              // one workgroup of 64: read, then write (ranges may overlap)
+    float v = 0.0f;
+    if (i < kDecimTaps - 1) v = x[4u * n_out + i];
+    __syncthreads();
+    if (i < kDecimTaps - 1) x[i] = v;
+}
+
 // publishes the first timed event of every touched voice
 __global__ void s2r_tev_heads_kernel(int32_t *heads, const S2rTimedEvent *tev, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1595,6 +1613,13 @@ hipError_t s2r_launch_events(const S2rVoiceArrays &v, const S2rVoiceEvent *dev_e
 hipError_t s2r_launch_tev_heads(int32_t *heads, const S2rTimedEvent *tev, uint32_t n, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(s2r_tev_heads_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, heads, tev, n);
+    return hipGetLastError();
+}
+
+hipError_t s2r_launch_decimate4(float *x_with_history, const float *taps, uint32_t n_out, float *out, hipStream_t stream) {
+    if (n_out == 0) return hipSuccess;
+    hipLaunchKernelGGL(s2r_decimate4_kernel, dim3((n_out + 255) / 256), dim3(256), 0, stream, x_with_history, taps, n_out, out);
+    hipLaunchKernelGGL(s2r_decimate4_history_kernel, dim3(1), dim3(64), 0, stream, x_with_history, n_out);
     return hipGetLastError();
 }
 

@@ -139,6 +139,7 @@ def load_library():
         "s2r_note_events": (C.c_int, [H, C.c_void_p, C.c_size_t]),
         "s2r_fill": (C.c_int, [H, _f32p, C.c_size_t, C.c_uint32]),
         "s2r_fill_stereo": (C.c_int, [H, _f32p, C.c_size_t, C.c_uint32]),
+        "s2r_fill_oversampled": (C.c_int, [H, _f32p, C.c_size_t, C.c_uint32]),
         "s2r_fill_device": (C.c_int, [H, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
         "s2r_fill_device_root": (C.c_int, [H, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
         "s2r_sum_partials_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_size_t, C.c_void_p, C.c_void_p]),
@@ -325,6 +326,12 @@ class Synth:
         assert buffer.dtype == np.float32 and buffer.flags["C_CONTIGUOUS"] and buffer.ndim == 1
         self._check(self.L.s2r_fill(self.h, buffer.ctypes.data_as(_f32p), buffer.size, int(sample_rate)))
         return buffer
+
+    def sample_oversampled(self, frames, sample_rate=SampleRateKhz(48000)):
+        """build-defined 4x oversampling: rendered at 4 * sample_rate, decimated to `frames` samples"""
+        out = np.empty(frames, dtype=np.float32)
+        self._check(self.L.s2r_fill_oversampled(self.h, out.ctypes.data_as(_f32p), frames, int(sample_rate)))
+        return out
 
     def sample_stereo(self, frames, sample_rate=SampleRateKhz(48000)):
         out = np.empty(2 * frames, dtype=np.float32)

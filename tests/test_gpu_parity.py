@@ -791,3 +791,26 @@ def test_very_old_voices_on_the_branch_free_path(base):
     for k in range(4):
         g, o = pr.render_voices(1024 if k != 2 else 1000)
         assert_bits_equal(g, o, "offsets from %d, buffer %d" % (base, k))
+
+
+@pytest.mark.parametrize("kind", [s2.FILT_ONEPOLE, s2.FILT_SVF_LP])
+def test_oversampled_4x_fill(kind):
+    """BASELINE config [4]'s shape end to end (build-defined, self-oracle): the path rendered at 192 kHz
+    and decimated to 48 kHz by the 63-tap filter, history carried from call to call; ragged sizes"""
+    patch = make_patch(osc_kind=s2.OSC_SAW, lpf_kind=kind, lpf_freq=3000.0, mod_env_to_lpf_freq=2.0, lpf_q=2.0)
+    pr = Pair(300, patch, max_frames=4096)
+    for v in range(200):
+        pr.note_on(28 + (v * 7) % 90)
+    hist = np.zeros(62, dtype=np.float32)
+    for b, frames in enumerate([1024, 1024, 500, 1, 37, 1024]):
+        g = pr.gpu.sample_oversampled(frames, SR)
+        pv = pr.cpu.render_voices(4 * frames, 4 * SR)
+        x = np.concatenate([hist, s2o.mix_tree(pv, pr.block_voices, 1)])
+        o = s2o.decimate4(x, frames)
+        hist = x[-62:]
+        assert_bits_equal(g, o, "oversampled, filter %d, buffer %d (%d frames)" % (kind, b, frames))
+        if b == 2:
+            for n in range(28, 118, 4):
+                pr.note_off(n)
+    with pytest.raises(s2.S2rError):
+        pr.gpu.sample_oversampled(1025, SR)              # 4 x 1025 > max_frames

@@ -300,3 +300,16 @@ def test_dsp_filters_restatement_properties():
     y = L.s2o_dsp_filter_process(1, st[0], st[1], st[2], st[3], 48000, 1000.0, 1.0, 0.5)
     assert abs(y - float(alpha * f(0.5))) <= 1e-9
     assert st[0].value == 0.5 and st[2].value == y
+
+
+def test_decimator_taps_are_a_sane_lowpass():
+    """the build-defined 4x decimator: unit DC gain, linear phase, >= 70 dB down from 0.16 cycles per input
+    sample (what lies above folds to below 17 kHz at 48 kHz out), within 1 dB up to 0.08 (15 kHz)"""
+    h = s2o.decim4_taps().astype(np.float64)
+    assert h.size == 63 and abs(h.sum() - 1.0) < 1e-6
+    assert np.allclose(h, h[::-1], atol=1e-9)
+    f = np.linspace(0.16, 0.5, 400)
+    resp = np.abs(np.exp(-2j * np.pi * np.outer(f, np.arange(63))) @ h)
+    assert 20 * np.log10(resp.max()) < -70.0
+    passband = np.abs(np.exp(-2j * np.pi * np.outer(np.linspace(0, 0.08, 50), np.arange(63))) @ h)
+    assert np.all(np.abs(20 * np.log10(passband)) < 1.0)
