@@ -8,7 +8,7 @@ are applied, every voice's 1024 frames are rendered (oscillator -> envelopes -> 
 mixed down.  Workload (config.workload): BASELINE config "65 536 voices ... 48 kHz on 1
 MI355X" with the reference's own patch (Synth::default_config: saw + amp/mod ADSR + the
 one-pole LPF; the reference has no SVF) — per GPU, so N GPUs render N x 65 536 voices (weak
-scaling), each rank owning a contiguous shard of the pool, with one all-gather of the 4 KiB
+scaling), the pool dealt out to the ranks in runs of 64 voices, with one all-gather of the 4 KiB
 partial mixes per buffer over RCCL and a rank-ordered sum on rank 0.
 
 `value` = voice-samples/s = voices x frames x steps / wall time, whole job, with the voice
@@ -129,6 +129,8 @@ def main():
                       block_voices=args.block_voices, lanes_per_voice=args.lanes, overlap=not args.no_overlap)
     synth = sh.renderer
     sh.load_patch("synth mySynth {\n\n}\n")       # example.synth2: empty body == default patch
+    if os.environ.get("S2R_COEFF_STREAM_MODE"):       # measurement aid (see s2r_set_coeff_stream); results are bit-identical
+        synth.set_coeff_stream(int(os.environ["S2R_COEFF_STREAM_MODE"]))
 
     # initial population: every voice of the pool gets a note (all ranks see the same stream)
     init = np.zeros(total, dtype=s2.NOTE_EVENT_DTYPE)

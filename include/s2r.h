@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S2R_ABI_VERSION 1
+#define S2R_ABI_VERSION 2
 
 typedef enum {
     S2R_OK = 0,
@@ -100,6 +100,17 @@ typedef struct {
     uint32_t lanes_per_voice;      /* 1, 2 or 4 GPU lanes cooperating on one voice (a pure
                                       scheduling knob: results are bit-identical); 0 => 1,
                                       the fastest at every pool size */
+    /* Round-robin sharding (0 => off: this handle renders the contiguous range above).  G > 0: the
+     * pool is dealt out in runs of G consecutive voices to shard_count handles, and this one
+     * (shard_index) renders every shard_count-th run — its local voice l is pool voice
+     * ((l / G) * shard_count + shard_index) * G + l % G; shard_begin is ignored and shard_voices is
+     * total_voices / shard_count.  G is a multiple of 16 that divides block_voices, and
+     * total_voices a multiple of G * shard_count.  The allocation policy sweeps the pool in index
+     * order (synth.rs:101-120 picks the oldest voice, first index on ties), so contiguous shards take
+     * a burst of note-ons one GPU at a time; dealt-out shards share it. */
+    uint32_t shard_interleave;
+    uint32_t shard_index;
+    uint32_t shard_count;
 } s2r_config;
 
 /* One voice's complete state, for checkpoint/resume and tests.

@@ -102,6 +102,7 @@ struct s2r_synth {
     s2r_config cfg{};
     int device = 0;
     uint32_t shard_begin = 0, shard_voices = 0, padded_voices = 0, block_voices = 256, n_blocks = 0, mix_groups = 1, lanes = 1;
+    uint32_t interleave = 0, shard_index = 0, shard_count = 1;   // round-robin sharding (s2r_config.shard_interleave)
     std::vector<s2r_patch> bank;                 // bank[0] is "the" patch of the reference's Synth
     uint32_t program = 0;                        // current program: the patch the next note_on gives its voice
     S2rBankEntry *bank_dev = nullptr;            // S2R_MAX_BANK entries, resolved for bank_rate
@@ -157,9 +158,25 @@ int set_err(s2r_synth *s, int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return set_err((s), S2R_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
+// pool index -> this handle's local voice index, or -1 when another handle renders it
+inline int64_t to_local(const s2r_synth *s, uint32_t pool_index) {
+    if (s->interleave == 0) {
+        if (pool_index < s->shard_begin || pool_index >= s->shard_begin + s->shard_voices) return -1;
+        return (int64_t)(pool_index - s->shard_begin);
+    }
+    const uint32_t run = pool_index / s->interleave;
+    if (run % s->shard_count != s->shard_index) return -1;
+    return (int64_t)((run / s->shard_count) * s->interleave + pool_index % s->interleave);
+}
+inline uint32_t to_pool(const s2r_synth *s, uint32_t local) {
+    if (s->interleave == 0) return s->shard_begin + local;
+    return ((local / s->interleave) * s->shard_count + s->shard_index) * s->interleave + local % s->interleave;
+}
+
 void push_event(s2r_synth *s, uint32_t pool_index, uint32_t flags, float pitch, uint32_t seed, uint32_t program = 0) {
-    if (pool_index < s->shard_begin || pool_index >= s->shard_begin + s->shard_voices) return;
-    const uint32_t local = pool_index - s->shard_begin;
+    const int64_t mine = to_local(s, pool_index);
+    if (mine < 0) return;
+    const uint32_t local = (uint32_t)mine;
     int32_t slot = s->pending_slot[local];
     if (slot < 0) {
         slot = (int32_t)s->pending.size();
@@ -436,10 +453,18 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
     if (!cfg || !out || cfg->struct_size != sizeof(s2r_config)) return S2R_ERR_INVALID;
     *out = nullptr;
     if (cfg->total_voices == 0 || cfg->max_frames == 0) return S2R_ERR_INVALID;
-    const uint32_t shard_voices = cfg->shard_voices ? cfg->shard_voices : cfg->total_voices - cfg->shard_begin;
-    if ((uint64_t)cfg->shard_begin + shard_voices > cfg->total_voices || shard_voices == 0) return S2R_ERR_INVALID;
     const uint32_t bv = cfg->block_voices ? cfg->block_voices : 256u;
     if (bv < 64 || bv > 1024 || (bv & 63u)) return S2R_ERR_INVALID;
+    uint32_t shard_voices;
+    if (cfg->shard_interleave) {
+        const uint32_t g = cfg->shard_interleave, n = cfg->shard_count;
+        if ((g & 15u) || bv % g || n == 0 || cfg->shard_index >= n || cfg->total_voices % ((uint64_t)g * n)) return S2R_ERR_INVALID;
+        shard_voices = cfg->total_voices / n;
+        if (cfg->shard_voices && cfg->shard_voices != shard_voices) return S2R_ERR_INVALID;
+    } else {
+        shard_voices = cfg->shard_voices ? cfg->shard_voices : cfg->total_voices - cfg->shard_begin;
+        if ((uint64_t)cfg->shard_begin + shard_voices > cfg->total_voices || shard_voices == 0) return S2R_ERR_INVALID;
+    }
 
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return S2R_ERR_NO_DEVICE;
@@ -454,7 +479,8 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
     if (!s) return S2R_ERR_OUT_OF_MEMORY;
     s->cfg = *cfg;
     s->device = dev;
-    s->shard_begin = cfg->shard_begin;
+    s->shard_begin = cfg->shard_interleave ? 0u : cfg->shard_begin;
+    s->interleave = cfg->shard_interleave; s->shard_index = cfg->shard_index; s->shard_count = cfg->shard_interleave ? cfg->shard_count : 1u;
     s->shard_voices = shard_voices;
     s->block_voices = bv;
     s->n_blocks = (shard_voices + bv - 1) / bv;
@@ -672,9 +698,10 @@ int s2r_note_events(s2r_synth *s, const s2r_note_event *events, size_t n) {
             fl = S2R_EV_RELEASE;
             if (vi < 0) continue;
         }
-        if ((uint64_t)vi < s->shard_begin || (uint64_t)vi >= (uint64_t)s->shard_begin + s->shard_voices) continue;
+        const int64_t mine = to_local(s, (uint32_t)vi);
+        if (mine < 0) continue;
         if (s->tpending.size() >= s->tev_capacity) return set_err(s, S2R_ERR_INVALID, "more than %u timed events in one fill", s->tev_capacity);
-        const uint32_t local = (uint32_t)vi - s->shard_begin;
+        const uint32_t local = (uint32_t)mine;
         const int32_t idx = (int32_t)s->tpending.size();
         S2rTimedEvent te{};
         te.voice = local; te.frame = frame; te.flags = fl; te.pitch = pitch; te.seed = seed; te.next = -1;
@@ -785,7 +812,7 @@ int s2r_export_state(s2r_synth *s, s2r_voice_state *voices) {
     S2R_HIP(s, hipMemcpyAsync(h.data(), s->voice_mem, pv * kVoiceWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     S2R_HIP(s, hipStreamSynchronize(s->stream));
     for (uint32_t i = 0; i < s->shard_voices; i++) {
-        const S2rHostVoice &hv = s->pool->voice(s->shard_begin + i);
+        const S2rHostVoice &hv = s->pool->voice(to_pool(s, i));
         s2r_voice_state &o = voices[i];
         std::memset(&o, 0, sizeof o);
         const uint32_t fl = h[3 * pv + i];
@@ -827,7 +854,7 @@ int s2r_import_state(s2r_synth *s, const s2r_voice_state *voices) {
         h[7 * pv + i] = s2r_f2u(in.filt_x1); h[8 * pv + i] = s2r_f2u(in.filt_x2);
         h[9 * pv + i] = s2r_f2u(in.filt_y1); h[10 * pv + i] = s2r_f2u(in.filt_y2);
         h[11 * pv + i] = in.program;
-        s->pool->set_voice(s->shard_begin + i, in.note, in.started != 0, in.released != 0,
+        s->pool->set_voice(to_pool(s, i), in.note, in.started != 0, in.released != 0,
                            in.current_frame_offset, in.release_frame_offset, in.velocity);
     }
     s->pool->rebuild();
@@ -839,13 +866,13 @@ int s2r_import_state(s2r_synth *s, const s2r_voice_state *voices) {
 int s2r_set_noise_seed(s2r_synth *s, uint32_t voice_index, uint32_t seed) {
     if (!s || voice_index >= s->pool->size()) return S2R_ERR_INVALID;
     s->seed_override[voice_index] = seed;
-    if (voice_index >= s->shard_begin && voice_index < s->shard_begin + s->shard_voices) {
+    if (to_local(s, voice_index) >= 0) {
         S2R_HIP(s, hipSetDevice(s->device));
         if (!s->tpending.empty()) return set_err(s, S2R_ERR_INVALID, "set_noise_seed with timed events pending: fill first");
         EventSlot *ts = nullptr; const S2rTimedEvent *td = nullptr;
         int rc = flush_events(s, s->stream, &ts, &td);
         if (rc != S2R_OK) return rc;
-        S2R_HIP(s, hipMemcpyAsync(s->v.seed + (voice_index - s->shard_begin), &s->seed_override[voice_index],
+        S2R_HIP(s, hipMemcpyAsync(s->v.seed + to_local(s, voice_index), &s->seed_override[voice_index],
                                   sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
         S2R_HIP(s, hipStreamSynchronize(s->stream));
     }

@@ -2,12 +2,14 @@
 single small exchange per buffer.
 
 Voices never interact before the mix (the reference adds each voice's 16-frame buffer into an
-accumulator, synth.rs:177-195), so the pool is cut into contiguous ranges, one per rank.  Every
+accumulator, synth.rs:177-195), so the pool is dealt out to the ranks in runs of 64 voices
+(round-robin; contiguous ranges with ``interleave=0``).  Every
 rank sees the SAME note-event stream and runs the same voice-allocation policy over the whole
 pool (host-side, cheap); only events that land in its own range reach its GPU.  Per buffer each
 rank renders a partial mix (frames x 4 B = 4 KiB at 1024 frames), the partials are all-gathered
 (RCCL over xGMI; latency-bound, not bandwidth-bound) and rank 0 adds them in RANK ORDER, rooted
-at +0.0 — the same association a single GPU produces with ``mix_groups = world``.
+at +0.0 (with contiguous ranges that is the association a single GPU produces with
+``mix_groups = world``).
 
 The renderer and the row-combine are injectable so the exchange logic can be exercised on CPU
 with gloo (tests/test_sharded_gloo.py feeds it partial rows made by the CPU oracle); the
@@ -21,17 +23,21 @@ from . import synth as _synth
 
 class ShardedSynth:
     def __init__(self, voices_per_rank, max_frames=1024, rank=0, world=1, device=None, renderer=None,
-                 combine=None, block_voices=0, lanes_per_voice=0, overlap=True):
+                 combine=None, block_voices=0, lanes_per_voice=0, overlap=True, interleave=64):
         self.rank, self.world = rank, world
         self.voices_per_rank = voices_per_rank
         self.total_voices = voices_per_rank * world
         self.max_frames = max_frames
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         if renderer is None:
+            # round-robin shards (runs of `interleave` voices dealt out to the ranks): the allocation policy
+            # sweeps the pool in index order, so a burst of note-ons lands on every GPU instead of one;
+            # interleave = 0 gives contiguous ranges
+            kw = (dict(shard_interleave=interleave, shard_index=rank, shard_count=world) if interleave and world > 1
+                  else dict(shard_begin=rank * voices_per_rank, shard_voices=voices_per_rank))
             renderer = _synth.Synth(self.total_voices, max_frames=max_frames,
                                     device=self.device.index if self.device.index is not None else -1,
-                                    shard_begin=rank * voices_per_rank, shard_voices=voices_per_rank,
-                                    block_voices=block_voices, lanes_per_voice=lanes_per_voice)
+                                    block_voices=block_voices, lanes_per_voice=lanes_per_voice, **kw)
         self.renderer = renderer
         self.combine = combine if combine is not None else self._combine_hip
         self.overlap = overlap and world > 1

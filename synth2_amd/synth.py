@@ -61,7 +61,8 @@ FILT_SVF_LP, FILT_SVF_BP, FILT_SVF_HP = 6, 7, 8      # build-defined state-varia
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("total_voices", C.c_uint32), ("shard_begin", C.c_uint32),
                 ("shard_voices", C.c_uint32), ("max_frames", C.c_uint32), ("device", C.c_int32),
-                ("block_voices", C.c_uint32), ("mix_groups", C.c_uint32), ("lanes_per_voice", C.c_uint32)]
+                ("block_voices", C.c_uint32), ("mix_groups", C.c_uint32), ("lanes_per_voice", C.c_uint32),
+                ("shard_interleave", C.c_uint32), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32)]
 
 
 class VoiceState(C.Structure):
@@ -203,6 +204,12 @@ def stream_frame_json(samples):
     return buf.raw[:n].decode("ascii")
 
 
+def shard_pool_indices(total_voices, shard_index, shard_count, interleave):
+    """pool indices of a round-robin shard's local voices, in local order (s2r_config.shard_interleave)"""
+    local = np.arange(total_voices // shard_count)
+    return ((local // interleave) * shard_count + shard_index) * interleave + local % interleave
+
+
 class VoicePool:
     """The allocation policy of Synth (synth.rs:61-120) without a device."""
 
@@ -246,11 +253,11 @@ class Synth:
     """
 
     def __init__(self, num_voices=8, max_frames=2048, device=-1, shard_begin=0, shard_voices=0,
-                 block_voices=0, mix_groups=0, lanes_per_voice=0):
+                 block_voices=0, mix_groups=0, lanes_per_voice=0, shard_interleave=0, shard_index=0, shard_count=1):
         self.L = load_library()
         self.h = C.c_void_p()
         cfg = Config(C.sizeof(Config), num_voices, shard_begin, shard_voices, max_frames, device, block_voices, mix_groups,
-                     lanes_per_voice)
+                     lanes_per_voice, shard_interleave, shard_index, shard_count)
         rc = self.L.s2r_create(C.byref(cfg), C.byref(self.h))
         if rc != S2R_OK:
             self.h = None

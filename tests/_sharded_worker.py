@@ -26,10 +26,10 @@ BLOCK = 256
 class OracleShardRenderer:
     """stands in for synth2_amd.Synth on a machine without a GPU"""
 
-    def __init__(self, total, begin, count):
+    def __init__(self, total, indices):
         self.ora = s2o.OracleSynth(total)
         self.pool = s2.VoicePool(total)          # the product's allocation policy, run alongside
-        self.begin, self.count = begin, count
+        self.indices = indices                   # pool indices of this rank's voices, in local order
         self.rows = None
 
     def note_events(self, events):
@@ -45,7 +45,7 @@ class OracleShardRenderer:
     def fill_device(self, ptr, frames, sample_rate, stream):
         self.rows = self.ora.render_voices(frames, sample_rate)
         self.pool.advance(frames)
-        part = s2o.mix_tree_partial(self.rows[self.begin:self.begin + self.count], BLOCK)
+        part = s2o.mix_tree_partial(self.rows[self.indices], BLOCK)
         ctypes.memmove(ptr, part.ctypes.data, frames * 4)
 
 
@@ -63,8 +63,10 @@ def main():
     vpr, frames = 512, 256
     total = vpr * world
     overlap = os.environ.get("S2R_OVERLAP", "1") == "1"
+    inter = int(os.environ.get("S2R_INTERLEAVE", "0"))     # 0: contiguous ranges, else runs of `inter` voices dealt out
+    shard = (lambda r: s2.shard_pool_indices(total, r, world, inter)) if inter else (lambda r: np.arange(r * vpr, (r + 1) * vpr))
     sh = ShardedSynth(vpr, max_frames=frames, rank=rank, world=world, device=torch.device("cpu"),
-                      renderer=OracleShardRenderer(total, rank * vpr, vpr), combine=combine_numpy, overlap=overlap)
+                      renderer=OracleShardRenderer(total, shard(rank)), combine=combine_numpy, overlap=overlap)
     ev = np.zeros(total, dtype=s2.NOTE_EVENT_DTYPE)
     ev["kind"] = 1
     ev["note"] = 36 + np.arange(total) % 61
@@ -80,7 +82,12 @@ def main():
         sh.note_events(churn)
         n = frames if k != 3 else 100                  # one short (ragged, non multiple of 16) buffer
         sh.fill(n, 48000)
-        expected.append((n, s2o.mix_tree(sh.renderer.rows, BLOCK, world)))
+        want = np.zeros(n, dtype=np.float32)               # accum = splat(0.0), then the ranks' partial rows in rank order
+        for r in range(world):
+            want = want + s2o.mix_tree_partial(sh.renderer.rows[shard(r)], BLOCK)
+        if not inter:                                      # contiguous ranges: the association of one GPU with mix_groups
+            assert np.array_equal(want.view(np.uint32), s2o.mix_tree(sh.renderer.rows, BLOCK, world).view(np.uint32))
+        expected.append((n, want))
         if not overlap or k == 5:
             sh.flush()
         if rank == 0 and (not overlap):

@@ -129,7 +129,13 @@ def test_fuzz_shards(seed):
     bank = [random_patch(rng) for _ in range(int(rng.choice([1, 1, 3])))]
     ora = s2o.OracleSynth(voices)
     ora.set_bank([oracle_cfg_from_patch(p) for p in bank])
-    sh = [s2.Synth(voices, max_frames=1024, shard_begin=r * per, shard_voices=per, block_voices=block) for r in range(ranks)]
+    inter = int(rng.choice([0, 16, 64, block]))                   # 0: contiguous ranges; else runs of `inter` voices dealt out
+    if inter:
+        sh = [s2.Synth(voices, max_frames=1024, block_voices=block, shard_interleave=inter, shard_index=r, shard_count=ranks) for r in range(ranks)]
+        idx = [s2.shard_pool_indices(voices, r, ranks, inter) for r in range(ranks)]
+    else:
+        sh = [s2.Synth(voices, max_frames=1024, shard_begin=r * per, shard_voices=per, block_voices=block) for r in range(ranks)]
+        idx = [np.arange(r * per, (r + 1) * per) for r in range(ranks)]
     for s in sh:
         s.set_patch_bank(bank)
     st = torch.cuda.current_stream().cuda_stream
@@ -171,10 +177,16 @@ def test_fuzz_shards(seed):
             n = min(16, frames - c)
             with np.errstate(all="ignore"):
                 pv[:, c:c + n] = ora.render_voices(n, SR)
-        what = "shard seed %d: %d ranks x %d voices, block %d, buffer %d (%d frames%s)" % (seed, ranks, per, block, b, frames, ", timed" if timed else "")
+        what = "shard seed %d: %d ranks x %d voices, block %d, interleave %d, buffer %d (%d frames%s)" % (
+            seed, ranks, per, block, inter, b, frames, ", timed" if timed else "")
+        total = np.zeros(frames, dtype=np.float32)                     # accum = splat(0.0), then the ranks in order
         for r in range(ranks):
-            assert_bits_equal(part[r].cpu().numpy(), s2o.mix_tree_partial(pv[r * per:(r + 1) * per], block), what + ", partial of rank %d" % r)
-        assert_bits_equal(out.cpu().numpy(), s2o.mix_tree(pv, block, ranks), what + ", combined")
+            want = s2o.mix_tree_partial(pv[idx[r]], block)
+            assert_bits_equal(part[r].cpu().numpy(), want, what + ", partial of rank %d" % r)
+            total = total + want
+        assert_bits_equal(out.cpu().numpy(), total, what + ", combined")
+        if not inter:
+            assert_bits_equal(total, s2o.mix_tree(pv, block, ranks), what + ", == one GPU with mix_groups")
 
 
 SR = 48000

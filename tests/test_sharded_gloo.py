@@ -17,13 +17,14 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,overlap", [(2, 1), (2, 0), (3, 1)])
-def test_sharded_partials_allgather_and_ordered_combine(world, overlap):
+@pytest.mark.parametrize("world,overlap,interleave", [(2, 1, 0), (2, 0, 64), (3, 1, 0), (2, 1, 64), (4, 1, 16)])
+def test_sharded_partials_allgather_and_ordered_combine(world, overlap, interleave):
+    """interleave 0: contiguous ranges per rank; else the pool dealt out in runs of `interleave` voices"""
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   S2R_OVERLAP=str(overlap), OMP_NUM_THREADS="1")
+                   S2R_OVERLAP=str(overlap), S2R_INTERLEAVE=str(interleave), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_sharded_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
