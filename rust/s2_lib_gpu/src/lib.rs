@@ -37,6 +37,9 @@ pub mod ffi {
         pub block_voices: u32,
         pub mix_groups: u32,
         pub lanes_per_voice: u32,
+        pub shard_interleave: u32,
+        pub shard_index: u32,
+        pub shard_count: u32,
     }
 
     #[repr(C)]
@@ -124,6 +127,9 @@ pub mod synth {
                 block_voices: 0,
                 mix_groups: 0,
                 lanes_per_voice: 0,
+                shard_interleave: 0,
+                shard_index: 0,
+                shard_count: 1,
             };
             let mut handle = std::ptr::null_mut();
             let rc = unsafe { ffi::s2r_create(&cfg, &mut handle) };
