@@ -236,8 +236,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "65536 voices per GPU, default patch (example.synth2 empty body: saw + amp/mod ADSR + one-pole LPF), "
-                                   "48 kHz, 1024-frame buffers, %d note-on + %d note-off per buffer per 64k voices" % (args.churn, args.churn),
+            "config": {"workload": "%d voices per GPU, default patch (example.synth2 empty body: saw + amp/mod ADSR + one-pole LPF), "
+                                   "48 kHz, 1024-frame buffers, %d note-on + %d note-off per buffer per 64k voices" % (vpg, args.churn, args.churn),
                        "voices_total": total, "frames": FRAMES, "sample_rate": SR,
                        "parallelism": "voice-shard x%d, all-gather of partial mixes" % world,
                        "block_voices": synth.block_voices, "lanes_per_voice": synth.lanes_per_voice},
