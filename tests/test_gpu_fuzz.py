@@ -45,14 +45,14 @@ def test_fuzz(seed):
     if lanes == 4 and block > 256:
         block = 256
     groups = int(rng.choice([0, 0, 2, 3]))
-    max_frames = 1024
+    max_frames = int(rng.choice([1024, 1024, 2048, 1040]))
     bank = [random_patch(rng) for _ in range(int(rng.choice([1, 1, 1, 2, 5])))]
     seeds = rng.randint(0, 2 ** 31, voices).astype(np.uint64) if rng.rand() < 0.15 else None   # NoiseState.seed overrides
     pr = Pair(voices, bank[0], max_frames=max_frames, block_voices=block, mix_groups=groups, lanes=lanes, seeds=seeds)
     if len(bank) > 1:
         pr.set_bank(bank)
     pr.gpu.set_coeff_stream(int(rng.choice([1, 3, 3, 4, 0])))
-    sr = int(rng.choice([48000, 48000, 44100, 96000, 22050, 12345]))
+    sr = int(rng.choice([48000, 48000, 44100, 96000, 22050, 12345, 8000, 192000, 384000]))
     held = []
     what = "seed %d: %d voices, block %d, lanes %d, groups %d, %d patches, sr %d" % (seed, voices, block, lanes, groups, len(bank), sr)
     for b in range(7):
@@ -61,7 +61,7 @@ def test_fuzz(seed):
         if b and len(bank) == 1 and rng.rand() < 0.15:   # the patch is swapped under sounding voices
             bank = [random_patch(rng)]
             pr.gpu.set_patch(bank[0]); pr.cpu.config = oracle_cfg_from_patch(bank[0])
-        frames = int(rng.choice([1024, 1024, 1000, 512, 256, 100, 17, 16]))
+        frames = int(rng.choice([1024, 1024, 1000, 512, 256, 100, 17, 16, max_frames, 1]))
         timed = len(bank) >= 1 and rng.rand() < 0.35 and frames >= 32
         n_ev = int(rng.randint(0, 30)) if b else int(rng.randint(voices // 2, voices + 5))
         if timed:
