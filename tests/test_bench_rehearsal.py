@@ -5,6 +5,7 @@ rendezvous, the same event stream on every rank, shard-local rendering, gather, 
 combine on rank 0, max-over-ranks timing, one JSON line."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -13,11 +14,19 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
 @pytest.mark.gpu
 def test_two_rank_bench_flow_on_one_gpu():
     env = dict(os.environ, S2R_BENCH_BACKEND="gloo", S2R_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--steps", "6", "--warmup", "2", "--voices-per-gpu", "8192"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
