@@ -15,6 +15,8 @@
  *        libm_xcheck div <c> <stride>                s2r_div_const(x, c) vs x / c for every
  *                                                    stride-th float with 2^-60 < |x| < 2^60
  *        libm_xcheck div65535                        all integers 0..65535 (the noise quotient)
+ *        libm_xcheck divrcp <n>                      s2r_div_by_rcp64(a, 1/(double)b) vs a / b for n random (a, b)
+ *                                                    plus every dividend against 4096 divisors near all-ones / one
  */
 #include <math.h>
 #include <stdint.h>
@@ -74,6 +76,33 @@ int main(int argc, char **argv) {
             if (s2r_f2u(a) != s2r_f2u(b)) bad++;
         }
         printf("checked=65536 mismatches=%llu\n", (unsigned long long)bad);
+        return bad ? 1 : 0;
+    }
+    if (argc >= 3 && !strcmp(argv[1], "divrcp")) {
+        const uint64_t n = strtoull(argv[2], 0, 10);
+        uint64_t x = 0x9E3779B97F4A7C15ull, bad = 0, cnt = 0;
+        for (uint64_t i = 0; i < n; i++) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            /* exponents 2^-40 .. 2^40 (the oscillator's range and far beyond), any significands */
+            const uint32_t ua = ((uint32_t)x & 0x007fffffu) | ((87u + (uint32_t)((x >> 24) % 81u)) << 23);
+            const uint32_t ub = ((uint32_t)(x >> 32) & 0x007fffffu) | ((87u + (uint32_t)((x >> 56) % 81u)) << 23);
+            const float a = s2r_u2f(ua), b = s2r_u2f(ub);
+            const float q = s2r_div_by_rcp64(a, s2r_rcp_f64(b)), r = a / b;
+            cnt++;
+            if (s2r_f2u(q) != s2r_f2u(r)) { bad++; if (shown < 10) { shown++; fprintf(stderr, "MISMATCH %a / %a: %a vs %a\n", a, b, q, r); } }
+        }
+        /* structured: divisors with significands next to 1.0 and to 2.0 (the hard cases of reciprocal-based division) */
+        for (uint32_t k = 0; k < 2048; k++)
+            for (int hi = 0; hi < 2; hi++) {
+                const float b = s2r_u2f(0x3f800000u | (hi ? 0x007fffffu - k : k));
+                const double rb = s2r_rcp_f64(b);
+                for (uint32_t m = 0; m < 0x00800000u; m += 37u) {
+                    const float a = s2r_u2f(0x3f800000u | m);
+                    cnt++;
+                    if (s2r_f2u(s2r_div_by_rcp64(a, rb)) != s2r_f2u(a / b)) { bad++; if (shown < 10) { shown++; fprintf(stderr, "MISMATCH %a / %a\n", a, b); } }
+                }
+            }
+        printf("checked=%llu mismatches=%llu\n", (unsigned long long)cnt, (unsigned long long)bad);
         return bad ? 1 : 0;
     }
     if (argc >= 4 && !strcmp(argv[1], "div")) return div_mode(strtof(argv[2], 0), (uint32_t)strtoul(argv[3], 0, 10));

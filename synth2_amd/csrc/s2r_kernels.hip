@@ -229,6 +229,12 @@ __device__ __forceinline__ OscK make_osck(float period) {
     return k;
 }
 
+// SIN_TABLE in LDS as pairs: entry i2 holds (SIN_TABLE[(i2 - 1) mod 1024], SIN_TABLE[i2]), so the two
+// neighbours a lookup interpolates between (lookup.rs:64-72: i1 and i2 = (i1 + 1) mod 1024) come with one read
+__device__ __forceinline__ float2 sin_pair(const float *sSin, uint32_t i2) {
+    return *reinterpret_cast<const float2 *>(sSin + 2u * i2);
+}
+
 // oscillators.rs basic::{Square,Saw,Triangle,Table}Oscillator[X16]::sample given the phased offset
 template <int OSC>
 __device__ __forceinline__ float osc_value(const OscK &k, float off, const float *sSin) {
@@ -250,8 +256,9 @@ __device__ __forceinline__ float osc_value(const OscK &k, float off, const float
         const float tv = x * 1024.0f / k.period;                // :63
         const uint32_t i1 = s2r_f32_as_u32(tv);                 // :64
         const uint32_t i2 = (i1 + 1u) & 1023u;                  // :67  (% 1024, wrapping add)
-        const float s1 = i1 < 1024u ? sSin[i1] : 0.0f;          // :72 gather_or_default
-        const float s2 = sSin[i2];
+        const float2 pr = sin_pair(sSin, i2);                   // one 8-byte LDS read: SIN_TABLE[i2 - 1], SIN_TABLE[i2]
+        const float s1 = i1 < 1024u ? pr.x : 0.0f;              // :72 gather_or_default
+        const float s2 = pr.y;
         return __builtin_fmaf((s2 - s1) / 1.0f, tv - (float)i1, s1);   // :75-84
     }
 }
@@ -728,6 +735,7 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
 #pragma unroll
         for (int q = 0; q < 4; ++q) xq[q] = stream_q[(size_t)q * 64u];      // 4 coalesced 16-byte loads, used last
     }
+    const double rcp_period = OSC == S2R_OSC_SINE ? s2r_rcp_f64(k.period) : 0.0;    // constant over the run: hoisted by the compiler
     // a lane without a started voice: see a0 / ampq below.  Its filter history must be 0 for that (frames
     // of the general path, which selects per frame instead, leave a running value in it)
     if (!live) r.last = 0.0f;
@@ -775,9 +783,10 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
                 const float first = __builtin_fmaf(k.b, x, 1.0f), second = __builtin_fmaf(k.c, x - k.a, -1.0f);
                 osc = x < k.a ? first : second;
             } else {
-                const float tv = x * 1024.0f / k.period;
+                const float tv = s2r_div_by_rcp64(x * 1024.0f, rcp_period);     // == x * 1024 / period, exactly (s2r_math.h)
                 const uint32_t i1 = s2r_f32_as_u32(tv), i2 = (i1 + 1u) & 1023u;
-                const float s1 = i1 < 1024u ? sSin[i1] : 0.0f, s2 = sSin[i2];
+                const float2 pr = sin_pair(sSin, i2);
+                const float s1 = i1 < 1024u ? pr.x : 0.0f, s2 = pr.y;
                 osc = __builtin_fmaf((s2 - s1) / 1.0f, tv - (float)i1, s1);
             }
             const float s = (osc + p.osc_gain) + nz[q][j];
@@ -814,7 +823,7 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
     constexpr bool TEV = MODE == 2;      // note events that take effect inside the fill
     const uint32_t kSuper = p.super_frames;                      // 64 or 256, wave-uniform
     __shared__ uint64_t sT[S2R_EXP2F_N];
-    __shared__ float sSin[OSC == S2R_OSC_SINE ? 1024 : 1];
+    __shared__ __attribute__((aligned(8))) float sSin[OSC == S2R_OSC_SINE ? 2048 : 2];
     extern __shared__ float s_dyn[];
 
     const uint32_t tid = threadIdx.x;
@@ -835,7 +844,7 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
 
     if (tid < S2R_EXP2F_N) sT[tid] = c_exp2f_table[tid];
     if (OSC == S2R_OSC_SINE)
-        for (uint32_t i = tid; i < 1024u; i += blockDim.x) sSin[i] = p.sin_table[i];
+        for (uint32_t i = tid; i < 1024u; i += blockDim.x) { sSin[2u * i] = p.sin_table[(i + 1023u) & 1023u]; sSin[2u * i + 1u] = p.sin_table[i]; }
 
     // ---- load per-voice state (coalesced SoA reads; the L lanes of a voice read the same words) ----
     const bool in_range = vi < p.n_voices;
@@ -1154,7 +1163,7 @@ __global__ void __launch_bounds__(MAXT) s2r_render_general_kernel(const S2rRende
     const uint32_t kSuper = p.super_frames;
     const bool PV = p.per_voice != nullptr, TEV = p.tev != nullptr;          // wave-uniform
     __shared__ uint64_t sT[S2R_EXP2F_N];
-    __shared__ float sSin[(OSC == S2R_OSC_SINE || OSC == S2R_OSC_ANY) ? 1024 : 1];
+    __shared__ __attribute__((aligned(8))) float sSin[(OSC == S2R_OSC_SINE || OSC == S2R_OSC_ANY) ? 2048 : 2];
     extern __shared__ float s_dyn[];
 
     const uint32_t tid = threadIdx.x;
@@ -1167,7 +1176,7 @@ __global__ void __launch_bounds__(MAXT) s2r_render_general_kernel(const S2rRende
 
     if (tid < S2R_EXP2F_N) sT[tid] = c_exp2f_table[tid];
     if (OSC == S2R_OSC_SINE || OSC == S2R_OSC_ANY)
-        for (uint32_t i = tid; i < 1024u; i += blockDim.x) sSin[i] = p.sin_table[i];
+        for (uint32_t i = tid; i < 1024u; i += blockDim.x) { sSin[2u * i] = p.sin_table[(i + 1023u) & 1023u]; sSin[2u * i + 1u] = p.sin_table[i]; }
 
     const bool in_range = vi < p.n_voices;
     const uint32_t flags = in_range ? p.v.flags[vi] : 0u;

@@ -250,6 +250,19 @@ S2R_HD float s2r_fmod_period(float off, float period) {
 }
 
 // ---------------------------------------------------------------------------------------
+// a / b correctly rounded to f32 for a divisor that stays the same over many quotients:
+// rb = RN53(1 / (double)b) once, then RN24(RN53((double)a * rb)) per quotient — three plain
+// instructions instead of the ~10 of an IEEE f32 division.  Why it is exact: a/b is the ratio of
+// two 24-bit significands, so unless it IS an f32 it differs from every f32 rounding boundary
+// (a 25-bit midpoint m) by at least 2^-49 relative — a - b*m is a non-zero multiple of the grid
+// of the <= 49-bit product b*m, and it cannot be zero because b*m has an odd 25-bit factor — while
+// (double)a * rb is within 2^-52 relative of a/b; so both lie on the same side of every boundary.
+// (Finite, non-zero b; a*rb inside the double range, which any two floats give.)
+// ---------------------------------------------------------------------------------------
+S2R_HD double s2r_rcp_f64(float b) { return 1.0 / (double)b; }
+S2R_HD float s2r_div_by_rcp64(float a, double rb) { return (float)((double)a * rb); }
+
+// ---------------------------------------------------------------------------------------
 // glibc sinf / cosf (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h; FMA ifunc variant):
 // double-precision polynomials after a quadrant reduction, rounded once to float.  Used by the
 // second-order filters of dsp_filters.rs (Rust f32::sin / f32::cos).  |y| < 120 goes through

@@ -92,6 +92,12 @@ def test_sinf_cosf_match_host_libm(libm_xcheck):
     _run(libm_xcheck, "tanf", 6000, 7000)
 
 
+def test_division_through_a_double_reciprocal(libm_xcheck):
+    """the sine lookup's x * 1024 / period as RN24((double)a * RN53(1 / period)): exact by the argument in
+    s2r_math.h; here 2*10^7 random pairs and 9*10^8 structured ones (divisors next to 1.0 and 2.0)"""
+    _run(libm_xcheck, "divrcp", 20000000)
+
+
 def test_noise_quotient_all_u16(libm_xcheck):
     _run(libm_xcheck, "div65535")
 

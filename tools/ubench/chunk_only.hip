@@ -7,7 +7,7 @@ namespace {
 template <int WITH_REDUCE>
 __global__ void __launch_bounds__(256) chunk_only(S2rRenderParams p, float *out, int n_chunks) {
     __shared__ uint64_t sT[S2R_EXP2F_N];
-    __shared__ float sSin[1];
+    __shared__ __attribute__((aligned(8))) float sSin[2];
     __shared__ float tile[4][kChunk * 65];
     __shared__ float sW[4][4][256];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
