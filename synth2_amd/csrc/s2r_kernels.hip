@@ -221,11 +221,13 @@ template <int OSC>
 __device__ __forceinline__ OscK make_osck(float period) {
     OscK k;
     k.period = period;
+    // One division: RN(c / period) for c = -2, -4, 4 is c/1 times RN(1 / period) exactly (a power of two commutes
+    // with rounding), and period / 2 is exact, so -2 / (period / 2) == RN(-4 / period).
     k.inv_period = 1.0f / period;                                // oscillators.rs:378
     k.a = k.b = k.c = 0.0f;
-    if (OSC == S2R_OSC_SAW) k.a = -2.0f / period;                // oscillators.rs:107-112
-    if (OSC == S2R_OSC_SQUARE) k.a = period / 2.0f;              // :68-69
-    if (OSC == S2R_OSC_TRIANGLE) { k.a = period / 2.0f; k.b = -2.0f / k.a; k.c = 2.0f / k.a; }   // :156-172
+    if (OSC == S2R_OSC_SAW) k.a = -2.0f * k.inv_period;          // -2.0 / period                  oscillators.rs:107-112
+    if (OSC == S2R_OSC_SQUARE) k.a = period * 0.5f;              // period / 2.0                   :68-69
+    if (OSC == S2R_OSC_TRIANGLE) { k.a = period * 0.5f; k.b = -4.0f * k.inv_period; k.c = 4.0f * k.inv_period; }   // -2.0 / half, 2.0 / half   :156-172
     return k;
 }
 
@@ -273,9 +275,9 @@ __device__ __forceinline__ OscK make_osck_any(int kind, float period) {
     k.period = period;
     k.inv_period = 1.0f / period;
     k.a = k.b = k.c = 0.0f;
-    if (kind == S2R_OSC_SAW) k.a = -2.0f / period;
-    if (kind == S2R_OSC_SQUARE || kind == S2R_OSC_TRIANGLE) k.a = period / 2.0f;
-    if (kind == S2R_OSC_TRIANGLE) { k.b = -2.0f / k.a; k.c = 2.0f / k.a; }
+    if (kind == S2R_OSC_SAW) k.a = -2.0f * k.inv_period;
+    if (kind == S2R_OSC_SQUARE || kind == S2R_OSC_TRIANGLE) k.a = period * 0.5f;
+    if (kind == S2R_OSC_TRIANGLE) { k.b = -4.0f * k.inv_period; k.c = 4.0f * k.inv_period; }
     return k;
 }
 
@@ -323,11 +325,11 @@ template <int OSC>
 __device__ __forceinline__ OscK4 make_osck4(f4 period) {
     OscK4 k;
     k.period = period;
-    k.inv_period = splat(1.0f) / period;                         // oscillators.rs:378
+    k.inv_period = splat(1.0f) / period;                         // oscillators.rs:378 (the one division, see make_osck)
     k.a = k.b = k.c = splat(0.0f);
-    if (OSC == S2R_OSC_SAW) k.a = splat(-2.0f) / period;         // oscillators.rs:107-112
-    if (OSC == S2R_OSC_SQUARE) k.a = period / splat(2.0f);       // :68-69
-    if (OSC == S2R_OSC_TRIANGLE) { k.a = period / splat(2.0f); k.b = splat(-2.0f) / k.a; k.c = splat(2.0f) / k.a; }
+    if (OSC == S2R_OSC_SAW) k.a = splat(-2.0f) * k.inv_period;   // oscillators.rs:107-112
+    if (OSC == S2R_OSC_SQUARE) k.a = period * splat(0.5f);       // :68-69
+    if (OSC == S2R_OSC_TRIANGLE) { k.a = period * splat(0.5f); k.b = splat(-4.0f) * k.inv_period; k.c = splat(4.0f) * k.inv_period; }
     return k;
 }
 
