@@ -134,6 +134,7 @@ struct s2r_synth {
     // coefficient stream (s2r_kernels.hip)
     int32_t *group_slot = nullptr; uint32_t *slot_group = nullptr; uint32_t *coeff_count = nullptr; float *coeff = nullptr;
     uint32_t coeff_capacity = 0, coeff_parity = 0; bool use_coeff = true, use_prep = true, force_stream = false;
+    uint32_t coeff_vecs = 1;                     // vectors per quad the stream buffer is sized for (3 once an FM patch streams)
     float pitch_table[256];
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool timing = false, timed = false, no_flat_shortcut = false;
@@ -256,10 +257,10 @@ int check_fill(s2r_synth *s, size_t frames, uint32_t sample_rate) {
 // The coefficient stream (and with it the classification launch) pays when a fill has many chunks
 // and the shard many waves; a 16-frame fill of a handful of voices — s2_bin's own call pattern,
 // main.rs:138-143 — is quicker without the two extra launches (28 -> 22 us per call).  Only where it is
-// defined: one-pole patch, no oscillator FM, the flat-envelope logic enabled.
+// defined: one-pole patch, the flat-envelope logic enabled.
 bool stream_wanted(const s2r_synth *s, size_t frames) {
     return s->use_coeff && !s->no_flat_shortcut && s->coeff != nullptr && s->bank.size() == 1 &&
-           s->bank[0].mod_env_to_osc_freq == 0.0f && s->bank[0].lpf_kind == S2R_FILT_ONEPOLE &&
+           s->bank[0].lpf_kind == S2R_FILT_ONEPOLE &&
            (s->force_stream || (frames >= 128 && s->shard_voices >= 1024u));
 }
 
@@ -288,7 +289,7 @@ S2rRenderParams make_params(s2r_synth *s, size_t frames, uint32_t sample_rate) {
     p.block_partials = s->block_partials;
     p.per_voice = nullptr;
     p.sin_table = s->sin_dev;
-    // stream only where it is defined: no oscillator FM, the flat-envelope logic enabled
+    // stream only where it is defined: one-pole patch, the flat-envelope logic enabled
     p.use_coeff = stream_wanted(s, frames) ? 1 : 0;
     p.bank = s->bank_dev;
     p.bank_size = (uint32_t)s->bank.size();
@@ -330,6 +331,14 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
         S2R_HIP(s, hipMemcpyAsync(s->bank_dev, host.data(), host.size() * sizeof(S2rBankEntry), hipMemcpyHostToDevice, stream));
         S2R_HIP(s, hipStreamSynchronize(stream));
         s->bank_dirty = false; s->bank_rate = sample_rate;
+    }
+    if (stream_wanted(s, frames) && s->bank[0].mod_env_to_osc_freq != 0.0f && s->coeff_vecs < 3u) {
+        // first streamed fill of an oscillator-FM patch: the stream carries (coefficient, period, 1 / period)
+        S2R_HIP(s, hipStreamSynchronize(stream));
+        S2R_HIP(s, hipStreamSynchronize(s->stream));
+        S2R_HIP(s, hipFree(s->coeff)); s->coeff = nullptr;
+        S2R_HIP(s, hipMalloc((void **)&s->coeff, (size_t)3 * s->coeff_capacity * s->cfg.max_frames * 64 * sizeof(float)));
+        s->coeff_vecs = 3u;
     }
     S2rRenderParams p = make_params(s, frames, sample_rate);
     p.per_voice = per_voice_dev;

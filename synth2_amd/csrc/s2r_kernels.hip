@@ -591,7 +591,7 @@ __global__ void __launch_bounds__(64) s2r_classify_kernel(const S2rRenderParams 
     }
 }
 
-template <bool FASTDIV>
+template <bool FASTDIV, bool FM>
 __global__ void __launch_bounds__(256) s2r_coeff_kernel(const S2rRenderParams p) {
     __shared__ uint64_t sT[S2R_EXP2F_N];
     if (threadIdx.x < S2R_EXP2F_N) sT[threadIdx.x] = c_exp2f_table[threadIdx.x];
@@ -613,7 +613,9 @@ __global__ void __launch_bounds__(256) s2r_coeff_kernel(const S2rRenderParams p)
         const float ro_m = __builtin_fmaxf(rel_f, p.mod.sus_off), end_m = ro_m + p.mod.R;
         EnvRun em = env_stage_at(p.mod, ro_m, end_m, 0.0f);
         float thr = -__builtin_inff();
-        f4 *dst = (f4 *)p.coeff + ((size_t)slot * n_quads + (size_t)chunk * kQuadsPerItem) * 64u + lane;
+        constexpr uint32_t kVec = FM ? 3u : 1u;                  // per quad: xc [, period, 1 / period]
+        const float pitch = (FM && in_range && (flags & S2R_VF_STARTED)) ? p.v.pitch[vi] : 440.0f;
+        f4 *dst = (f4 *)p.coeff + ((size_t)slot * n_quads + (size_t)chunk * kQuadsPerItem) * kVec * 64u + lane;
         const uint32_t q1 = (chunk + 1) * kQuadsPerItem < n_quads ? kQuadsPerItem : n_quads - chunk * kQuadsPerItem;
         for (uint32_t q = 0; q < q1; ++q) {
             const uint32_t oi = offset + (chunk * kQuadsPerItem + q) * kP;
@@ -628,7 +630,13 @@ __global__ void __launch_bounds__(256) s2r_coeff_kernel(const S2rRenderParams p)
             const f4 f_lpf = pow2_sleef_core4(mod * splat(p.amt_lpf)) * splat(p.lpf_freq);
             const f4 num = splat(-2.0f * 3.14159274101257324f) * f_lpf;
             const f4 arg = FASTDIV ? div_const_nocheck4(num, p.sr, p.rcp_sr) : (num / splat(p.sr));
-            dst[(size_t)q * 64u] = expf4(arg, sT);
+            dst[(size_t)(q * kVec) * 64u] = expf4(arg, sT);
+            if (FM) {
+                const f4 f_osc = pow2_sleef_core4(mod * splat(p.amt_osc)) * splat(pitch);       // process.rs:146-147,231-250
+                const f4 period = splat(p.sr) / f_osc;                                             // units.rs:32-42
+                dst[(size_t)(q * kVec + 1u) * 64u] = period;
+                dst[(size_t)(q * kVec + 2u) * 64u] = splat(1.0f) / period;                         // oscillators.rs:378
+            }
         }
     }
 }
@@ -726,18 +734,24 @@ __global__ void __launch_bounds__(64) s2r_prep_kernel(const S2rPrepParams a) {
 // ---------------------------------------------------------------------------------------
 //   FILT != 0 (general kernel, flat stages only): the layer's filter is dsp_filters.rs' / the SVF with the
 //   constant coefficients `fcoef`, state in *f2, instead of the one-pole.
-template <int OSC, int SRC, int FILT = 0>
+//   FMV (with SRC == 1, oscillator FM): the stream carries three vectors per quad — the LPF coefficient, the
+//   oscillator period sr / f_osc and its reciprocal — and the period constants are per-frame values.
+template <int OSC, int SRC, int FILT = 0, bool FMV = false>
 __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &r, const EnvRun &ea, const EnvRun &em,
                                            const FlatCache &fc, const OscK &k, uint32_t o_chunk, const f4 *stream_q,
                                            const uint64_t *sT, const float *sSin, bool live, float *tile_col,
                                            uint32_t tile_stride, float *pv_dst,
                                            const FiltCoef *fcoef = nullptr, Filt2 *f2 = nullptr) {
-    f4 xq[4];
+    f4 xq[4], pq[4], iq[4];
+    constexpr uint32_t kVec = FMV ? 3u : 1u;                      // vectors per quad in the stream
     if (SRC == 1) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) xq[q] = stream_q[(size_t)q * 64u];      // 4 coalesced 16-byte loads, used last
+        for (int q = 0; q < 4; ++q) {                            // coalesced 16-byte loads, used last
+            xq[q] = stream_q[(size_t)(q * kVec) * 64u];
+            if (FMV) { pq[q] = stream_q[(size_t)(q * kVec + 1u) * 64u]; iq[q] = stream_q[(size_t)(q * kVec + 2u) * 64u]; }
+        }
     }
-    const double rcp_period = OSC == S2R_OSC_SINE ? s2r_rcp_f64(k.period) : 0.0;    // constant over the run: hoisted by the compiler
+    const double rcp_period = (OSC == S2R_OSC_SINE && !FMV) ? s2r_rcp_f64(k.period) : 0.0;   // constant over the run: hoisted by the compiler
     // a lane without a started voice: see a0 / ampq below.  Its filter history must be 0 for that (frames
     // of the general path, which selects per frame instead, leave a running value in it)
     if (!live) r.last = 0.0f;
@@ -767,25 +781,32 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
         if (!live) { a0 = splat(0.0f); ampq = splat(0.0f); }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            // the frame's oscillator constants: the run's (k), or under FM the streamed period and 1/period with
+            // the rest by exact scalings (make_osck)
+            const float period = FMV ? pq[q][j] : k.period, inv_period = FMV ? iq[q][j] : k.inv_period;
+            const float ka = !FMV ? k.a : (OSC == S2R_OSC_SAW ? -2.0f * inv_period : period * 0.5f);
+            const float kb = !FMV ? k.b : -4.0f * inv_period, kc = !FMV ? k.c : 4.0f * inv_period;
             const float ph = r.phase;
-            const float nx = ph + k.inv_period;                  // oscillators.rs:377-381; 0 <= nx < 2
+            const float nx = ph + inv_period;                    // oscillators.rs:377-381; 0 <= nx < 2
             // fmodf(nx, 1) for nx >= 0 is its fractional part, which is exact; v_fract_f32 returns
             // min(nx - floor(nx), 0x1.fffffep-1) and the clamp cannot bind for nx < 2^23
             r.phase = __builtin_amdgcn_fractf(nx);
-            const float off = k.period * ph;                     // fma(period, ph, +0) with a product >= +0
+            const float off = period * ph;                       // fma(period, ph, +0) with a product >= +0
             // fmodf(off, period) on [0, period] (off == period -> 0): both are non-negative floats, so
             // bits(off) - bits(period) is negative exactly when off < period (the compiler turns this into an
             // integer compare + select on an SGPR pair, cheaper here than the float compare through VCC)
-            const int32_t keep = ((int32_t)s2r_f2u(off) - (int32_t)s2r_f2u(k.period)) >> 31;
+            const int32_t keep = ((int32_t)s2r_f2u(off) - (int32_t)s2r_f2u(period)) >> 31;
             const float x = s2r_u2f(s2r_f2u(off) & (uint32_t)keep);
             float osc;
-            if (OSC == S2R_OSC_SAW) osc = __builtin_fmaf(k.a, x, 1.0f);
-            else if (OSC == S2R_OSC_SQUARE) osc = x < k.a ? 1.0f : -1.0f;
+            if (OSC == S2R_OSC_SAW) osc = __builtin_fmaf(ka, x, 1.0f);
+            else if (OSC == S2R_OSC_SQUARE) osc = x < ka ? 1.0f : -1.0f;
             else if (OSC == S2R_OSC_TRIANGLE) {
-                const float first = __builtin_fmaf(k.b, x, 1.0f), second = __builtin_fmaf(k.c, x - k.a, -1.0f);
-                osc = x < k.a ? first : second;
+                const float first = __builtin_fmaf(kb, x, 1.0f), second = __builtin_fmaf(kc, x - ka, -1.0f);
+                osc = x < ka ? first : second;
             } else {
-                const float tv = s2r_div_by_rcp64(x * 1024.0f, rcp_period);     // == x * 1024 / period, exactly (s2r_math.h)
+                // x * 1024 / period: through the run's double reciprocal, exactly (s2r_math.h); a true division when
+                // the period changes every frame
+                const float tv = FMV ? x * 1024.0f / period : s2r_div_by_rcp64(x * 1024.0f, rcp_period);
                 const uint32_t i1 = s2r_f32_as_u32(tv), i2 = (i1 + 1u) & 1023u;
                 const float2 pr = sin_pair(sSin, i2);
                 const float s1 = i1 < 1024u ? pr.x : 0.0f, s2 = pr.y;
@@ -905,12 +926,16 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
         (FM || __ballot(!(k_const.period > 0.0f && k_const.period < __builtin_inff())) == 0ull);
     // coefficient stream for this wave's 64-voice group, if one was prepared (wave-uniform)
     int32_t slot = -1;
-    if (!FM && p.use_coeff && p.coeff_count[p.coeff_parity] <= p.coeff_capacity)
+    if (p.use_coeff && p.coeff_count[p.coeff_parity] <= p.coeff_capacity)
         slot = p.group_slot[__builtin_amdgcn_readfirstlane((blockIdx.x * block_voices + tid / L) / 64u)];
     const bool have_stream = slot >= 0;
-    const f4 *stream = (const f4 *)p.coeff + ((size_t)(have_stream ? slot : 0) * (x16_frames / kP)) * 64u + ((tid / L) & 63u);
+    // under oscillator FM the stream holds three vectors per quad and only the branch-free chunks read it; the
+    // general path then computes in-lane as if there were none
+    constexpr uint32_t kVec = FM ? 3u : 1u;
+    const bool have_stream_gp = have_stream && !FM;
+    const f4 *stream = (const f4 *)p.coeff + ((size_t)(have_stream ? slot : 0) * (x16_frames / kP)) * kVec * 64u + ((tid / L) & 63u);
     f4 xc_next = splat(0.0f);
-    if (have_stream && x16_frames) xc_next = stream[(size_t)sub * 64u];
+    if (have_stream_gp && x16_frames) xc_next = stream[(size_t)sub * 64u];
     const size_t pv_base = (size_t)vi * p.frames;
     const bool pv_lane = in_range && sub == 0;
     float *bp = p.block_partials + (size_t)blockIdx.x * p.frames_stride;
@@ -987,7 +1012,7 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
                     else if (clear_for(left)) run = left;
                     else if (left > 4u && clear_for(4u)) run = 4u;
                     else if (clear_for(1u)) run = 1u;
-                    if (FM && run) {
+                    if (FM && run && !have_stream) {
                         const bool fm_flat = !p.no_flat_shortcut &&
                             __ballot(em.slope != 0.0f || !(fc.k.period > 0.0f && fc.k.period < __builtin_inff())) == 0ull;
                         if (!fm_flat) run = 0;
@@ -1014,20 +1039,20 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
                                 float prev = 0.0f;
                                 if (i) prev = tile_sum((i - 1u) & 1u);
                                 float *pvd = (PV && pv_lane) ? p.per_voice + pv_base + sc0 + f0 : nullptr;
-                                const f4 *sq = stream + (size_t)((sc0 + f0) / kP) * 64u;
-                                chunk_fast<OSC, SRC>(p, r, ea, em, fc, FM ? fc.k : k_const, o_chunk + i * kChunk, sq, sT, sSin, live,
-                                                     tile + (i & 1u) * kTile + col, VW + 1, pvd);
+                                const f4 *sq = stream + (size_t)((sc0 + f0) / kP) * kVec * 64u;
+                                chunk_fast<OSC, SRC, 0, (FM && SRC == 1)>(p, r, ea, em, fc, FM ? fc.k : k_const, o_chunk + i * kChunk, sq, sT, sSin, live,
+                                                                          tile + (i & 1u) * kTile + col, VW + 1, pvd);
                                 if (i && r_on) sw_row[f0 - kChunk] = prev;
                             }
                             const float last = tile_sum((run - 1u) & 1u);
                             if (r_on) sw_row[c16 + (run - 1u) * kChunk] = last;
                         };
-                        if (FM) run_chunks(std::integral_constant<int, 0>{});        // flat everywhere (checked above)
-                        else if (have_stream) run_chunks(std::integral_constant<int, 1>{});
+                        if (have_stream) run_chunks(std::integral_constant<int, 1>{});
+                        else if (FM) run_chunks(std::integral_constant<int, 0>{});   // flat everywhere (checked above)
                         else if (!p.no_flat_shortcut && __ballot(live && em.slope != 0.0f) == 0ull) run_chunks(std::integral_constant<int, 0>{});
                         else run_chunks(std::integral_constant<int, 2>{});
                         c16 += (run - 1u) * kChunk;
-                        if (have_stream) {                       // keep the general path's one-ahead prefetch coherent
+                        if (have_stream_gp) {                    // keep the general path's one-ahead prefetch coherent
                             const uint32_t qn = (sc0 + c16 + kChunk) / kP + sub;
                             if (qn < x16_frames / kP) xc_next = stream[(size_t)qn * 64u];
                         }
@@ -1038,12 +1063,12 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
                     // closed-form work of frames sc0+g+4*sub .. +3 on this lane
                     FrameCF4 cf; OscK4 kf;
                     const f4 xc_now = xc_next;
-                    if (have_stream) {       // prefetch the next group's quadruple while this one is consumed
+                    if (have_stream_gp) {    // prefetch the next group's quadruple while this one is consumed
                         const uint32_t qn = (sc0 + g + G) / kP + sub;
                         if (qn < x16_frames / kP) xc_next = stream[(size_t)qn * 64u];
                     }
                     closed_form_x4<OSC, FM>(p, r, ea, em, thr_min, fc, r.offset + sc0 + g + kP * sub, sT,
-                                                     have_stream, xc_now, cf, kf);
+                                                     have_stream_gp, xc_now, cf, kf);
                     // recurrence for the 4*L frames of the group, every lane of the voice alike
 #define S2R_QUAD(Q)                                                                              \
                     if constexpr (Q < L) {                                                       \
@@ -1574,12 +1599,22 @@ hipError_t launch_osc(const S2rRenderParams &p, uint32_t block_voices, uint32_t 
 
 }  // namespace
 
+static void launch_coeff_pass(const S2rRenderParams &p, hipStream_t stream) {
+    const bool fm = p.amt_osc != 0.0f;
+    if (p.fast_div_sr) {
+        if (fm) hipLaunchKernelGGL((s2r_coeff_kernel<true, true>), dim3(2048), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((s2r_coeff_kernel<true, false>), dim3(2048), dim3(256), 0, stream, p);
+    } else {
+        if (fm) hipLaunchKernelGGL((s2r_coeff_kernel<false, true>), dim3(2048), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((s2r_coeff_kernel<false, false>), dim3(2048), dim3(256), 0, stream, p);
+    }
+}
+
 hipError_t s2r_launch_coeff(const S2rRenderParams &p, hipStream_t stream) {
     if (!p.use_coeff || p.n_voices == 0 || p.frames < 16u) return hipSuccess;
     const uint32_t n_groups64 = (p.n_voices + 63u) / 64u;
     hipLaunchKernelGGL(s2r_classify_kernel, dim3(n_groups64), dim3(64), 0, stream, p);
-    if (p.fast_div_sr) hipLaunchKernelGGL(s2r_coeff_kernel<true>, dim3(2048), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(s2r_coeff_kernel<false>, dim3(2048), dim3(256), 0, stream, p);
+    launch_coeff_pass(p, stream);
     return hipGetLastError();
 }
 
@@ -1587,8 +1622,7 @@ hipError_t s2r_launch_prep(const S2rPrepParams &a, hipStream_t stream) {
     if (a.p.n_voices == 0 || a.p.frames < 16u || !a.p.use_coeff) return hipErrorInvalidValue;
     const uint32_t n_groups64 = (a.p.n_voices + 63u) / 64u;
     hipLaunchKernelGGL(s2r_prep_kernel, dim3(n_groups64), dim3(64), 0, stream, a);
-    if (a.p.fast_div_sr) hipLaunchKernelGGL(s2r_coeff_kernel<true>, dim3(2048), dim3(256), 0, stream, a.p);
-    else hipLaunchKernelGGL(s2r_coeff_kernel<false>, dim3(2048), dim3(256), 0, stream, a.p);
+    launch_coeff_pass(a.p, stream);
     return hipGetLastError();
 }
 

@@ -814,3 +814,29 @@ def test_oversampled_4x_fill(kind):
                 pr.note_off(n)
     with pytest.raises(s2.S2rError):
         pr.gpu.sample_oversampled(1025, SR)              # 4 x 1025 > max_frames
+
+
+@pytest.mark.parametrize("osc", [s2.OSC_SQUARE, s2.OSC_SAW, s2.OSC_TRIANGLE, s2.OSC_SINE])
+@pytest.mark.parametrize("mode", [3, 4, 0])
+def test_fm_patch_through_the_coefficient_stream(osc, mode):
+    """oscillator FM while the mod envelope moves: the stream carries the LPF coefficient, the period
+    and its reciprocal per frame and the branch-free chunk reads them (mode 3/4: forced on for this small
+    pool, events in the classification launch / separate kernels; 0: everything in-lane)"""
+    patch = make_patch(osc_kind=osc, mod_env_to_osc_freq=3.25, mod_env_to_lpf_freq=6.0, noise=0.15, osc_gain=0.8)
+    patch.mod_env.attack_ms = 40.0
+    patch.mod_env.decay_ms = 60.0
+    patch.mod_env.sustain = 0.35
+    patch.mod_env.release_ms = 50.0
+    pr = Pair(320, patch, max_frames=1024)
+    pr.gpu.set_coeff_stream(mode)
+    for v in range(250):
+        pr.note_on(26 + (v * 5) % 85)
+    for k in range(9):
+        g, o, _pv = pr.sample(1024 if k != 4 else 1000)
+        assert_bits_equal(g, o, "fm through the stream, osc %d, mode %d, buffer %d" % (osc, mode, k))
+        if k == 2:
+            for n in range(26, 111, 3):
+                pr.note_off(n)
+        if k in (3, 6):
+            for v in range(30):
+                pr.note_on(35 + v)
