@@ -257,10 +257,10 @@ int check_fill(s2r_synth *s, size_t frames, uint32_t sample_rate) {
 // The coefficient stream (and with it the classification launch) pays when a fill has many chunks
 // and the shard many waves; a 16-frame fill of a handful of voices — s2_bin's own call pattern,
 // main.rs:138-143 — is quicker without the two extra launches (28 -> 22 us per call).  Only where it is
-// defined: one-pole patch, the flat-envelope logic enabled.
+// defined: a single patch (the dsp_filters.rs kinds with workgroups of up to 256 voices), the flat-envelope logic enabled.
 bool stream_wanted(const s2r_synth *s, size_t frames) {
     return s->use_coeff && !s->no_flat_shortcut && s->coeff != nullptr && s->bank.size() == 1 &&
-           s->bank[0].lpf_kind == S2R_FILT_ONEPOLE &&
+           (s->bank[0].lpf_kind == S2R_FILT_ONEPOLE || s->block_voices <= 256u) &&
            (s->force_stream || (frames >= 128 && s->shard_voices >= 1024u));
 }
 
@@ -332,13 +332,15 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
         S2R_HIP(s, hipStreamSynchronize(stream));
         s->bank_dirty = false; s->bank_rate = sample_rate;
     }
-    if (stream_wanted(s, frames) && s->bank[0].mod_env_to_osc_freq != 0.0f && s->coeff_vecs < 3u) {
-        // first streamed fill of an oscillator-FM patch: the stream carries (coefficient, period, 1 / period)
+    const uint32_t vecs_needed = (s->bank[0].lpf_kind != S2R_FILT_ONEPOLE ? 3u : 1u) + (s->bank[0].mod_env_to_osc_freq != 0.0f ? 2u : 0u);
+    if (stream_wanted(s, frames) && s->coeff_vecs < vecs_needed) {
+        // first streamed fill of a patch that needs more per frame than the one-pole's coefficient: three filter
+        // coefficients for the dsp_filters.rs kinds / the SVF, the period and its reciprocal under oscillator FM
         S2R_HIP(s, hipStreamSynchronize(stream));
         S2R_HIP(s, hipStreamSynchronize(s->stream));
         S2R_HIP(s, hipFree(s->coeff)); s->coeff = nullptr;
-        S2R_HIP(s, hipMalloc((void **)&s->coeff, (size_t)3 * s->coeff_capacity * s->cfg.max_frames * 64 * sizeof(float)));
-        s->coeff_vecs = 3u;
+        S2R_HIP(s, hipMalloc((void **)&s->coeff, (size_t)vecs_needed * s->coeff_capacity * s->cfg.max_frames * 64 * sizeof(float)));
+        s->coeff_vecs = vecs_needed;
     }
     S2rRenderParams p = make_params(s, frames, sample_rate);
     p.per_voice = per_voice_dev;

@@ -591,7 +591,7 @@ __global__ void __launch_bounds__(64) s2r_classify_kernel(const S2rRenderParams 
     }
 }
 
-template <bool FASTDIV, bool FM>
+template <bool FASTDIV, bool FM, bool DSPF>
 __global__ void __launch_bounds__(256) s2r_coeff_kernel(const S2rRenderParams p) {
     __shared__ uint64_t sT[S2R_EXP2F_N];
     if (threadIdx.x < S2R_EXP2F_N) sT[threadIdx.x] = c_exp2f_table[threadIdx.x];
@@ -613,7 +613,7 @@ __global__ void __launch_bounds__(256) s2r_coeff_kernel(const S2rRenderParams p)
         const float ro_m = __builtin_fmaxf(rel_f, p.mod.sus_off), end_m = ro_m + p.mod.R;
         EnvRun em = env_stage_at(p.mod, ro_m, end_m, 0.0f);
         float thr = -__builtin_inff();
-        constexpr uint32_t kVec = FM ? 3u : 1u;                  // per quad: xc [, period, 1 / period]
+        constexpr uint32_t kBase = DSPF ? 3u : 1u, kVec = kBase + (FM ? 2u : 0u);   // per quad: xc | alpha, beta, gamma [, period, 1 / period]
         const float pitch = (FM && in_range && (flags & S2R_VF_STARTED)) ? p.v.pitch[vi] : 440.0f;
         f4 *dst = (f4 *)p.coeff + ((size_t)slot * n_quads + (size_t)chunk * kQuadsPerItem) * kVec * 64u + lane;
         const uint32_t q1 = (chunk + 1) * kQuadsPerItem < n_quads ? kQuadsPerItem : n_quads - chunk * kQuadsPerItem;
@@ -629,13 +629,25 @@ __global__ void __launch_bounds__(256) s2r_coeff_kernel(const S2rRenderParams p)
             }
             const f4 f_lpf = pow2_sleef_core4(mod * splat(p.amt_lpf)) * splat(p.lpf_freq);
             const f4 num = splat(-2.0f * 3.14159274101257324f) * f_lpf;
-            const f4 arg = FASTDIV ? div_const_nocheck4(num, p.sr, p.rcp_sr) : (num / splat(p.sr));
-            dst[(size_t)(q * kVec) * 64u] = expf4(arg, sT);
+            if (DSPF) {                                          // dsp_filters.rs / SVF coefficients at the modulated cutoff
+                f4 al, be, ga;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const FiltCoef fc = dsp_filter_coef(p.lpf_kind, p.lpf_damping, p.sr, f_lpf[c]);
+                    al[c] = fc.alpha; be[c] = fc.beta; ga[c] = fc.gamma;
+                }
+                dst[(size_t)(q * kVec) * 64u] = al;
+                dst[(size_t)(q * kVec + 1u) * 64u] = be;
+                dst[(size_t)(q * kVec + 2u) * 64u] = ga;
+            } else {
+                const f4 arg = FASTDIV ? div_const_nocheck4(num, p.sr, p.rcp_sr) : (num / splat(p.sr));
+                dst[(size_t)(q * kVec) * 64u] = expf4(arg, sT);
+            }
             if (FM) {
                 const f4 f_osc = pow2_sleef_core4(mod * splat(p.amt_osc)) * splat(pitch);       // process.rs:146-147,231-250
                 const f4 period = splat(p.sr) / f_osc;                                             // units.rs:32-42
-                dst[(size_t)(q * kVec + 1u) * 64u] = period;
-                dst[(size_t)(q * kVec + 2u) * 64u] = splat(1.0f) / period;                         // oscillators.rs:378
+                dst[(size_t)(q * kVec + kBase) * 64u] = period;
+                dst[(size_t)(q * kVec + kBase + 1u) * 64u] = splat(1.0f) / period;                 // oscillators.rs:378
             }
         }
     }
@@ -742,13 +754,16 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
                                            const uint64_t *sT, const float *sSin, bool live, float *tile_col,
                                            uint32_t tile_stride, float *pv_dst,
                                            const FiltCoef *fcoef = nullptr, Filt2 *f2 = nullptr) {
-    f4 xq[4], pq[4], iq[4];
-    constexpr uint32_t kVec = FMV ? 3u : 1u;                      // vectors per quad in the stream
+    // stream layout per quad: the filter's coefficients (one vector for the one-pole, alpha / beta / gamma for the
+    // others), then under FM the period and its reciprocal
+    f4 xq[4], bq[4], gq[4], pq[4], iq[4];
+    constexpr uint32_t kBase = FILT != 0 ? 3u : 1u, kVec = kBase + (FMV ? 2u : 0u);
     if (SRC == 1) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                            // coalesced 16-byte loads, used last
             xq[q] = stream_q[(size_t)(q * kVec) * 64u];
-            if (FMV) { pq[q] = stream_q[(size_t)(q * kVec + 1u) * 64u]; iq[q] = stream_q[(size_t)(q * kVec + 2u) * 64u]; }
+            if (FILT != 0) { bq[q] = stream_q[(size_t)(q * kVec + 1u) * 64u]; gq[q] = stream_q[(size_t)(q * kVec + 2u) * 64u]; }
+            if (FMV) { pq[q] = stream_q[(size_t)(q * kVec + kBase) * 64u]; iq[q] = stream_q[(size_t)(q * kVec + kBase + 1u) * 64u]; }
         }
     }
     const double rcp_period = (OSC == S2R_OSC_SINE && !FMV) ? s2r_rcp_f64(k.period) : 0.0;   // constant over the run: hoisted by the compiler
@@ -820,7 +835,9 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
                 out = y * ampq[j];
             } else {
                 // (a dead lane's filter state may run away on its made-up input: select per frame here)
-                const float y = dsp_filter_apply(FILT, *fcoef, s, *f2);
+                FiltCoef cj = *fcoef;                            // the run's constants, or this frame's from the stream
+                if (SRC == 1) { cj.alpha = xq[q][j]; cj.beta = bq[q][j]; cj.gamma = gq[q][j]; }
+                const float y = dsp_filter_apply(FILT, cj, s, *f2);
                 out = live ? y * amp[q][j] : 0.0f;
             }
             tile_col[(4 * q + j) * tile_stride] = out;
@@ -1246,7 +1263,8 @@ __global__ void __launch_bounds__(MAXT) s2r_render_general_kernel(const S2rRende
     uint32_t mod_key = 0xffffffffu;          // bits of the mod value `k`, `xc`, `fc` were computed for (a NaN: never equal)
     OscK k = make_osck_any<OSC>(lp.osc_kind, lp.sr / r.pitch);
     float xc = 0.0f;                         // one-pole coefficient exp(-2 pi f / sr), filters.rs:21
-    FiltCoef fc; fc.alpha = fc.beta = fc.gamma = fc.k = 0.0f;
+    FiltCoef fc; fc.alpha = fc.beta = fc.gamma = 0.0f;
+    fc.k = lp.lpf_kind >= S2R_FILT_SVF_LP ? 1.0f / lp.lpf_damping : 0.0f;   // the SVF's k = 1 / q does not depend on the cutoff
     if (TEV && in_range) {
         ev_idx = p.voice_ev_head[vi];
         if (ev_idx >= 0) { ev_frame = p.tev[ev_idx].frame; p.voice_ev_head[vi] = -1; }
@@ -1258,6 +1276,16 @@ __global__ void __launch_bounds__(MAXT) s2r_render_general_kernel(const S2rRende
     const size_t pv_base = (size_t)vi * p.frames;
     float *bp = p.block_partials + (size_t)blockIdx.x * p.frames_stride;
     uint32_t buf = 0;
+    // coefficient stream of this wave's 64-voice group (single patch, 256-thread workgroups): alpha / beta / gamma
+    // per frame, and under oscillator FM the period and its reciprocal
+    constexpr bool kFast = !BANK && MAXT == 256;
+    const bool fmv = p.amt_osc != 0.0f;                          // kernel argument: uniform
+    int32_t slot = -1;
+    if (kFast && p.use_coeff && p.coeff_count[p.coeff_parity] <= p.coeff_capacity)
+        slot = p.group_slot[__builtin_amdgcn_readfirstlane(vi / 64u)];
+    const bool have_stream = slot >= 0;
+    const uint32_t stream_vecs = 3u + (fmv ? 2u : 0u);
+    const f4 *stream = (const f4 *)p.coeff + ((size_t)(have_stream ? slot : 0) * (x16_frames / kP)) * stream_vecs * 64u + lane;
 
     auto reduce_chunk = [&](uint32_t f_base, uint32_t n_frames) {
         const uint32_t f = lane & 15u, grp = lane >> 4;
@@ -1319,8 +1347,8 @@ __global__ void __launch_bounds__(MAXT) s2r_render_general_kernel(const S2rRende
                 // every lane's mod envelope sits in a zero-slope stage for the whole chunk: its value (0 * (t -
                 // base) + y0, the same bits on every frame) is looked at once instead of per frame
                 const bool flat = calm && __ballot(em.slope != 0.0f) == 0ull;
-                if (flat) refresh(env_value(em, (float)(r.offset + sc0 + c16)));
-                if (!BANK && flat) {
+                if (flat && !have_stream) refresh(env_value(em, (float)(r.offset + sc0 + c16)));
+                if (kFast && calm && (flat || have_stream)) {
                     // One patch, every lane's mod envelope flat: oscillator constants and filter coefficients are
                     // constants of the run, so the branch-free chunk of the one-pole kernel applies with this
                     // patch's filter in its recurrence.  Same run rule: the LAST frame of the run is below every
@@ -1332,17 +1360,21 @@ __global__ void __launch_bounds__(MAXT) s2r_render_general_kernel(const S2rRende
                     };
                     uint32_t run = 1u;                           // `calm` already covers this chunk
                     if (!TEV) { if (clear_for(left)) run = left; else if (left > 4u && clear_for(4u)) run = 4u; }
-                    if (__ballot(!(k.period > 0.0f && k.period < __builtin_inff() && r.phase >= 0.0f && r.phase < 1.0f)) != 0ull) run = 0u;
+                    if (__ballot(!(((have_stream && fmv) || (k.period > 0.0f && k.period < __builtin_inff())) && r.phase >= 0.0f && r.phase < 1.0f)) != 0ull) run = 0u;
                     if (run) {
                         run = (uint32_t)__builtin_amdgcn_readfirstlane((int)run);
                         FlatCache fcx; fcx.xc = xc; fcx.k = k;
                         auto run_chunks = [&](auto filt_tag) {
                             constexpr int FILT = decltype(filt_tag)::value;
+                            constexpr int O = OSC == S2R_OSC_ANY ? 0 : OSC;
                             for (uint32_t i = 0; i < run; ++i) {
                                 const uint32_t f0 = c16 + i * kChunk;
                                 float *pvd = (PV && in_range) ? p.per_voice + pv_base + sc0 + f0 : nullptr;
-                                chunk_fast<(OSC == S2R_OSC_ANY ? 0 : OSC), 0, FILT>(p, r, ea, em, fcx, k, o_chunk + i * kChunk, nullptr, sT, sSin,
-                                                                                 live, tile + lane, VW + 1, pvd, &fc, &f2);
+                                const f4 *sq = stream + (size_t)((sc0 + f0) / kP) * stream_vecs * 64u;
+                                float *tc = tile + lane;
+                                if (!have_stream) chunk_fast<O, 0, FILT>(p, r, ea, em, fcx, k, o_chunk + i * kChunk, sq, sT, sSin, live, tc, VW + 1, pvd, &fc, &f2);
+                                else if (fmv) chunk_fast<O, 1, FILT, true>(p, r, ea, em, fcx, k, o_chunk + i * kChunk, sq, sT, sSin, live, tc, VW + 1, pvd, &fc, &f2);
+                                else chunk_fast<O, 1, FILT, false>(p, r, ea, em, fcx, k, o_chunk + i * kChunk, sq, sT, sSin, live, tc, VW + 1, pvd, &fc, &f2);
                                 reduce_chunk(f0, kChunk);
                             }
                         };
@@ -1355,7 +1387,7 @@ __global__ void __launch_bounds__(MAXT) s2r_render_general_kernel(const S2rRende
                         case S2R_FILT_SVF_LP: run_chunks(std::integral_constant<int, S2R_FILT_SVF_LP>{}); break;
                         case S2R_FILT_SVF_BP: run_chunks(std::integral_constant<int, S2R_FILT_SVF_BP>{}); break;
                         case S2R_FILT_SVF_HP: run_chunks(std::integral_constant<int, S2R_FILT_SVF_HP>{}); break;
-                        default: run_chunks(std::integral_constant<int, S2R_FILT_ONEPOLE>{}); break;
+                        default: break;                          // (the one-pole has its own kernel)
                         }
                         c16 += (run - 1u) * kChunk;
                         continue;
@@ -1601,12 +1633,15 @@ hipError_t launch_osc(const S2rRenderParams &p, uint32_t block_voices, uint32_t 
 
 static void launch_coeff_pass(const S2rRenderParams &p, hipStream_t stream) {
     const bool fm = p.amt_osc != 0.0f;
-    if (p.fast_div_sr) {
-        if (fm) hipLaunchKernelGGL((s2r_coeff_kernel<true, true>), dim3(2048), dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((s2r_coeff_kernel<true, false>), dim3(2048), dim3(256), 0, stream, p);
+    if (p.lpf_kind != S2R_FILT_ONEPOLE) {
+        if (fm) hipLaunchKernelGGL((s2r_coeff_kernel<false, true, true>), dim3(2048), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((s2r_coeff_kernel<false, false, true>), dim3(2048), dim3(256), 0, stream, p);
+    } else if (p.fast_div_sr) {
+        if (fm) hipLaunchKernelGGL((s2r_coeff_kernel<true, true, false>), dim3(2048), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((s2r_coeff_kernel<true, false, false>), dim3(2048), dim3(256), 0, stream, p);
     } else {
-        if (fm) hipLaunchKernelGGL((s2r_coeff_kernel<false, true>), dim3(2048), dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((s2r_coeff_kernel<false, false>), dim3(2048), dim3(256), 0, stream, p);
+        if (fm) hipLaunchKernelGGL((s2r_coeff_kernel<false, true, false>), dim3(2048), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((s2r_coeff_kernel<false, false, false>), dim3(2048), dim3(256), 0, stream, p);
     }
 }
 

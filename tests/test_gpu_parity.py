@@ -840,3 +840,29 @@ def test_fm_patch_through_the_coefficient_stream(osc, mode):
         if k in (3, 6):
             for v in range(30):
                 pr.note_on(35 + v)
+
+
+@pytest.mark.parametrize("kind", DSP_KINDS)
+@pytest.mark.parametrize("fm,mode", [(0.0, 3), (1.75, 4)])
+def test_dsp_filters_through_the_coefficient_stream(kind, fm, mode):
+    """the first/second-order filters and the SVF with a moving mod envelope: alpha / beta / gamma per frame
+    come from the stream (plus period and 1/period under oscillator FM), forced on for this small pool"""
+    patch = make_patch(osc_kind=s2.OSC_SAW if kind % 2 else s2.OSC_SINE, lpf_kind=kind, lpf_freq=700.0, mod_env_to_lpf_freq=4.0,
+                       mod_env_to_osc_freq=fm, lpf_damping=0.7, lpf_q=2.5, noise=0.1)
+    patch.mod_env.attack_ms = 30.0
+    patch.mod_env.decay_ms = 45.0
+    patch.mod_env.sustain = 0.3
+    patch.mod_env.release_ms = 35.0
+    pr = Pair(320, patch, max_frames=1024)
+    pr.gpu.set_coeff_stream(mode)
+    for v in range(250):
+        pr.note_on(26 + (v * 5) % 85)
+    for k in range(8):
+        g, o, _pv = pr.sample(1024 if k != 3 else 1000)
+        assert_bits_equal(g, o, "filter %d through the stream, fm %g, mode %d, buffer %d" % (kind, fm, mode, k))
+        if k == 2:
+            for n in range(26, 111, 3):
+                pr.note_off(n)
+        if k == 5:
+            for v in range(30):
+                pr.note_on(35 + v)
