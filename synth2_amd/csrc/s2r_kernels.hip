@@ -1364,19 +1364,24 @@ __global__ void __launch_bounds__(MAXT) s2r_render_general_kernel(const S2rRende
                     if (run) {
                         run = (uint32_t)__builtin_amdgcn_readfirstlane((int)run);
                         FlatCache fcx; fcx.xc = xc; fcx.k = k;
+                        const FiltCoef fcc = fc;                 // the run's constants, by value
                         auto run_chunks = [&](auto filt_tag) {
                             constexpr int FILT = decltype(filt_tag)::value;
                             constexpr int O = OSC == S2R_OSC_ANY ? 0 : OSC;
-                            for (uint32_t i = 0; i < run; ++i) {
-                                const uint32_t f0 = c16 + i * kChunk;
-                                float *pvd = (PV && in_range) ? p.per_voice + pv_base + sc0 + f0 : nullptr;
-                                const f4 *sq = stream + (size_t)((sc0 + f0) / kP) * stream_vecs * 64u;
-                                float *tc = tile + lane;
-                                if (!have_stream) chunk_fast<O, 0, FILT>(p, r, ea, em, fcx, k, o_chunk + i * kChunk, sq, sT, sSin, live, tc, VW + 1, pvd, &fc, &f2);
-                                else if (fmv) chunk_fast<O, 1, FILT, true>(p, r, ea, em, fcx, k, o_chunk + i * kChunk, sq, sT, sSin, live, tc, VW + 1, pvd, &fc, &f2);
-                                else chunk_fast<O, 1, FILT, false>(p, r, ea, em, fcx, k, o_chunk + i * kChunk, sq, sT, sSin, live, tc, VW + 1, pvd, &fc, &f2);
-                                reduce_chunk(f0, kChunk);
-                            }
+                            auto loop = [&](auto src_tag, auto fmv_tag) {          // one tight loop per coefficient source
+                                constexpr int SRC = decltype(src_tag)::value;
+                                constexpr bool FMV = decltype(fmv_tag)::value;
+                                for (uint32_t i = 0; i < run; ++i) {
+                                    const uint32_t f0 = c16 + i * kChunk;
+                                    float *pvd = (PV && in_range) ? p.per_voice + pv_base + sc0 + f0 : nullptr;
+                                    const f4 *sq = stream + (size_t)((sc0 + f0) / kP) * stream_vecs * 64u;
+                                    chunk_fast<O, SRC, FILT, FMV>(p, r, ea, em, fcx, k, o_chunk + i * kChunk, sq, sT, sSin, live, tile + lane, VW + 1, pvd, &fcc, &f2);
+                                    reduce_chunk(f0, kChunk);
+                                }
+                            };
+                            if (!have_stream) loop(std::integral_constant<int, 0>{}, std::false_type{});
+                            else if (fmv) loop(std::integral_constant<int, 1>{}, std::true_type{});
+                            else loop(std::integral_constant<int, 1>{}, std::false_type{});
                         };
                         switch (lp.lpf_kind) {                   // wave-uniform: the patch is a kernel argument here
                         case S2R_FILT_LP1: run_chunks(std::integral_constant<int, S2R_FILT_LP1>{}); break;
