@@ -155,7 +155,7 @@ hipError_t s2r_launch_prep(const S2rPrepParams &a, hipStream_t stream);      // 
 hipError_t s2r_launch_render(const S2rRenderParams &p, uint32_t block_voices, uint32_t lanes_per_voice, hipStream_t stream);
 hipError_t s2r_launch_mix(const S2rMixParams &p, hipStream_t stream);
 hipError_t s2r_launch_events(const S2rVoiceArrays &v, const S2rVoiceEvent *dev_events, uint32_t n, hipStream_t stream);
-hipError_t s2r_launch_tev_heads(int32_t *heads, const S2rTimedEvent *tev, uint32_t n, hipStream_t stream);
+hipError_t s2r_launch_tev_heads(int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n, hipStream_t stream);
 // build-defined 4x decimator: x = 62 samples of history + 4 * n_out new ones, h = 63 taps (device), and the
 // last 62 inputs copied to the front of x afterwards (second launch) for the next call
 hipError_t s2r_launch_decimate4(float *x_with_history, const float *taps, uint32_t n_out, float *out, hipStream_t stream);

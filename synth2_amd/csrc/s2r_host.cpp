@@ -120,6 +120,7 @@ struct s2r_synth {
     uint32_t fill_time = 0;                      // frames of the next fill the pool clock has already moved
     uint32_t tev_capacity = 0;
     int32_t *voice_ev_head = nullptr;
+    S2rTimedEvent *tev_copy = nullptr;           // the fill's timed events in HBM (copied from the mapped slot by the heads kernel)
     // device
     hipStream_t stream = nullptr;
     S2rVoiceArrays v{};
@@ -210,8 +211,8 @@ int flush_events(s2r_synth *s, hipStream_t stream, EventSlot **timed_slot, const
     const uint32_t nt = (uint32_t)s->tpending.size();
     if (nt) {
         std::memcpy(sl.thost, s->tpending.data(), nt * sizeof(S2rTimedEvent));
-        S2R_HIP(s, s2r_launch_tev_heads(s->voice_ev_head, sl.tdev, nt, stream));
-        *timed_slot = &sl; *tev_dev = sl.tdev;
+        S2R_HIP(s, s2r_launch_tev_heads(s->voice_ev_head, sl.tdev, s->tev_copy, nt, stream));
+        *timed_slot = &sl; *tev_dev = s->tev_copy;         // the kernels read the HBM copy
         for (const S2rTimedEvent &e : s->tpending) s->tlast[e.voice] = -1;
         s->tpending.clear();
     } else {
@@ -429,6 +430,7 @@ void release_all(s2r_synth *s) {
     if (s->sin_dev) (void)hipFree(s->sin_dev);
     if (s->per_voice_dev) (void)hipFree(s->per_voice_dev);
     if (s->voice_ev_head) (void)hipFree(s->voice_ev_head);
+    if (s->tev_copy) (void)hipFree(s->tev_copy);
     if (s->group_slot) (void)hipFree(s->group_slot);
     if (s->slot_group) (void)hipFree(s->slot_group);
     if (s->coeff_count) (void)hipFree(s->coeff_count);
@@ -558,6 +560,7 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
         CREATE_HIP(hipHostGetDevicePointer((void **)&sl.tdev, sl.thost, 0));
     }
     CREATE_HIP(hipMalloc((void **)&s->voice_ev_head, pv * sizeof(int32_t)));
+    CREATE_HIP(hipMalloc((void **)&s->tev_copy, (size_t)s->tev_capacity * sizeof(S2rTimedEvent)));
     CREATE_HIP(hipMemsetAsync(s->voice_ev_head, 0xff, pv * sizeof(int32_t), s->stream));
     {
         // coefficient stream: room for half of the 64-voice groups (beyond that the in-lane path is

@@ -567,8 +567,8 @@ __global__ void __launch_bounds__(64) s2r_classify_kernel(const S2rRenderParams 
     if (group == 0 && lane == 0) p.coeff_count[p.coeff_parity ^ 1u] = 0u;       // ready for the next fill
     bool moving = false, timed = false;
     if (vi < p.n_voices) {
-        // a voice that is re-triggered or released inside this fill invalidates anything computed
-        // from its state at the start of the fill: its whole group computes in-lane
+        // a voice that is re-triggered or released inside this fill: its group streams, and the coefficient
+        // pass follows the voice's event chain chunk by chunk
         if (p.tev != nullptr) timed = p.voice_ev_head[vi] >= 0;
         const uint32_t flags = p.v.flags[vi];
         if (flags & S2R_VF_STARTED) {
@@ -580,7 +580,7 @@ __global__ void __launch_bounds__(64) s2r_classify_kernel(const S2rRenderParams 
             moving = !(e0.slope == 0.0f && t_last < e0.thr);
         }
     }
-    const bool any = __ballot(moving) != 0ull && __ballot(timed) == 0ull;
+    const bool any = __ballot(moving || timed) != 0ull;
     if (lane == 0) {
         int32_t slot = -1;
         if (any) {
@@ -607,14 +607,33 @@ __global__ void __launch_bounds__(256) s2r_coeff_kernel(const S2rRenderParams p)
         const uint32_t slot = it / chunks, chunk = it % chunks;
         const uint32_t vi = p.slot_group[slot] * 64u + lane;
         const bool in_range = vi < p.n_voices;
-        const uint32_t flags = in_range ? p.v.flags[vi] : 0u;
-        const uint32_t offset = in_range ? p.v.offset[vi] : 0u;
-        const float rel_f = (flags & S2R_VF_RELEASED) ? (float)p.v.release[vi] : 4294967296.0f;
+        uint32_t flags = in_range ? p.v.flags[vi] : 0u;
+        uint32_t offset = in_range ? p.v.offset[vi] : 0u;
+        uint32_t release = (flags & S2R_VF_RELEASED) ? p.v.release[vi] : 0u;
+        float pitch = (FM && in_range && (flags & S2R_VF_STARTED)) ? p.v.pitch[vi] : 440.0f;
+        if (p.tev != nullptr && in_range) {
+            // note events inside this fill (they land on 16-frame boundaries == item boundaries): the voice's state
+            // for this item's frames is its state at the start of the fill with every event up to the item's first
+            // frame applied, exactly as the render kernel applies them (apply_events_at)
+            const uint32_t first = chunk * kQuadsPerItem * kP;
+            int32_t ei = p.voice_ev_head[vi];
+            while (ei >= 0) {
+                const S2rTimedEvent e = p.tev[ei];
+                if (e.frame > first) break;
+                if (e.flags & S2R_EV_RESTART) {
+                    flags = S2R_VF_STARTED | ((e.flags & S2R_EV_RELEASE) ? S2R_VF_RELEASED : 0u);
+                    offset = 0u - e.frame; release = 0u; pitch = e.pitch;
+                } else if ((e.flags & S2R_EV_RELEASE) && (flags & S2R_VF_STARTED) && !(flags & S2R_VF_RELEASED)) {
+                    flags |= S2R_VF_RELEASED; release = offset + e.frame;
+                }
+                ei = e.next;
+            }
+        }
+        const float rel_f = (flags & S2R_VF_RELEASED) ? (float)release : 4294967296.0f;
         const float ro_m = __builtin_fmaxf(rel_f, p.mod.sus_off), end_m = ro_m + p.mod.R;
         EnvRun em = env_stage_at(p.mod, ro_m, end_m, 0.0f);
         float thr = -__builtin_inff();
         constexpr uint32_t kBase = DSPF ? 3u : 1u, kVec = kBase + (FM ? 2u : 0u);   // per quad: xc | alpha, beta, gamma [, period, 1 / period]
-        const float pitch = (FM && in_range && (flags & S2R_VF_STARTED)) ? p.v.pitch[vi] : 440.0f;
         f4 *dst = (f4 *)p.coeff + ((size_t)slot * n_quads + (size_t)chunk * kQuadsPerItem) * kVec * 64u + lane;
         const uint32_t q1 = (chunk + 1) * kQuadsPerItem < n_quads ? kQuadsPerItem : n_quads - chunk * kQuadsPerItem;
         for (uint32_t q = 0; q < q1; ++q) {
@@ -1002,7 +1021,12 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
         const float rf = r.released ? (float)r.release_u : 4294967296.0f;
         r.ro_a = __builtin_fmaxf(rf, p.amp.sus_off); r.end_a = r.ro_a + p.amp.R;
         r.ro_m = __builtin_fmaxf(rf, p.mod.sus_off); r.end_m = r.ro_m + p.mod.R;
-        thr_min = -__builtin_inff();                         // re-run the envelope cascade
+        // the envelope cascade for the boundary's frame, so that the chunk can take the branch-free path at once
+        const float t0 = (float)(r.offset + fpos);
+        ea = env_stage_at(p.amp, r.ro_a, r.end_a, t0);
+        em = env_stage_at(p.mod, r.ro_m, r.end_m, t0);
+        thr_min = __builtin_fminf(ea.thr, em.thr);
+        fc = refresh_flat<OSC, FM>(p, r, em, sT, fc);
     };
 
     // Frames are walked in super-chunks of 64 (one barrier and one cross-wave combine each), each
@@ -1025,9 +1049,18 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
                         return __ballot(!((float)(o_chunk + n * kChunk - 1u) < thr_min)) == 0ull;
                     };
                     uint32_t run = 0;
-                    if (TEV) run = clear_for(1u) ? 1u : 0u;      // events may land on any chunk boundary
-                    else if (clear_for(left)) run = left;
-                    else if (left > 4u && clear_for(4u)) run = 4u;
+                    uint32_t most = left;                        // under timed events: up to the wave's next one
+                    if (TEV) {
+                        uint32_t nxt = ev_frame;                 // 0xffffffff: none
+#pragma unroll
+                        for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)nxt, sh); nxt = o < nxt ? o : nxt; }
+                        nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
+                        const uint32_t until = nxt == 0xffffffffu ? left : (nxt - (sc0 + c16)) / kChunk;
+                        most = until < left ? until : left;      // (nxt > sc0 + c16: events at this boundary were just applied)
+                    }
+                    if (most == 0u) run = 0u;
+                    else if (clear_for(most)) run = most;
+                    else if (most > 4u && clear_for(4u)) run = 4u;
                     else if (clear_for(1u)) run = 1u;
                     if (FM && run && !have_stream) {
                         const bool fm_flat = !p.no_flat_shortcut &&
@@ -1548,10 +1581,13 @@ __global__ void s2r_decimate4_history_kernel(float *x, uint32_t n_out) {
 }
 
 // publishes the first timed event of every touched voice
-__global__ void s2r_tev_heads_kernel(int32_t *heads, const S2rTimedEvent *tev, uint32_t n) {
+// ... and moves the records from mapped host memory into HBM in one coalesced sweep: the coefficient pass and
+// the render kernel follow per-voice chains through them, and a PCIe round trip per hop is what they cannot afford
+__global__ void s2r_tev_heads_kernel(int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const S2rTimedEvent e = tev[i];
+    tev_copy[i] = e;
     if (e.flags & S2R_TEV_FIRST) heads[e.voice] = (int32_t)i;
 }
 
@@ -1695,9 +1731,9 @@ hipError_t s2r_launch_events(const S2rVoiceArrays &v, const S2rVoiceEvent *dev_e
     return hipGetLastError();
 }
 
-hipError_t s2r_launch_tev_heads(int32_t *heads, const S2rTimedEvent *tev, uint32_t n, hipStream_t stream) {
+hipError_t s2r_launch_tev_heads(int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(s2r_tev_heads_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, heads, tev, n);
+    hipLaunchKernelGGL(s2r_tev_heads_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, heads, tev, tev_copy, n);
     return hipGetLastError();
 }
 

@@ -866,3 +866,44 @@ def test_dsp_filters_through_the_coefficient_stream(kind, fm, mode):
         if k == 5:
             for v in range(30):
                 pr.note_on(35 + v)
+
+
+@pytest.mark.parametrize("patch_kw", [dict(), dict(mod_env_to_osc_freq=2.0, osc_kind=2), dict(lpf_kind=3, lpf_freq=900.0, mod_env_to_lpf_freq=3.0)])
+def test_timed_events_with_the_coefficient_stream(patch_kw):
+    """note events inside a fill on groups that stream their coefficients: the coefficient pass follows each
+    voice's event chain (restart -> new offsets and pitch from that frame on, release -> the release stage), and
+    the render kernel runs branch-free up to the wave's next event"""
+    voices = 1088
+    patch = make_patch(**patch_kw)
+    patch.mod_env.decay_ms = 60.0
+    patch.mod_env.sustain = 0.25
+    patch.mod_env.release_ms = 30.0
+    pr = Pair(voices, patch, max_frames=1024)
+    pr.threads = 8
+    pr.gpu.set_coeff_stream(3)
+    rng = np.random.RandomState(17)
+    held = []
+    for b in range(4):
+        frames = 1024 if b != 2 else 1000
+        n_ev = int(rng.randint(20, 200)) if b else voices
+        times = np.sort(rng.randint(0, (frames + 15) // 16, n_ev)) * 16 if b else np.zeros(n_ev, dtype=np.int64)
+        ev = np.zeros(n_ev, dtype=s2.NOTE_EVENT_DTYPE)
+        for i, t in enumerate(times):
+            on = (not held) or b == 0 or rng.randint(0, 3) > 0
+            if on:
+                note = int(rng.randint(30, 100)); held.append(note)
+            else:
+                note = held.pop(int(rng.randint(len(held))))
+            ev[i] = (1 if on else 0, note, int(t), 1.0)
+        pr.gpu.note_events(ev)
+        g = pr.gpu.sample(np.empty(frames, dtype=np.float32))
+        pv = np.zeros((voices, frames), dtype=np.float32)
+        k = 0
+        for c in range(0, frames, 16):
+            while k < n_ev and ev["frame"][k] == c:
+                (pr.cpu.note_on if ev["kind"][k] else pr.cpu.note_off)(int(ev["note"][k]))
+                k += 1
+            n = min(16, frames - c)
+            pv[:, c:c + n] = pr.cpu.render_voices(n, threads=8)
+        assert k == n_ev
+        assert_bits_equal(g, s2o.mix_tree(pv, pr.block_voices, 1), "timed events + stream, %s, buffer %d" % (patch_kw, b))
