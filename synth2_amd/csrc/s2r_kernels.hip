@@ -1345,6 +1345,7 @@ __global__ void __launch_bounds__(MAXT) s2r_render_general_kernel(const S2rRende
                 seed_now = e.seed;
                 r.seed_rot = (e.seed << 5) | (e.seed >> 27);
                 if (BANK) { program = e.program; lp = lane_patch_from_bank(p.bank, p.bank_size, program, p.sr); }
+                k = make_osck_any<OSC>(lp.osc_kind, lp.sr / r.pitch);    // the new pitch's constants (what FM-free frames use)
                 live = true;
             } else if ((e.flags & S2R_EV_RELEASE) && live && !r.released) {   // synth.rs:74-75
                 r.released = true;
@@ -1355,7 +1356,11 @@ __global__ void __launch_bounds__(MAXT) s2r_render_general_kernel(const S2rRende
             ev_frame = ev_idx >= 0 ? p.tev[ev_idx].frame : 0xffffffffu;
         }
         set_release_thresholds();
-        thr_min = -__builtin_inff();                             // re-run the envelope cascade
+        // the envelope cascade for the boundary's frame, so that the chunk can take the branch-free path at once
+        const float t0 = (float)(r.offset + fpos);
+        ea = env_stage_at(lp.amp, r.ro_a, r.end_a, t0);
+        em = env_stage_at(lp.mod, r.ro_m, r.end_m, t0);
+        thr_min = __builtin_fminf(ea.thr, em.thr);
     };
 
     // everything below `mod` that depends on it alone (and on the voice's pitch) is kept while no lane's
@@ -1392,7 +1397,16 @@ __global__ void __launch_bounds__(MAXT) s2r_render_general_kernel(const S2rRende
                         return __ballot(!((float)(o_chunk + n * kChunk - 1u) < thr_min)) == 0ull;
                     };
                     uint32_t run = 1u;                           // `calm` already covers this chunk
-                    if (!TEV) { if (clear_for(left)) run = left; else if (left > 4u && clear_for(4u)) run = 4u; }
+                    uint32_t most = left;                        // under timed events: up to the wave's next one
+                    if (TEV) {
+                        uint32_t nxt = ev_frame;                 // 0xffffffff: none
+#pragma unroll
+                        for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)nxt, sh); nxt = o < nxt ? o : nxt; }
+                        nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
+                        const uint32_t until = nxt == 0xffffffffu ? left : (nxt - (sc0 + c16)) / kChunk;
+                        most = until < left ? until : left;
+                    }
+                    if (most > 1u) { if (clear_for(most)) run = most; else if (most > 4u && clear_for(4u)) run = 4u; }
                     if (__ballot(!(((have_stream && fmv) || (k.period > 0.0f && k.period < __builtin_inff())) && r.phase >= 0.0f && r.phase < 1.0f)) != 0ull) run = 0u;
                     if (run) {
                         run = (uint32_t)__builtin_amdgcn_readfirstlane((int)run);
