@@ -26,6 +26,12 @@ FLAGS = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fn
          "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
 
+# S2R_WITH_LANE_VARIANTS=1 in the environment also builds the 2- and 4-lanes-per-voice render kernels (48 more
+# kernels, +50 % build time): bit-identical to one lane per voice and slower, kept for experiments
+if os.environ.get("S2R_WITH_LANE_VARIANTS") == "1":
+    FLAGS = FLAGS + ["-DS2R_WITH_LANE_VARIANTS"]
+
+
 def _hipcc():
     for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):

@@ -153,6 +153,7 @@ struct S2rMixParams {
 hipError_t s2r_launch_coeff(const S2rRenderParams &p, hipStream_t stream);   // classify + coefficient pass
 hipError_t s2r_launch_prep(const S2rPrepParams &a, hipStream_t stream);      // events + classify in one launch, then the coefficient pass
 hipError_t s2r_launch_render(const S2rRenderParams &p, uint32_t block_voices, uint32_t lanes_per_voice, hipStream_t stream);
+bool s2r_lane_variants_built();      // the 2- and 4-lanes-per-voice kernels exist only in builds with -DS2R_WITH_LANE_VARIANTS
 hipError_t s2r_launch_mix(const S2rMixParams &p, hipStream_t stream);
 hipError_t s2r_launch_events(const S2rVoiceArrays &v, const S2rVoiceEvent *dev_events, uint32_t n, hipStream_t stream);
 hipError_t s2r_launch_tev_heads(int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n, hipStream_t stream);

@@ -506,6 +506,7 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
         // against 0.175 ms at L = 4).  2 and 4 remain as a bit-identical knob.
         uint32_t l = cfg->lanes_per_voice;
         if (l == 0) l = 1u;
+        if ((l == 2 || l == 4) && !s2r_lane_variants_built()) l = 1u;   // same bits; those kernels are an opt-in of the build
         while (l > 1 && (bv * l > 1024u || (l == 2 && bv > 256u))) l >>= 1;
         if (l != 1 && l != 2 && l != 4) { delete s; return S2R_ERR_INVALID; }
         s->lanes = l;

@@ -1647,11 +1647,15 @@ hipError_t launch_l(const S2rRenderParams &p0, uint32_t block_voices, uint32_t l
         if (threads <= 256) hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, MODE, 1, 256>), dim3(grid), block, lds, stream, p);
         else hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, MODE, 1, 1024>), dim3(grid), block, lds, stream, p);
         break;
+#if defined(S2R_WITH_LANE_VARIANTS)
+    // 2 or 4 lanes per voice: bit-identical, slower at every pool size since the branch-free runs (which exist for
+    // one lane per voice only), and 48 more kernels to compile — built only on request (synth2_amd/build.py)
     case 2:
         if (threads > 512) return hipErrorInvalidValue;
         hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, MODE, 2, 512>), dim3(grid), block, lds, stream, p);
         break;
     case 4: hipLaunchKernelGGL((s2r_render_kernel<OSC, FM, MODE, 4, 1024>), dim3(grid), block, lds, stream, p); break;
+#endif
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1714,6 +1718,14 @@ hipError_t s2r_launch_prep(const S2rPrepParams &a, hipStream_t stream) {
     hipLaunchKernelGGL(s2r_prep_kernel, dim3(n_groups64), dim3(64), 0, stream, a);
     launch_coeff_pass(a.p, stream);
     return hipGetLastError();
+}
+
+bool s2r_lane_variants_built() {
+#if defined(S2R_WITH_LANE_VARIANTS)
+    return true;
+#else
+    return false;
+#endif
 }
 
 hipError_t s2r_launch_render(const S2rRenderParams &p, uint32_t block_voices, uint32_t lanes_per_voice, hipStream_t stream) {
