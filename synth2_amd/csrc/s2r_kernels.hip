@@ -205,8 +205,7 @@ __device__ __forceinline__ float hash_noise(uint32_t seed_rot, float t) {
     // depend only on the low 16 bits of both factors
     const uint16_t h = (uint16_t)((uint16_t)(seed_rot ^ off) * (uint16_t)0x79b9u);
     const float value = (float)h;                               // cast::<f32>()
-    // value / u16_max: integers 0..65535 are inside the exhaustively verified window
-    const float q = s2r_div_const_nocheck(value, 65535.0f, 0x1.0001p-16f);
+    const float q = s2r_div_u16_by_65535(value);                // value / u16_max, correctly rounded
     return __builtin_fmaf(q, 2.0f, -1.0f);                      // (q * 2) is exact, then - 1
 }
 
@@ -333,6 +332,11 @@ __device__ __forceinline__ OscK4 make_osck4(f4 period) {
     return k;
 }
 
+// s2r_div_u16_by_65535 on four lanes
+__device__ __forceinline__ f4 div_u16_by_65535_4(f4 value) {
+    return vfma(value, splat(0x1.0001p-32f), value * splat(0x1p-16f));
+}
+
 // hashnoise.rs:33-51 on four offsets
 __device__ __forceinline__ f4 hash_noise4(uint32_t seed_rot, f4 t) {
     u4 off;
@@ -341,8 +345,22 @@ __device__ __forceinline__ f4 hash_noise4(uint32_t seed_rot, f4 t) {
     // 16 bits of the factors: a full-rate 16-bit multiply instead of the quarter-rate 32-bit one
     const us4 h = __builtin_convertvector(off ^ seed_rot, us4) * (unsigned short)0x79b9u;
     const f4 value = __builtin_convertvector(h, f4);
-    const f4 q = div_const_nocheck4(value, 65535.0f, 0x1.0001p-16f);
-    return vfma(q, splat(2.0f), splat(-1.0f));
+    return vfma(div_u16_by_65535_4(value), splat(2.0f), splat(-1.0f));
+}
+
+// The same for four offsets below 2^24, given as the low 16 bits of two pairs of them: there (offset as f32) as u32
+// is the offset itself (hashnoise.rs:37 casts a value that is exact), and the hash's low 16 bits need only the low
+// 16 bits of offset and seed.  Two frames per 32-bit register: one xor and one packed 16-bit multiply per pair, no
+// conversions of the offset.  `seed_pair` holds the low half of rotl(seed, 5) in both halves.
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b));
+}
+__device__ __forceinline__ f4 hash_noise4_low16(uint32_t seed_pair, uint32_t off01, uint32_t off23) {
+    const us2 h01 = __builtin_bit_cast(us2, off01 ^ seed_pair) * (unsigned short)0x79b9u;
+    const us2 h23 = __builtin_bit_cast(us2, off23 ^ seed_pair) * (unsigned short)0x79b9u;
+    const f4 value = {(float)h01.x, (float)h01.y, (float)h23.x, (float)h23.y};
+    return vfma(div_u16_by_65535_4(value), splat(2.0f), splat(-1.0f));
 }
 
 // While the mod envelope sits in a stage whose slope is zero (sustain, end, or a degenerate
@@ -767,7 +785,11 @@ __global__ void __launch_bounds__(64) s2r_prep_kernel(const S2rPrepParams a) {
 //   constant coefficients `fcoef`, state in *f2, instead of the one-pole.
 //   FMV (with SRC == 1, oscillator FM): the stream carries three vectors per quad — the LPF coefficient, the
 //   oscillator period sr / f_osc and its reciprocal — and the period constants are per-frame values.
-template <int OSC, int SRC, int FILT = 0, bool FMV = false>
+//   SMALL (one-pole kernel): every lane's offsets of the chunk are below 2^24, so the f32 offsets are exact sums and
+//   the noise hash works on their low 16 bits (hash_noise4_low16), and the patch's noise level is 0.0, so adding it
+//   (process.rs:353-356) changes nothing: the noise value itself is never +-0 (v / 65535 == 0.5 has no integer
+//   solution), and n + 0.0 == n for every other n.
+template <int OSC, int SRC, int FILT = 0, bool FMV = false, bool SMALL = false>
 __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &r, const EnvRun &ea, const EnvRun &em,
                                            const FlatCache &fc, const OscK &k, uint32_t o_chunk, const f4 *stream_q,
                                            const uint64_t *sT, const float *sSin, bool live, float *tile_col,
@@ -788,15 +810,31 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
     const double rcp_period = (OSC == S2R_OSC_SINE && !FMV) ? s2r_rcp_f64(k.period) : 0.0;   // constant over the run: hoisted by the compiler
     // a lane without a started voice: see a0 / ampq below.  Its filter history must be 0 for that (frames
     // of the general path, which selects per frame instead, leave a running value in it)
-    if (!live) r.last = 0.0f;
+    // — and its amplitude line is 0 * (t - 0) + 0 = +0 and, where the coefficient is the run's constant, x = 1
+    // (a0 = 1 - 1 = 0): selected once per chunk instead of per quad
+    // (selects, not a branch: control flow here would split the chunk's basic block)
+    r.last = live ? r.last : 0.0f;
+    const float ea_slope = live ? ea.slope : 0.0f, ea_base = live ? ea.base : 0.0f, ea_y0 = live ? ea.y0 : 0.0f;
+    const float xc0 = live ? fc.xc : 1.0f;
     f4 amp[4], nz[4];
+    const float t_chunk = (float)o_chunk;
+    // SMALL: the low 16 bits of the chunk's first four offsets as two pairs, and of rotl(seed, 5) twice
+    const uint32_t o_lo = o_chunk & 0xffffu;
+    const uint32_t o01 = pk_add_u16(o_lo | (o_lo << 16), 0x00010000u), o23 = pk_add_u16(o01, 0x00020002u);
+    const uint32_t seed_pair = (r.seed_rot & 0xffffu) | (r.seed_rot << 16);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const u4 ou = (u4)(o_chunk + 4u * q) + (u4){0u, 1u, 2u, 3u};
-        const f4 t = __builtin_convertvector(ou, f4);
-        amp[q] = splat(ea.slope) * (t - splat(ea.base)) + splat(ea.y0);
-        nz[q] = hash_noise4(r.seed_rot, t) + splat(p.noise_level);
-        if (SRC == 0) xq[q] = splat(fc.xc);
+        f4 t;
+        if (SMALL) {
+            t = splat(t_chunk) + (f4){4.0f * q, 4.0f * q + 1.0f, 4.0f * q + 2.0f, 4.0f * q + 3.0f};   // exact below 2^24
+            nz[q] = hash_noise4_low16(seed_pair, pk_add_u16(o01, 0x00040004u * q), pk_add_u16(o23, 0x00040004u * q));
+        } else {
+            const u4 ou = (u4)(o_chunk + 4u * q) + (u4){0u, 1u, 2u, 3u};
+            t = __builtin_convertvector(ou, f4);
+            nz[q] = hash_noise4(r.seed_rot, t) + splat(p.noise_level);
+        }
+        amp[q] = splat(ea_slope) * (t - splat(ea_base)) + splat(ea_y0);
+        if (SRC == 0) xq[q] = splat(xc0);
         if (SRC == 2) {
             const f4 mod = splat(em.slope) * (t - splat(em.base)) + splat(em.y0);
             const f4 f_lpf = pow2_sleef_core4(mod * splat(p.amt_lpf)) * splat(p.lpf_freq);
@@ -809,10 +847,10 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
     for (int q = 0; q < 4; ++q) {
         // filters.rs:23.  A lane without a started voice must put +0.0 into the mix (synth.rs:178 skips
         // it): with a0 = 0 and last = 0 its y is 0*s + x*0 = +0 for every finite s and x >= 0, and
-        // (+0) * (amp = +0) = +0 — two selects per quad instead of one per frame
+        // (+0) * (amp = +0) = +0 — no select per frame
         f4 a0 = splat(1.0f) - xq[q];
-        f4 ampq = amp[q];
-        if (!live) { a0 = splat(0.0f); ampq = splat(0.0f); }
+        const f4 ampq = amp[q];
+        if (SRC != 0 && !live) a0 = splat(0.0f);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             // the frame's oscillator constants: the run's (k), or under FM the streamed period and 1/period with
@@ -1082,25 +1120,36 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
                             return acc;
                         };
                         float *const sw_row = sW + (buf * n_groups + wave * GW + (r_on ? rgrp : 0u)) * kSuper + rf;
-                        auto run_chunks = [&](auto src_tag) {
+                        auto run_chunks = [&](auto src_tag, auto small_tag) {
                             constexpr int SRC = decltype(src_tag)::value;
+                            constexpr bool SMALL = decltype(small_tag)::value;
                             for (uint32_t i = 0; i < run; ++i) {
                                 const uint32_t f0 = c16 + i * kChunk;            // frame inside the super-chunk
-                                float prev = 0.0f;
-                                if (i) prev = tile_sum((i - 1u) & 1u);
+                                // unconditional, so that the loads and the serial adds sit in the chunk's basic block and
+                                // the scheduler spreads them over it (before the run's first chunk the other tile holds
+                                // stale or no data: read, never used)
+                                const float prev = tile_sum((i - 1u) & 1u);
                                 float *pvd = (PV && pv_lane) ? p.per_voice + pv_base + sc0 + f0 : nullptr;
                                 const f4 *sq = stream + (size_t)((sc0 + f0) / kP) * kVec * 64u;
-                                chunk_fast<OSC, SRC, 0, (FM && SRC == 1)>(p, r, ea, em, fc, FM ? fc.k : k_const, o_chunk + i * kChunk, sq, sT, sSin, live,
-                                                                          tile + (i & 1u) * kTile + col, VW + 1, pvd);
+                                chunk_fast<OSC, SRC, 0, (FM && SRC == 1), SMALL>(p, r, ea, em, fc, FM ? fc.k : k_const, o_chunk + i * kChunk, sq, sT, sSin, live,
+                                                                                 tile + (i & 1u) * kTile + col, VW + 1, pvd);
                                 if (i && r_on) sw_row[f0 - kChunk] = prev;
                             }
                             const float last = tile_sum((run - 1u) & 1u);
                             if (r_on) sw_row[c16 + (run - 1u) * kChunk] = last;
                         };
-                        if (have_stream) run_chunks(std::integral_constant<int, 1>{});
-                        else if (FM) run_chunks(std::integral_constant<int, 0>{});   // flat everywhere (checked above)
-                        else if (!p.no_flat_shortcut && __ballot(live && em.slope != 0.0f) == 0ull) run_chunks(std::integral_constant<int, 0>{});
-                        else run_chunks(std::integral_constant<int, 2>{});
+                        // every offset of the run below 2^24 on every lane (349 s at 48 kHz; voices are never freed,
+                        // synth.rs:196-199, so older ones exist) and a patch without noise (the default one): the cheaper
+                        // offset and noise arithmetic of SMALL
+                        const bool small = p.noise_level == 0.0f && __ballot(o_chunk + run * kChunk > (1u << 24)) == 0ull;
+                        const bool flat = FM || (!p.no_flat_shortcut && __ballot(live && em.slope != 0.0f) == 0ull);   // FM: checked above
+                        if (have_stream) {
+                            if (small) run_chunks(std::integral_constant<int, 1>{}, std::true_type{});
+                            else run_chunks(std::integral_constant<int, 1>{}, std::false_type{});
+                        } else if (flat) {
+                            if (small) run_chunks(std::integral_constant<int, 0>{}, std::true_type{});
+                            else run_chunks(std::integral_constant<int, 0>{}, std::false_type{});
+                        } else run_chunks(std::integral_constant<int, 2>{}, std::false_type{});
                         c16 += (run - 1u) * kChunk;
                         if (have_stream_gp) {                    // keep the general path's one-ahead prefetch coherent
                             const uint32_t qn = (sc0 + c16 + kChunk) / kP + sub;

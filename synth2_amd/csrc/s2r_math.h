@@ -202,6 +202,14 @@ S2R_HD float s2r_div_const_nocheck(float x, float c, float rc) {   // caller gua
     const float e = __builtin_fmaf(-q0, c, x);
     return __builtin_fmaf(e, rc, q0);
 }
+// v / 65535 for an integer 0 <= v <= 65535 (hashnoise.rs:46, value / u16_max), correctly rounded in two
+// operations: 1/65535 = 2^-16 + 2^-32 + 2^-48 + ..., so v/65535 = v*2^-16 (exact) + v*(2^-32 + 2^-48) + v*2^-64*(..),
+// and one fma rounds v*(2^-32 + 2^-48) + v*2^-16 — the dropped tail (< 2^-48) never reaches a rounding
+// boundary: compared with true division for all 65 536 values (tests/test_host_logic.py, exact in f64;
+// tests/test_gpu_parity.py::test_noise_division_all_u16_values on the device).
+S2R_HD float s2r_div_u16_by_65535(float v) {
+    return __builtin_fmaf(v, 0x1.0001p-32f, v * 0x1p-16f);
+}
 S2R_HD float s2r_div_const(float x, float c, float rc) {
     const float q0 = x * rc;
     const float e = __builtin_fmaf(-q0, c, x);

@@ -306,15 +306,48 @@ def test_export_import_roundtrip_and_large_offsets():
 
 
 def test_noise_division_all_u16_values():
-    """hash_noise's 3-op exact quotient v/65535 on the device for all 65536 values: offsets
-    0..65535*k hit every low-16 pattern of h; compare a long noise-only render."""
-    patch = make_patch(noise=1.0, osc_gain=0.0)
-    patch.amp_env.attack_ms = 0.0
-    pr = Pair(64, patch)
-    pr.note_on(69)
-    for _ in range(5):
-        g, o = pr.render_voices(2048)
-        assert_bits_equal(g[0], o[0], "noise quotient")
+    """hash_noise's two-operation exact quotient v/65535 on the device for all 65536 values: 65536 consecutive
+    offsets hit every low-16 pattern of h (the multiplier is odd); compare a long noise-only render, through the
+    general arithmetic (noise level 1) and through the small-offset chunk (noise level 0, which still ADDS the
+    noise value, process.rs:353-356)."""
+    for level in (1.0, 0.0):
+        patch = make_patch(noise=level, osc_gain=0.0)
+        patch.amp_env.attack_ms = 0.0
+        pr = Pair(64, patch)
+        pr.note_on(69)
+        for _ in range(33):
+            g, o = pr.render_voices(2048)
+            assert_bits_equal(g[0], o[0], "noise quotient, level %g" % level)
+
+
+def test_offsets_across_2_pow_24():
+    """The branch-free chunk takes exact f32 offsets and a 16-bit noise hash while every offset of a wave's run is
+    below 2^24, and the general arithmetic (hashnoise.rs:37: the offset goes through f32, which rounds there)
+    above: waves below, across and above 2^24 in one pool, with the reference's seed 0 and with per-voice seeds."""
+    V = 192
+    seeds = ((np.arange(V, dtype=np.uint64) * 2654435761 + 12345) & 0xffffffff).astype(np.uint32)
+    for noise, sd in ((0.0, None), (0.0, seeds), (0.25, seeds)):
+        pr = Pair(V, make_patch(noise=noise), seeds=sd)
+        for v in range(V):
+            pr.note_on(36 + v % 61)
+        g, o, _ = pr.sample(1024)
+        assert_bits_equal(g, o, "before the edit")
+        st = pr.gpu.export_state()
+        for v in range(V):
+            if v < 64:
+                off = 20000 + 977 * v                                   # a wave that stays small
+            elif v < 128:
+                off = (1 << 24) - 3000 + 61 * (v - 64) if v % 3 else 50000 + v   # lanes cross 2^24 inside the fills
+            else:
+                off = (1 << 24) + 100 + 4001 * (v - 128)                # a wave beyond it
+            st["current_frame_offset"][v] = off
+            pr.cpu.voice(v).current_frame_offset = off
+        pr.gpu.import_state(st)
+        for frames in (1024, 2048, 1000):
+            g, o, _ = pr.sample(frames)
+            assert_bits_equal(g, o, "noise %g, %d frames across 2^24" % (noise, frames))
+        gv, ov = pr.render_voices(512)
+        assert_bits_equal(gv, ov, "per voice, noise %g" % noise)
 
 
 def test_error_statuses():

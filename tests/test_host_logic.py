@@ -201,3 +201,18 @@ def test_stream_frame_json_is_serde_json_for_vec_f32():
         assert np.array_equal(back[fin].view(np.uint32), x[fin].view(np.uint32))
         assert np.all(np.isnan(back[~fin]))
     assert s2.stream_frame_json(np.zeros(0, dtype=np.float32)) == "[]"
+
+
+def test_u16_over_65535_two_operation_quotient():
+    """s2r_div_u16_by_65535 (s2r_math.h): fma(v, 0x1.0001p-32, v * 2^-16) is RN(v / 65535) for every integer
+    0 <= v <= 65535 (hashnoise.rs:46, value / u16_max).  v * (2^-16 + 2^-32 + 2^-48) has at most 49 significant
+    bits, so the f64 evaluation below is exact and its one rounding to f32 is the fma's."""
+    v = np.arange(65536, dtype=np.float64)
+    c = float.fromhex("0x1.0001p-32")
+    got = (v * c + v * 2.0 ** -16).astype(np.float32)
+    want = v.astype(np.float32) / np.float32(65535.0)
+    assert want.dtype == np.float32
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # and the noise value built from it is never a zero, which is what lets a 0.0 noise level skip its add
+    n = (got.astype(np.float64) * 2.0 - 1.0).astype(np.float32)
+    assert not np.any(n == 0.0)
