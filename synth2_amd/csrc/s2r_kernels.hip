@@ -820,14 +820,18 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
     const float t_chunk = (float)o_chunk;
     // SMALL: the low 16 bits of the chunk's first four offsets as two pairs, and of rotl(seed, 5) twice
     const uint32_t o_lo = o_chunk & 0xffffu;
-    const uint32_t o01 = pk_add_u16(o_lo | (o_lo << 16), 0x00010000u), o23 = pk_add_u16(o01, 0x00020002u);
+    uint32_t o01 = pk_add_u16(o_lo | (o_lo << 16), 0x00010000u), o23 = pk_add_u16(o01, 0x00020002u);
     const uint32_t seed_pair = (r.seed_rot & 0xffffu) | (r.seed_rot << 16);
+    f4 t_small = splat(t_chunk) + (f4){0.0f, 1.0f, 2.0f, 3.0f};      // exact below 2^24, as are the + 4 steps
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         f4 t;
         if (SMALL) {
-            t = splat(t_chunk) + (f4){4.0f * q, 4.0f * q + 1.0f, 4.0f * q + 2.0f, 4.0f * q + 3.0f};   // exact below 2^24
-            nz[q] = hash_noise4_low16(seed_pair, pk_add_u16(o01, 0x00040004u * q), pk_add_u16(o23, 0x00040004u * q));
+            // stepping (one inline constant, one scalar literal) instead of 4 q + k per quad (a scalar move per literal)
+            t = t_small;
+            nz[q] = hash_noise4_low16(seed_pair, o01, o23);
+            t_small = t_small + splat(4.0f);
+            o01 = pk_add_u16(o01, 0x00040004u); o23 = pk_add_u16(o23, 0x00040004u);
         } else {
             const u4 ou = (u4)(o_chunk + 4u * q) + (u4){0u, 1u, 2u, 3u};
             t = __builtin_convertvector(ou, f4);
