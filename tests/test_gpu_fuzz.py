@@ -55,9 +55,22 @@ def test_fuzz(seed):
     sr = int(rng.choice([48000, 48000, 44100, 96000, 22050, 12345, 8000, 192000, 384000]))
     held = []
     what = "seed %d: %d voices, block %d, lanes %d, groups %d, %d patches, sr %d" % (seed, voices, block, lanes, groups, len(bank), sr)
+    rng_age = np.random.RandomState(int(os.environ.get("S2R_FUZZ_BASE", "1000")) * 31 + 7 + seed)   # its own stream: the cases above stay what they were
     for b in range(7):
         if b and rng.rand() < 0.15:                      # checkpoint round trip between two buffers
             pr.gpu.import_state(pr.gpu.export_state())
+        if b and rng_age.rand() < 0.12:
+            # voices are never freed (synth.rs:196-199), so old ones exist: age some to just below, across and beyond
+            # 2^24 frames, where the offset's trip through f32 (hashnoise.rs:37, simdtest.rs:271) starts to round —
+            # the branch-free chunk switches arithmetic there, per wave and per run
+            st = pr.gpu.export_state()
+            for v in np.nonzero(st["started"])[0]:
+                if rng_age.rand() < 0.5:
+                    add = (1 << 24) - int(rng_age.randint(0, 4000)) + (int(rng_age.randint(0, 1 << 25)) if rng_age.rand() < 0.3 else 0)
+                    off = int(st["current_frame_offset"][v]) + add
+                    st["current_frame_offset"][v] = off
+                    pr.cpu.voice(int(v)).current_frame_offset = off
+            pr.gpu.import_state(st)
         if b and len(bank) == 1 and rng.rand() < 0.15:   # the patch is swapped under sounding voices
             bank = [random_patch(rng)]
             pr.gpu.set_patch(bank[0]); pr.cpu.config = oracle_cfg_from_patch(bank[0])
