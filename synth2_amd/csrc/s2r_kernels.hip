@@ -678,7 +678,10 @@ __global__ void __launch_bounds__(256) s2r_coeff_kernel(const S2rRenderParams p)
                 dst[(size_t)(q * kVec + 2u) * 64u] = ga;
             } else {
                 const f4 arg = FASTDIV ? div_const_nocheck4(num, p.sr, p.rcp_sr) : (num / splat(p.sr));
-                dst[(size_t)(q * kVec) * 64u] = expf4(arg, sT);
+                // a lane without a started voice (for these frames) gets x = 1: the render kernel's branch-free chunk
+                // then has a0 = 1 - 1 = 0 and x * last = 1 * 0 for it without a select of its own (chunk_fast)
+                const f4 xv = expf4(arg, sT);
+                dst[(size_t)(q * kVec) * 64u] = (flags & S2R_VF_STARTED) ? xv : splat(1.0f);
             }
             if (FM) {
                 const f4 f_osc = pow2_sleef_core4(mod * splat(p.amt_osc)) * splat(pitch);       // process.rs:146-147,231-250
@@ -854,7 +857,7 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
         // (+0) * (amp = +0) = +0 — no select per frame
         f4 a0 = splat(1.0f) - xq[q];
         const f4 ampq = amp[q];
-        if (SRC != 0 && !live) a0 = splat(0.0f);
+        if (SRC == 2 && !live) a0 = splat(0.0f);                 // SRC 1: the stream holds x = 1 for such a lane (s2r_coeff_kernel)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             // the frame's oscillator constants: the run's (k), or under FM the streamed period and 1/period with
