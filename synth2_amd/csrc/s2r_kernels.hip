@@ -1156,7 +1156,8 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
                         } else if (flat) {
                             if (small) run_chunks(std::integral_constant<int, 0>{}, std::true_type{});
                             else run_chunks(std::integral_constant<int, 0>{}, std::false_type{});
-                        } else run_chunks(std::integral_constant<int, 2>{}, std::false_type{});
+                        } else if (small) run_chunks(std::integral_constant<int, 2>{}, std::true_type{});
+                        else run_chunks(std::integral_constant<int, 2>{}, std::false_type{});
                         c16 += (run - 1u) * kChunk;
                         if (have_stream_gp) {                    // keep the general path's one-ahead prefetch coherent
                             const uint32_t qn = (sc0 + c16 + kChunk) / kP + sub;
