@@ -715,13 +715,22 @@ __global__ void __launch_bounds__(64) s2r_prep_kernel(const S2rPrepParams a) {
     // ---- the fill's note events (synth.rs:61-80): 64 records per step, one per lane; the few that
     //      hit this group are handed to their lane ----
     uint32_t my_flags = 0u, my_pitch = 0u;
-    for (uint32_t base = 0; base < a.n_events; base += 64u) {
-        const uint32_t i = base + lane;
+    // every step's records are fetched before the first is looked at: one trip to the kernel-argument
+    // segment for the wave instead of one per 64 events
+    constexpr uint32_t kSteps = (S2R_PREP_MAX_EVENTS + 63u) / 64u;
+    uint32_t evv[kSteps], evf[kSteps], evp[kSteps];
+#pragma unroll
+    for (uint32_t k = 0; k < kSteps; ++k) {
+        const uint32_t i = k * 64u + lane;
         const bool have = i < a.n_events;
-        const uint32_t ev_voice = have ? a.ev[3u * i] : 0xffffffffu;
-        const uint32_t ev_flags = have ? a.ev[3u * i + 1u] : 0u;
-        const uint32_t ev_pitch = have ? a.ev[3u * i + 2u] : 0u;
-        uint64_t hits = __ballot(have && (ev_voice >> 6) == group);
+        evv[k] = have ? a.ev[3u * i] : 0xffffffffu;
+        evf[k] = have ? a.ev[3u * i + 1u] : 0u;
+        evp[k] = have ? a.ev[3u * i + 2u] : 0u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kSteps; ++k) {
+        const uint32_t ev_voice = evv[k], ev_flags = evf[k], ev_pitch = evp[k];
+        uint64_t hits = __ballot(ev_voice != 0xffffffffu && (ev_voice >> 6) == group);
         while (hits) {                                           // wave-uniform
             const int src = __builtin_ctzll(hits);
             hits &= hits - 1ull;
