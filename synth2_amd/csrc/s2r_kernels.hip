@@ -801,7 +801,10 @@ __global__ void __launch_bounds__(64) s2r_prep_kernel(const S2rPrepParams a) {
 //   the noise hash works on their low 16 bits (hash_noise4_low16), and the patch's noise level is 0.0, so adding it
 //   (process.rs:353-356) changes nothing: the noise value itself is never +-0 (v / 65535 == 0.5 has no integer
 //   solution), and n + 0.0 == n for every other n.
-template <int OSC, int SRC, int FILT = 0, bool FMV = false, bool SMALL = false>
+//   AFLAT (with SMALL): every started voice of the wave sits in an amplitude stage of slope +-0 (sustain, end) for
+//   the whole run, so slope * (t - base) + y0 is (+-0) + y0 with the product's sign fixed by the slope's (t >= base
+//   inside a stage): one evaluation per chunk, at its first frame, is every frame's value bit for bit.
+template <int OSC, int SRC, int FILT = 0, bool FMV = false, bool SMALL = false, bool AFLAT = false>
 __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &r, const EnvRun &ea, const EnvRun &em,
                                            const FlatCache &fc, const OscK &k, uint32_t o_chunk, const f4 *stream_q,
                                            const uint64_t *sT, const float *sSin, bool live, float *tile_col,
@@ -849,7 +852,8 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
             t = __builtin_convertvector(ou, f4);
             nz[q] = hash_noise4(r.seed_rot, t) + splat(p.noise_level);
         }
-        amp[q] = splat(ea_slope) * (t - splat(ea_base)) + splat(ea_y0);
+        if (AFLAT) amp[q] = splat(ea_slope * (t_chunk - ea_base) + ea_y0);
+        else amp[q] = splat(ea_slope) * (t - splat(ea_base)) + splat(ea_y0);
         if (SRC == 0) xq[q] = splat(xc0);
         if (SRC == 2) {
             const f4 mod = splat(em.slope) * (t - splat(em.base)) + splat(em.y0);
@@ -1136,9 +1140,10 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
                             return acc;
                         };
                         float *const sw_row = sW + (buf * n_groups + wave * GW + (r_on ? rgrp : 0u)) * kSuper + rf;
-                        auto run_chunks = [&](auto src_tag, auto small_tag) {
+                        auto run_chunks = [&](auto src_tag, auto small_tag, auto aflat_tag) {
                             constexpr int SRC = decltype(src_tag)::value;
                             constexpr bool SMALL = decltype(small_tag)::value;
+                            constexpr bool AFLAT = decltype(aflat_tag)::value;
                             for (uint32_t i = 0; i < run; ++i) {
                                 const uint32_t f0 = c16 + i * kChunk;            // frame inside the super-chunk
                                 // unconditional, so that the loads and the serial adds sit in the chunk's basic block and
@@ -1147,7 +1152,7 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
                                 const float prev = tile_sum((i - 1u) & 1u);
                                 float *pvd = (PV && pv_lane) ? p.per_voice + pv_base + sc0 + f0 : nullptr;
                                 const f4 *sq = stream + (size_t)((sc0 + f0) / kP) * kVec * 64u;
-                                chunk_fast<OSC, SRC, 0, (FM && SRC == 1), SMALL>(p, r, ea, em, fc, FM ? fc.k : k_const, o_chunk + i * kChunk, sq, sT, sSin, live,
+                                chunk_fast<OSC, SRC, 0, (FM && SRC == 1), SMALL, AFLAT>(p, r, ea, em, fc, FM ? fc.k : k_const, o_chunk + i * kChunk, sq, sT, sSin, live,
                                                                                  tile + (i & 1u) * kTile + col, VW + 1, pvd);
                                 if (i && r_on) sw_row[f0 - kChunk] = prev;
                             }
@@ -1159,14 +1164,20 @@ __global__ void __launch_bounds__(MAXT) s2r_render_kernel(const S2rRenderParams 
                         // offset and noise arithmetic of SMALL
                         const bool small = p.noise_level == 0.0f && __ballot(o_chunk + run * kChunk > (1u << 24)) == 0ull;
                         const bool flat = FM || (!p.no_flat_shortcut && __ballot(live && em.slope != 0.0f) == 0ull);   // FM: checked above
+                        // ... and every started voice's amplitude envelope in a zero-slope stage (no threshold falls inside
+                        // the run, so the stage holds): the amplitude is one value per chunk (AFLAT)
+                        const bool aflat = small && __ballot(live && ea.slope != 0.0f) == 0ull;
+                        using T = std::true_type; using F = std::false_type;
                         if (have_stream) {
-                            if (small) run_chunks(std::integral_constant<int, 1>{}, std::true_type{});
-                            else run_chunks(std::integral_constant<int, 1>{}, std::false_type{});
+                            if (aflat) run_chunks(std::integral_constant<int, 1>{}, T{}, T{});
+                            else if (small) run_chunks(std::integral_constant<int, 1>{}, T{}, F{});
+                            else run_chunks(std::integral_constant<int, 1>{}, F{}, F{});
                         } else if (flat) {
-                            if (small) run_chunks(std::integral_constant<int, 0>{}, std::true_type{});
-                            else run_chunks(std::integral_constant<int, 0>{}, std::false_type{});
-                        } else if (small) run_chunks(std::integral_constant<int, 2>{}, std::true_type{});
-                        else run_chunks(std::integral_constant<int, 2>{}, std::false_type{});
+                            if (aflat) run_chunks(std::integral_constant<int, 0>{}, T{}, T{});
+                            else if (small) run_chunks(std::integral_constant<int, 0>{}, T{}, F{});
+                            else run_chunks(std::integral_constant<int, 0>{}, F{}, F{});
+                        } else if (small) run_chunks(std::integral_constant<int, 2>{}, T{}, F{});
+                        else run_chunks(std::integral_constant<int, 2>{}, F{}, F{});
                         c16 += (run - 1u) * kChunk;
                         if (have_stream_gp) {                    // keep the general path's one-ahead prefetch coherent
                             const uint32_t qn = (sc0 + c16 + kChunk) / kP + sub;
