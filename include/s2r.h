@@ -221,7 +221,11 @@ uint32_t s2r_abi_version(void);
 uint32_t s2r_shard_voices(const s2r_synth *s);
 uint32_t s2r_block_voices(const s2r_synth *s);
 uint32_t s2r_lanes_per_voice(const s2r_synth *s);
-uint64_t s2r_double_release_count(const s2r_synth *s);      /* synth.rs:77 warn counter */
+/* note_offs that found no active (started, unreleased) voice holding the note and therefore did nothing.  The
+ * reference ignores them silently: its `log::warn!("note {} released twice")` (synth.rs:77) sits behind
+ * find_active_voice, which only returns unreleased voices (synth.rs:36-38,82-90), so it can never fire — this
+ * counter is the diagnostic that warning was meant to be. */
+uint64_t s2r_double_release_count(const s2r_synth *s);
 /* device time of the most recent fill's render kernel in milliseconds (HIP events recorded
  * on the library's stream around the launch); < 0 if timing is off.  Enable with
  * s2r_set_timing(s, 1): adds two event records per fill. */
@@ -248,8 +252,9 @@ const char *s2r_status_string(int status);
 /* The wire format of the reference's (disabled) websocket audio server, one text frame per buffer:
  * serde_json::to_string(&Vec<f32>) (threads.rs:303-305; BUFFER_SIZE = 4096 frames, 32 kHz mono,
  * threads.rs:6,263; consumer www/streamer.js:82-90).  Writes a NUL-terminated JSON array into `out`
- * and returns its length; when `out` is NULL or `cap` is below the worst case (3 + 16 n) it writes
- * nothing and returns the capacity to provide.  Host-only. */
+ * and returns its length; when `out` is NULL or `cap` is below the worst case (3 + S2R_STREAM_CHARS_PER_SAMPLE * n:
+ * the longest element, e.g. "-0.0000012345678", is 16 chars + ','; one spare) it writes nothing and returns the capacity to provide.  Host-only. */
+#define S2R_STREAM_CHARS_PER_SAMPLE 18u
 #define S2R_STREAM_FRAMES 4096u
 #define S2R_STREAM_RATE_HZ 32000u
 size_t s2r_stream_frame_json(const float *samples, size_t n, char *out, size_t cap);

@@ -209,6 +209,23 @@ int flush_events(s2r_synth *s, hipStream_t stream, EventSlot **timed_slot, const
         S2R_HIP(s, s2r_launch_events(s->v, sl.dev, n, stream));
     }
     const uint32_t nt = (uint32_t)s->tpending.size();
+    if (nt > s->tev_capacity) {
+        // more timed events in one fill than the buffers hold: grow all of them (rare; every earlier user of the
+        // old buffers is waited for first)
+        S2R_HIP(s, hipStreamSynchronize(stream));
+        S2R_HIP(s, hipStreamSynchronize(s->stream));
+        uint32_t cap = s->tev_capacity;
+        while (cap < nt) cap *= 2u;
+        for (EventSlot &e : s->slots) {
+            if (e.in_flight) { S2R_HIP(s, hipEventSynchronize(e.done)); e.in_flight = false; }
+            S2R_HIP(s, hipHostFree(e.thost)); e.thost = nullptr; e.tdev = nullptr;
+            S2R_HIP(s, hipHostMalloc((void **)&e.thost, (size_t)cap * sizeof(S2rTimedEvent), hipHostMallocMapped));
+            S2R_HIP(s, hipHostGetDevicePointer((void **)&e.tdev, e.thost, 0));
+        }
+        S2R_HIP(s, hipFree(s->tev_copy)); s->tev_copy = nullptr;
+        S2R_HIP(s, hipMalloc((void **)&s->tev_copy, (size_t)cap * sizeof(S2rTimedEvent)));
+        s->tev_capacity = cap;
+    }
     if (nt) {
         std::memcpy(sl.thost, s->tpending.data(), nt * sizeof(S2rTimedEvent));
         S2R_HIP(s, s2r_launch_tev_heads(s->voice_ev_head, sl.tdev, s->tev_copy, nt, stream));
@@ -673,23 +690,42 @@ int s2r_note_off(s2r_synth *s, uint8_t note) {
     if (s->fill_time) return set_err(s, S2R_ERR_INVALID, "untimed note_off after timed events: fill first or give it a frame");
     const int64_t i = s->pool->note_off(note);
     if (i >= 0) push_event(s, (uint32_t)i, S2R_EV_RELEASE, 0.0f, 0u);
+    else s->double_release++;                 // synth.rs:77: `log::warn!("double release")`, nothing else happens
     return S2R_OK;
 }
 
 int s2r_note_events(s2r_synth *s, const s2r_note_event *events, size_t n) {
     if (!s || (!events && n)) return S2R_ERR_INVALID;
+    // The whole batch is checked before the first event touches the pool, the pool clock or the pending lists: a
+    // rejected batch leaves the handle exactly as it was (the reference's note_on / note_off cannot fail at all,
+    // synth.rs:61-80, so every error here is a malformed batch, not a state of the synth).
+    {
+        uint32_t t = s->fill_time;
+        size_t bank_n = s->bank.size();
+        for (size_t k = 0; k < n; k++) {
+            const s2r_note_event &e = events[k];
+            if (e.kind == S2R_PROGRAM_CHANGE) {
+                if (e.note >= bank_n) return set_err(s, S2R_ERR_INVALID, "event %zu: program %u, the bank holds %zu patches", k, (unsigned)e.note, bank_n);
+                continue;
+            }
+            if (e.kind != S2R_NOTE_ON && e.kind != S2R_NOTE_OFF)
+                return set_err(s, S2R_ERR_INVALID, "event %zu: unknown kind %u", k, (unsigned)e.kind);
+            const uint32_t frame = e.frame;
+            if (frame % 16u) return set_err(s, S2R_ERR_INVALID, "event %zu: frame %u is not a multiple of 16 (events land between 16-frame chunks, main.rs:138-143)", k, frame);
+            if (frame < t) return set_err(s, S2R_ERR_INVALID, "event %zu: frame %u precedes an earlier event at %u", k, frame, t);
+            // an event must fall inside the next fill, and no fill is longer than max_frames: a later frame could
+            // never be rendered and would leave the handle refusing every fill
+            if (frame >= s->cfg.max_frames) return set_err(s, S2R_ERR_INVALID, "event %zu: frame %u is not inside any fill (max_frames %u)", k, frame, s->cfg.max_frames);
+            t = frame;
+        }
+    }
     for (size_t k = 0; k < n; k++) {
         const s2r_note_event &e = events[k];
         if (e.kind == S2R_PROGRAM_CHANGE) {      // host-side state: which patch the following note_ons get
-            if (e.note >= s->bank.size()) return set_err(s, S2R_ERR_INVALID, "event %zu: program %u, the bank holds %zu patches", k, (unsigned)e.note, s->bank.size());
             s->program = e.note;
             continue;
         }
-        if (e.kind != S2R_NOTE_ON && e.kind != S2R_NOTE_OFF)
-            return set_err(s, S2R_ERR_INVALID, "event %zu: unknown kind %u", k, (unsigned)e.kind);
         const uint32_t frame = e.frame;
-        if (frame % 16u) return set_err(s, S2R_ERR_INVALID, "event %zu: frame %u is not a multiple of 16 (events land between 16-frame chunks, main.rs:138-143)", k, frame);
-        if (frame < s->fill_time) return set_err(s, S2R_ERR_INVALID, "event %zu: frame %u precedes an earlier event at %u", k, frame, s->fill_time);
         if (frame == 0) {                     // takes effect before the next fill: folded per voice
             if (e.kind == S2R_NOTE_ON) {
                 const uint32_t i = s->pool->note_on(e.note, e.velocity);
@@ -697,6 +733,7 @@ int s2r_note_events(s2r_synth *s, const s2r_note_event *events, size_t n) {
             } else {
                 const int64_t i = s->pool->note_off(e.note);
                 if (i >= 0) push_event(s, (uint32_t)i, S2R_EV_RELEASE, 0.0f, 0u);
+                else s->double_release++;         // synth.rs:77 logs "double release" and carries on
             }
             continue;
         }
@@ -711,11 +748,12 @@ int s2r_note_events(s2r_synth *s, const s2r_note_event *events, size_t n) {
         } else {
             vi = s->pool->note_off(e.note);
             fl = S2R_EV_RELEASE;
-            if (vi < 0) continue;
+            if (vi < 0) { s->double_release++; continue; }
         }
         const int64_t mine = to_local(s, (uint32_t)vi);
         if (mine < 0) continue;
-        if (s->tpending.size() >= s->tev_capacity) return set_err(s, S2R_ERR_INVALID, "more than %u timed events in one fill", s->tev_capacity);
+        // (no capacity limit here: the device-side buffers grow in flush_events when a fill brings more timed
+        // events than they hold)
         const uint32_t local = (uint32_t)mine;
         const int32_t idx = (int32_t)s->tpending.size();
         S2rTimedEvent te{};

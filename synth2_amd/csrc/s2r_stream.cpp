@@ -63,14 +63,20 @@ size_t format_f32(float v, char *out) {
 }  // namespace
 
 extern "C" size_t s2r_stream_frame_json(const float *samples, size_t n, char *out, size_t cap) {
-    // worst case per sample: sign + 9 digits + '.' + "e-45" + ',' = 16 chars
-    const size_t need = 2 + n * 16 + 1;
+    // longest element: 16 chars — "-0.00000" + 8 digits (1e-6 <= |v| < 1e-5 needs at most eight), "-0.0000" + 9
+    // digits, or sign + 13 integer digits + ".0" — + ',' = 17 (the scientific layout: sign + d + '.' + 8 digits +
+    // "e-45" = 15).  The advertised capacity allows 18 per sample; the loop below checks the space it has anyway.
+    const size_t need = 2 + n * S2R_STREAM_CHARS_PER_SAMPLE + 1;
     if (!out || cap < need) return need;
     char *p = out;
     *p++ = '[';
     for (size_t i = 0; i < n; i++) {
         if (i) *p++ = ',';
-        p += format_f32(samples[i], p);
+        char one[32];                                      // format_f32 writes at most 24 chars
+        const size_t len = format_f32(samples[i], one);
+        if ((size_t)(out + cap - p) < len + 3) return need;    // cannot happen with cap >= need; never write past cap
+        std::memcpy(p, one, len);
+        p += len;
     }
     *p++ = ']';
     *p = '\0';

@@ -113,12 +113,13 @@ def load_library():
     if _lib is not None:
         return _lib
     path = _build.LIB
-    try:
-        if _build.needs_build():
+    if _build.needs_build():
+        # sources newer than the library (or no library): rebuild, and fail loudly if that is impossible — a stale
+        # libs2r.so would let tests and the bench pass against old code
+        try:
             path = _build.build()
-    except Exception:
-        if not os.path.exists(path):
-            raise
+        except Exception as e:
+            raise RuntimeError("libs2r.so is missing or older than its sources and could not be rebuilt: %s" % (e,)) from e
     L = C.CDLL(path)
     H = C.c_void_p
     sig = {
@@ -198,7 +199,7 @@ def stream_frame_json(samples):
     serde_json's rendering of a Vec<f32> (host only, no device needed)"""
     L = load_library()
     a = np.ascontiguousarray(samples, dtype=np.float32)
-    cap = 3 + 16 * a.size
+    cap = L.s2r_stream_frame_json(None, a.size, None, 0)      # the worst case for n samples (3 + 18 n)
     buf = C.create_string_buffer(cap)
     n = L.s2r_stream_frame_json(a.ctypes.data_as(C.c_void_p), a.size, buf, cap)
     return buf.raw[:n].decode("ascii")

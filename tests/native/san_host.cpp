@@ -3,7 +3,12 @@
 // Built and run by tests/test_sanitizers.py.
 #include "s2r_voices.h"
 #include "s2r_patch.h"
+#include "s2r.h"
+#include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
 #include <random>
 #include <string>
 int main() {
@@ -35,4 +40,33 @@ int main() {
         (s2r_parse_patch(t.data(), t.size(), &p, &name, &err) == 0 ? ok : bad)++;
     }
     printf("pool ok; parser: %d accepted, %d rejected\n", ok, bad);
+    // s2r_stream_frame_json into a heap buffer of EXACTLY the advertised capacity (ASan sees one byte past it):
+    // magnitudes 1e-7 .. 1e13 of both signs, nine-digit values in the "0.00000ddddddddd" window, specials
+    size_t longest = 0;
+    for (int round = 0; round < 40; round++) {
+        const size_t n = round == 0 ? 0 : 1 + rng() % 5000;
+        std::vector<float> x(n);
+        for (size_t i = 0; i < n; i++) {
+            const double mag = std::pow(10.0, -7.0 + 20.0 * (double)(rng() % 100000) / 100000.0);
+            float v = (float)(mag * (1.0 + (double)(rng() % 1000003) / 1000003.0));
+            if (round % 4 == 1) {          // consecutive floats below 2^-19 = 1.9e-6: eight digits behind "-0.00000", the 16-char layout (with the ',' one more than the 16 per sample the first version allowed)
+                uint32_t b; const float hi = 0x1p-19f; std::memcpy(&b, &hi, 4); b -= 1u + (uint32_t)(round * 5000 + i); std::memcpy(&v, &b, 4);
+                x[i] = -v; continue;
+            }
+            if (rng() % 97 == 0) v = (rng() & 1) ? NAN : INFINITY;
+            if (rng() % 89 == 0) { uint32_t b = rng(); std::memcpy(&v, &b, 4); }
+            x[i] = (rng() & 1) ? -v : v;
+        }
+        const size_t need = s2r_stream_frame_json(x.data(), n, nullptr, 0);
+        if (need != 3 + (size_t)S2R_STREAM_CHARS_PER_SAMPLE * n) { printf("stream: need %zu for n %zu\n", need, n); return 1; }
+        char *buf = (char *)std::malloc(need);
+        const size_t len = s2r_stream_frame_json(x.data(), n, buf, need);
+        if (len >= need || buf[len] != 0 || buf[0] != '[' || buf[len - 1] != ']') { printf("stream: bad frame\n"); return 1; }
+        // every element's own length, and the too-small-buffer answer
+        size_t start = 1;
+        for (size_t i = 1; i <= len; i++) if (buf[i] == ',' || buf[i] == ']') { if (i - start > longest) longest = i - start; start = i + 1; }
+        if (n && s2r_stream_frame_json(x.data(), n, buf, need - 1) != need) { printf("stream: short buffer accepted\n"); return 1; }
+        std::free(buf);
+    }
+    printf("stream ok; longest element %zu chars\n", longest);
 }

@@ -48,7 +48,8 @@ def test_fuzz(seed):
     max_frames = int(rng.choice([1024, 1024, 2048, 1040]))
     bank = [random_patch(rng) for _ in range(int(rng.choice([1, 1, 1, 2, 5])))]
     seeds = rng.randint(0, 2 ** 31, voices).astype(np.uint64) if rng.rand() < 0.15 else None   # NoiseState.seed overrides
-    pr = Pair(voices, bank[0], max_frames=max_frames, block_voices=block, mix_groups=groups, lanes=lanes, seeds=seeds)
+    pr = Pair(voices, bank[0], max_frames=max_frames, block_voices=block, mix_groups=groups, lanes=lanes, seeds=seeds,
+              strict_lanes=False)      # a build without the 2- / 4-lane kernels runs the case with one lane
     if len(bank) > 1:
         pr.set_bank(bank)
     pr.gpu.set_coeff_stream(int(rng.choice([1, 3, 3, 4, 0])))

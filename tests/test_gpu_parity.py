@@ -463,10 +463,69 @@ def test_timed_event_errors():
     ev[0] = (1, 60, 24, 1.0)                 # not a multiple of 16
     with pytest.raises(s2.S2rError):
         s.note_events(ev)
-    ev[0] = (1, 60, 256, 1.0)                # at the end of the buffer: belongs to the next fill
-    s.note_events(ev)
+    ev[0] = (1, 60, 256, 1.0)                # no fill of this handle is long enough to contain frame 256
     with pytest.raises(s2.S2rError):
-        s.sample(np.empty(256, dtype=np.float32))
+        s.note_events(ev)
+    s.sample(np.empty(256, dtype=np.float32))        # ... and the handle is not stuck
+    ev[0] = (1, 60, 128, 1.0)
+    s.note_events(ev)
+    with pytest.raises(s2.S2rError):         # a fill that ends before the queued event
+        s.sample(np.empty(64, dtype=np.float32))
+    with pytest.raises(s2.S2rError):         # untimed events cannot follow timed ones
+        s.note_on(61)
+    s.sample(np.empty(256, dtype=np.float32))        # the fill that contains it still works
+
+
+def test_rejected_event_batch_leaves_the_handle_untouched():
+    """a batch is validated as a whole before the first event is applied — an error in its last event
+    must not leave the earlier ones half-applied (host pool and device state would diverge)."""
+    pair = Pair(8, max_frames=256)
+    pair.note_on(60); pair.note_on(64)
+    g, want, _ = pair.sample(256)
+    assert_bits_equal(g, want, "before")
+    for bad_tail in [(7, 60, 0, 1.0),        # unknown kind
+                     (1, 62, 40, 1.0),       # frame % 16
+                     (1, 62, 16, 1.0),       # out of order (after the event at 32)
+                     (0, 62, 4096, 0.0),     # not inside any fill
+                     (2, 5, 0, 0.0)]:        # program past the bank
+        ev = np.zeros(4, dtype=s2.NOTE_EVENT_DTYPE)
+        ev[0] = (1, 67, 0, 1.0); ev[1] = (0, 60, 0, 0.0); ev[2] = (1, 72, 32, 1.0); ev[3] = bad_tail
+        with pytest.raises(s2.S2rError):
+            pair.gpu.note_events(ev)
+        # nothing of the batch happened: the oracle, which never saw it, still agrees — allocation included
+        assert pair.gpu.L.s2r_double_release_count(pair.gpu.h) == 0
+        pair.note_on(65); pair.note_off(64)
+        g, want, _ = pair.sample(256)
+        assert_bits_equal(g, want, "after a rejected batch %r" % (bad_tail,))
+        pair.note_on(64)
+    pair.gpu.note_off(99)                    # nobody holds note 99: ignored (synth.rs:72-80), counted
+    pair.cpu.note_off(99)
+    assert pair.gpu.L.s2r_double_release_count(pair.gpu.h) == 1
+    g, want, _ = pair.sample(256)
+    assert_bits_equal(g, want, "after an unmatched note_off")
+
+
+def test_more_timed_events_than_the_initial_buffers_hold():
+    """the timed-event buffers start at max(4096, shard voices) records and grow on demand"""
+    voices = 64
+    pair = Pair(voices, max_frames=2048)
+    rng = np.random.default_rng(3)
+    n = 6000
+    ev = np.zeros(n, dtype=s2.NOTE_EVENT_DTYPE)
+    frames = np.sort(rng.integers(1, 128, n)) * 16
+    ev["kind"] = rng.integers(0, 2, n); ev["note"] = rng.integers(50, 60, n); ev["frame"] = frames; ev["velocity"] = 1.0
+    pair.gpu.note_events(ev)
+    got = pair.gpu.sample(np.empty(2048, dtype=np.float32))
+    pv = np.zeros((voices, 2048), dtype=np.float32)
+    pos = 0
+    k = 0
+    while pos < 2048:                        # the oracle in the reference's 16-frame call pattern
+        while k < n and ev["frame"][k] == pos:
+            (pair.cpu.note_on if ev["kind"][k] == 1 else pair.cpu.note_off)(int(ev["note"][k]))
+            k += 1
+        pv[:, pos:pos + 16] = pair.cpu.render_voices(16, SR)
+        pos += 16
+    assert_bits_equal(got, s2o.mix_tree(pv, pair.block_voices, 1), "6000 timed events in one fill")
 
 
 # ---------------------------------------------------------------------------------------------

@@ -127,3 +127,18 @@ def test_full_sweeps(libm_xcheck, sleef_xcheck):
     _run(libm_xcheck, "tanf", "all")
     _run(sleef_xcheck, "pow2", -10, 10)
     _run(sleef_xcheck, "grid", 200000000, 7)
+
+
+def test_exp2f_table_is_the_correctly_rounded_one():
+    """s2r_math.h's exp2f table == tools/gen_exp2f_table.py (exact integer arithmetic, no libm)"""
+    import importlib.util
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_exp2f_table", os.path.join(root, "tools", "gen_exp2f_table.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    text = open(os.path.join(root, "synth2_amd", "csrc", "s2r_math.h")).read()
+    body = text[text.index("#define S2R_EXP2F_TABLE_INIT"):]
+    body = body[:body.index("}")]
+    have = [int(x, 16) for x in re.findall(r"0x([0-9a-f]{16})ull", body)]
+    assert have == mod.table()

@@ -1,0 +1,106 @@
+// Micro-benchmark (development aid, not part of the product): what ONE SIMD of gfx950 sustains for the instruction
+// classes of the render kernel, by waves per SIMD, by independent instructions per wave (ILP) and by EXEC mask.
+// Every measured instruction is an `asm volatile` statement with opaque register operands, so the compiler can
+// neither fold, fuse (v_pk_*) nor reorder them; tools/ubench/run_issue_rates3.sh disassembles the code object and
+// checks that each kernel's loop holds exactly the instructions it claims (round 1's issue_rates2.hip let the
+// compiler fold three rows and pack a fourth: VERDICT r1 item 8).
+//
+// Output: cycles per wave-instruction per wave (s_memtime ticks = shader cycles, MI355X_MICROARCH.md) and the SIMD's
+// view (that divided by the waves it holds).
+//
+// build: hipcc --offload-arch=gfx950 -O2 tools/ubench/issue_rates3.hip -o tools/ubench/_build/issue_rates3
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+constexpr int kUnroll = 16;      // asm statements per register per loop iteration
+constexpr int kIters = 256;
+
+// One kernel per instruction form.  ILP independent chains x kUnroll statements per iteration.
+#define S2R_UB_KERNEL(NAME, ILP, DECL, STMT)                                                            \
+    __global__ void __launch_bounds__(1024) ub_##NAME##_ilp##ILP(unsigned long long *ticks, float *sink, \
+                                                                 float a, float b, unsigned m, int half) { \
+        DECL                                                                                            \
+        if (half && (threadIdx.x & 32u)) return;      /* EXEC = lanes 0..31 of every wave */            \
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                     \
+        for (int i = 0; i < kIters; i++) {                                                              \
+            _Pragma("unroll") for (int u = 0; u < kUnroll; u++) {                                       \
+                _Pragma("unroll") for (int j = 0; j < ILP; j++) { STMT }                                \
+            }                                                                                           \
+        }                                                                                               \
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                     \
+        float s = 0.0f;                                                                                 \
+        for (int j = 0; j < ILP; j++) s += x[j] + (float)y[j].x;                                        \
+        sink[blockIdx.x * blockDim.x + threadIdx.x] = s;                                                \
+        if ((threadIdx.x & 63u) == 0) ticks[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0; \
+    }
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+#define DECL_REGS(ILP)                                                                                  \
+    float x[ILP]; f2 y[ILP]; unsigned w[ILP];                                                           \
+    for (int j = 0; j < ILP; j++) { x[j] = threadIdx.x * 1e-3f + j; y[j] = (f2){x[j], x[j] + 1.0f}; w[j] = threadIdx.x * 77u + j; } \
+    f2 a2 = {a, a}, b2 = {b, b}; (void)a2; (void)b2; (void)w;
+
+#define FORMS(ILP)                                                                                                    \
+    S2R_UB_KERNEL(fma, ILP, DECL_REGS(ILP), asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[j]) : "v"(a), "v"(b));)   \
+    S2R_UB_KERNEL(add, ILP, DECL_REGS(ILP), asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[j]) : "v"(a));)               \
+    S2R_UB_KERNEL(mul, ILP, DECL_REGS(ILP), asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[j]) : "v"(a));)               \
+    S2R_UB_KERNEL(pkfma, ILP, DECL_REGS(ILP), asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(y[j]) : "v"(a2), "v"(b2));) \
+    S2R_UB_KERNEL(pkmul, ILP, DECL_REGS(ILP), asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(y[j]) : "v"(a2));)         \
+    S2R_UB_KERNEL(pkadd, ILP, DECL_REGS(ILP), asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(y[j]) : "v"(a2));)         \
+    S2R_UB_KERNEL(fract, ILP, DECL_REGS(ILP), asm volatile("v_fract_f32 %0, %0" : "+v"(x[j]));)                        \
+    S2R_UB_KERNEL(cvtu, ILP, DECL_REGS(ILP), asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(x[j]));)                       \
+    S2R_UB_KERNEL(xor, ILP, DECL_REGS(ILP), asm volatile("v_xor_b32 %0, %0, %1" : "+v"(w[j]) : "v"(m));)               \
+    S2R_UB_KERNEL(addu, ILP, DECL_REGS(ILP), asm volatile("v_add_u32 %0, %0, %1" : "+v"(w[j]) : "v"(m));)              \
+    S2R_UB_KERNEL(ashr, ILP, DECL_REGS(ILP), asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(w[j]));)                    \
+    S2R_UB_KERNEL(mullo, ILP, DECL_REGS(ILP), asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(w[j]) : "v"(m));)          \
+    S2R_UB_KERNEL(pkmullo16, ILP, DECL_REGS(ILP), asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(w[j]) : "v"(m));)   \
+    S2R_UB_KERNEL(pkaddu16, ILP, DECL_REGS(ILP), asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(w[j]) : "v"(m));)       \
+    S2R_UB_KERNEL(cndmask, ILP, DECL_REGS(ILP), asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[j]) : "v"(a));)  \
+    S2R_UB_KERNEL(cmp, ILP, DECL_REGS(ILP), asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(x[j]), "v"(a) : "vcc");)   \
+    S2R_UB_KERNEL(rcp, ILP, DECL_REGS(ILP), asm volatile("v_rcp_f32 %0, %0" : "+v"(x[j]));)                            \
+    S2R_UB_KERNEL(fma64, ILP, DECL_REGS(ILP), asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(y[j]) : "v"(a2), "v"(b2));) \
+    S2R_UB_KERNEL(readlane, ILP, DECL_REGS(ILP), { unsigned s_; asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(s_) : "v"(w[j])); })
+
+FORMS(1)
+FORMS(4)
+FORMS(8)
+
+typedef void (*kern_t)(unsigned long long *, float *, float, float, unsigned, int);
+struct Row { const char *name; kern_t k1, k4, k8; };
+#define ROW(NAME) {#NAME, ub_##NAME##_ilp1, ub_##NAME##_ilp4, ub_##NAME##_ilp8}
+
+int main(int argc, char **argv) {
+    const Row rows[] = {ROW(fma), ROW(add), ROW(mul), ROW(pkfma), ROW(pkmul), ROW(pkadd), ROW(fract), ROW(cvtu), ROW(xor),
+                        ROW(addu), ROW(ashr), ROW(mullo), ROW(pkmullo16), ROW(pkaddu16), ROW(cndmask), ROW(cmp), ROW(rcp),
+                        ROW(fma64), ROW(readlane)};
+    unsigned long long *ticks; float *sink;
+    hipMalloc(&ticks, 256 * 16 * sizeof(unsigned long long));
+    hipMalloc(&sink, 256 * 1024 * sizeof(float));
+    std::vector<unsigned long long> h(256 * 16);
+    printf("# cycles per wave-instruction as one wave sees them (median over waves, s_memtime) | the SIMD's cycles per wave-instruction\n");
+    printf("# 256 workgroups (one per CU); %d statements per chain per iteration, %d iterations\n", kUnroll, kIters);
+    printf("%-10s %4s %5s %5s | %8s %8s\n", "instr", "ilp", "w/SIMD", "exec", "per wave", "per SIMD");
+    for (const Row &r : rows) {
+        for (int ilp : {1, 4, 8}) {
+            kern_t k = ilp == 1 ? r.k1 : ilp == 4 ? r.k4 : r.k8;
+            for (int waves : {1, 2, 4}) {
+                for (int half : {0, 1}) {
+                    if (half && ilp == 1) continue;
+                    const int threads = 256 * waves;
+                    hipLaunchKernelGGL(k, dim3(256), dim3(threads), 0, 0, ticks, sink, 1.0001f, 0.5f, 0x1234567u, half);
+                    hipLaunchKernelGGL(k, dim3(256), dim3(threads), 0, 0, ticks, sink, 1.0001f, 0.5f, 0x1234567u, half);
+                    hipDeviceSynchronize();
+                    const int n_w = 256 * threads / 64;
+                    hipMemcpy(h.data(), ticks, n_w * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+                    std::sort(h.begin(), h.begin() + n_w);
+                    const double cyc = (double)h[n_w / 2] / ((double)kIters * kUnroll * ilp);
+                    printf("%-10s %4d %5d %5s | %8.2f %8.2f\n", r.name, ilp, waves, half ? "0-31" : "all", cyc, cyc / waves);
+                }
+            }
+        }
+    }
+    return 0;
+}
