@@ -97,10 +97,9 @@ typedef struct {
                                       0 => 256.  Part of the mix-tree spec */
     uint32_t mix_groups;           /* >= 1: second-level grouping of the block partials so a
                                       1-GPU run reproduces the G-GPU summation order; 0 => 1 */
-    uint32_t lanes_per_voice;      /* 1, 2 or 4 GPU lanes cooperating on one voice (a pure
-                                      scheduling knob: results are bit-identical); 0 => 1,
-                                      the fastest at every pool size.  2 and 4 need a build with
-                                      -DS2R_WITH_LANE_VARIANTS and otherwise mean 1 */
+    uint32_t lanes_per_voice;      /* 0 or 1: one GPU lane per voice.  (2 and 4 — round 1's kernels that
+                                      spread a voice over several lanes, bit-identical and slower at every
+                                      pool size — are still accepted and mean 1.) */
     /* Round-robin sharding (0 => off: this handle renders the contiguous range above).  G > 0: the
      * pool is dealt out in runs of G consecutive voices to shard_count handles, and this one
      * (shard_index) renders every shard_count-th run — its local voice l is pool voice

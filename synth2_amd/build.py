@@ -12,8 +12,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libs2r.so")
-SOURCES = ["s2r_kernels.hip", "s2r_host.cpp", "s2r_patch.cpp", "s2r_stream.cpp"]
-HEADERS = ["s2r_device.h", "s2r_math.h", "s2r_patch.h", "s2r_voices.h"]
+# One translation unit per oscillator kind for each of the two render kernels: they compile in parallel (the whole
+# library in ~40 s on 8 cores instead of ~110 s as one file) and share everything through s2r_kern_common.h.
+SOURCES = ["s2r_render_onepole_square.hip", "s2r_render_onepole_saw.hip", "s2r_render_onepole_triangle.hip",
+           "s2r_render_onepole_sine.hip", "s2r_render_general_square.hip", "s2r_render_general_saw.hip",
+           "s2r_render_general_triangle.hip", "s2r_render_general_sine.hip", "s2r_render_general_bank.hip",
+           "s2r_aux.hip", "s2r_host.cpp", "s2r_patch.cpp", "s2r_stream.cpp"]
+HEADERS = ["s2r_device.h", "s2r_math.h", "s2r_patch.h", "s2r_voices.h", "s2r_kern_common.h", "s2r_render_onepole.inc",
+           "s2r_render_general.inc"]
+OBJ_DIR = os.path.join(HERE, "_build")
 # -amdgpu-sched-strategy=max-ilp: the render kernels run one wavefront per SIMD (64 k voices =
 # 1024 waves), so nothing hides a dependent instruction's latency except independent work of the
 # same wave; the default (occupancy-driven) scheduler lines the recurrences up back to back
@@ -23,7 +30,7 @@ HEADERS = ["s2r_device.h", "s2r_math.h", "s2r_patch.h", "s2r_voices.h"]
 # writer of it existed in the loop; -O1 and -O2 builds of the identical source are right).
 FLAGS = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
          "-mllvm", "-amdgpu-sched-strategy=max-ilp",
-         "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+         "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
 # S2R_WITH_LANE_VARIANTS=1 in the environment also builds the 2- and 4-lanes-per-voice render kernels (48 more
@@ -47,14 +54,37 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return LIB
-    cmd = [_hipcc()] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB] + \
-          [os.path.join(CSRC, f) for f in SOURCES]
+def _compile_one(args):
+    cc, src, obj, verbose = args
+    cmd = [cc] + FLAGS + ["-x", "hip", "-c", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", obj, src]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    return obj
+
+
+def build(force=False, verbose=False, jobs=None):
+    if not force and not needs_build():
+        return LIB
+    from concurrent.futures import ThreadPoolExecutor
+    cc = _hipcc()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    lib_deps = [os.path.join(CSRC, f) for f in HEADERS] + [os.path.join(ROOT, "include", "s2r.h"), __file__]
+    newest_dep = max(os.path.getmtime(d) for d in lib_deps)
+    todo, objs = [], []
+    for f in SOURCES:
+        src, obj = os.path.join(CSRC, f), os.path.join(OBJ_DIR, os.path.splitext(f)[0] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(newest_dep, os.path.getmtime(src)):
+            todo.append((cc, src, obj, verbose))
+    jobs = jobs or max(1, min(len(todo), os.cpu_count() or 1, 8))
+    if todo:
+        with ThreadPoolExecutor(max_workers=jobs) as ex:
+            list(ex.map(_compile_one, todo))
+    link = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(link), file=sys.stderr)
+    subprocess.check_call(link)
     return LIB
 
 

@@ -1,0 +1,233 @@
+// s2r_aux.hip — the small kernels around the render kernels (coefficient tables, note events, mix, decimator) and
+// the launch dispatch.  gfx950 only; -ffp-contract=off.
+#include "s2r_kern_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// Coefficient tables of one patch (S2rTabRef): one thread per entry.  The mod envelope's value at the
+// entry — the very expression the render kernels evaluate, env_value() on the stage's line — goes through the same
+// routines a voice would run per frame: sleef pow (process.rs:231-250), then filters.rs:20-24 or dsp_filters.rs.
+//   entries [0, n_ad)                     attack + decay, index = frame offset t
+//           [n_ad, n_ad + n_rel)          release that starts at the clamp attack + decay, index = t - rc_t0
+//           [n_ad + n_rel, n_ad + 2 n_rel) later release, index = t - release_frame_offset
+//           then 16 x sustain, 16 x end, 16 x "no voice" (x = 1, 1 - x = 0)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) s2r_table_kernel(const S2rTabBuild b) {
+    __shared__ uint64_t sT[S2R_EXP2F_N];
+    if (threadIdx.x < S2R_EXP2F_N) sT[threadIdx.x] = c_exp2f_table[threadIdx.x];
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.n_entries) return;
+    const S2rEnv &e = b.mod;
+    float mod;
+    bool dead = false;
+    if (i < b.n_ad) {
+        const float t = (float)i;
+        const EnvRun s = env_stage_at(e, __builtin_inff(), __builtin_inff(), t);      // attack, decay (then sustain: padding)
+        mod = env_value(s, t);
+    } else if (i < b.n_ad + b.n_rel) {
+        const float t = (float)(b.rc_t0 + (i - b.n_ad));
+        mod = e.slope_rel * (t - e.sus_off) + e.S;               // simdtest.rs:312-318 with release_offset = attack + decay
+    } else if (i < b.n_ad + 2u * b.n_rel) {
+        const float d = (float)(i - b.n_ad - b.n_rel);           // t - release_offset, exact below 2^24
+        mod = e.slope_rel * d + e.S;
+    } else if (i < b.n_ad + 2u * b.n_rel + 16u) {
+        mod = 0.0f * 1.0f + e.S;                                 // sustain: 0 * (t - 0) + S
+    } else {
+        mod = 0.0f;                                              // end: 0 * (t - 0) + 0
+        dead = i >= b.n_ad + 2u * b.n_rel + 32u;
+    }
+    const float f_lpf = s2r_pow2_sleef_core(mod * b.amt_lpf) * b.lpf_freq;            // process.rs:148-152
+    float c0, c1, c2 = 0.0f;
+    if (b.lpf_kind == S2R_FILT_ONEPOLE) {
+        const float num = (-2.0f * 3.14159274101257324f) * f_lpf;                     // filters.rs:20-21
+        const float arg = b.fast_div_sr ? s2r_div_const_nocheck(num, b.sr, b.rcp_sr) : (num / b.sr);
+        c0 = s2r_expf(arg, sT);
+        c1 = 1.0f - c0;                                          // a0, filters.rs:23
+        if (dead) { c0 = 1.0f; c1 = 0.0f; }
+    } else {
+        const FiltCoef fc = dsp_filter_coef(b.lpf_kind, b.lpf_damping, b.sr, f_lpf);
+        c0 = fc.alpha; c1 = fc.beta; c2 = fc.gamma;
+    }
+    b.base[i] = c0;
+    b.base[(size_t)b.plane + i] = c1;
+    if (b.lpf_kind != S2R_FILT_ONEPOLE) b.base[2u * (size_t)b.plane + i] = c2;
+    if (b.fm_plane) b.base[(size_t)b.fm_plane * b.plane + i] = dead ? 1.0f : s2r_pow2_sleef_core(mod * b.amt_osc);   // process.rs:146-147
+}
+
+// ---------------------------------------------------------------------------------------
+// mix kernel: adds the workgroup partial rows in the fixed order of DESIGN.md 4.3:
+//   runs of 16 consecutive workgroups sequentially -> the run sums of a mix group sequentially
+//   -> the mix groups sequentially -> root (+0.0) + total.
+// One workgroup handles 16 frames: thread (slot, f) adds whole runs (16 independent loads in
+// flight each), the run sums meet in LDS, 16 threads finish.  Runs never straddle a mix group.
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t kMixRun = 16;
+
+__global__ void __launch_bounds__(256) s2r_mix_kernel(const S2rMixParams m) {
+    extern __shared__ float s_run[];                             // [total runs][16 frames]
+    const uint32_t f_local = threadIdx.x & 15u, slot = threadIdx.x >> 4;
+    const uint32_t f = blockIdx.x * 16u + f_local;
+    const uint32_t runs_per_group = (m.blocks_per_group + kMixRun - 1) / kMixRun;
+    const uint32_t total_runs = runs_per_group * m.n_groups;
+    if (f < m.frames) {
+        for (uint32_t run = slot; run < total_runs; run += 16u) {
+            const uint32_t g = run / runs_per_group, rg = run % runs_per_group;
+            const uint32_t gb0 = g * m.blocks_per_group;
+            uint32_t gb1 = gb0 + m.blocks_per_group; if (gb1 > m.n_blocks) gb1 = m.n_blocks;
+            const uint32_t b0 = gb0 + rg * kMixRun;
+            float v[kMixRun];
+#pragma unroll
+            for (uint32_t j = 0; j < kMixRun; ++j) v[j] = (b0 + j < gb1) ? m.block_partials[(size_t)(b0 + j) * m.frames_stride + f] : 0.0f;
+            float acc = v[0];
+#pragma unroll
+            for (uint32_t j = 1; j < kMixRun; ++j) if (b0 + j < gb1) acc += v[j];
+            s_run[run * 16u + f_local] = (b0 < gb1) ? acc : 0.0f;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 16u && f < m.frames) {
+        float total = 0.0f;                                      // accum = splat(0.0), synth.rs:176
+        for (uint32_t g = 0; g < m.n_groups; ++g) {
+            const uint32_t gb0 = g * m.blocks_per_group;
+            uint32_t gb1 = gb0 + m.blocks_per_group; if (gb1 > m.n_blocks) gb1 = m.n_blocks;
+            if (gb0 >= gb1) continue;
+            const uint32_t n_runs = (gb1 - gb0 + kMixRun - 1) / kMixRun;
+            float acc = s_run[(g * runs_per_group) * 16u + f_local];
+            for (uint32_t r = 1; r < n_runs; ++r) acc += s_run[(g * runs_per_group + r) * 16u + f_local];
+            total = (m.root_add || g > 0) ? total + acc : acc;
+        }
+        if (m.stereo) { m.out[2 * f] = total; m.out[2 * f + 1] = total; }
+        else m.out[f] = total;
+    }
+}
+
+// out[i] = ((+0.0 + rows[0][i]) + rows[1][i]) + ...   (rank-order combine of shard partials)
+__global__ void s2r_sum_rows_kernel(const float *rows, uint32_t n_rows, uint32_t frames, float *out) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= frames) return;
+    float total = 0.0f;
+    for (uint32_t r = 0; r < n_rows; ++r) total += rows[(size_t)r * frames + f];
+    out[f] = total;
+}
+
+// build-defined 4x decimator: out[n] = sum over k of h[k] * x[4n + k], taps in index order,
+// product and sum rounded separately
+constexpr int kDecimTaps = 63;
+__global__ void s2r_decimate4_kernel(const float *x, const float *h, uint32_t n_out, float *out) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_out) return;
+    float acc = 0.0f;
+    for (int k = 0; k < kDecimTaps; ++k) acc = acc + h[k] * x[4u * n + (uint32_t)k];
+    out[n] = acc;
+}
+__global__ void s2r_decimate4_history_kernel(float *x, uint32_t n_out) {
+    const uint32_t i = threadIdx.x;                              // one workgroup of 64: read, then write (ranges may overlap)
+    float v = 0.0f;
+    if (i < kDecimTaps - 1) v = x[4u * n_out + i];
+    __syncthreads();
+    if (i < kDecimTaps - 1) x[i] = v;
+}
+
+// publishes the first timed event of every touched voice
+// ... and moves the records from mapped host memory into HBM in one coalesced sweep: the coefficient pass and
+// the render kernel follow per-voice chains through them, and a PCIe round trip per hop is what they cannot afford
+__global__ void s2r_tev_heads_kernel(int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const S2rTimedEvent e = tev[i];
+    tev_copy[i] = e;
+    if (e.flags & S2R_TEV_FIRST) heads[e.voice] = (int32_t)i;
+}
+
+// note events folded per voice by the host (synth.rs:61-80)
+__global__ void s2r_events_kernel(const S2rVoiceArrays v, const S2rVoiceEvent *ev, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const S2rVoiceEvent e = ev[i];
+    const uint32_t vi = e.voice;
+    if (e.flags & S2R_EV_RESTART) {                              // *voice = Voice { .. }, synth.rs:63-69
+        v.pitch[vi] = e.pitch;
+        v.offset[vi] = 0u;
+        v.release[vi] = 0u;                                      // a release right after the on is at offset 0
+        v.flags[vi] = S2R_VF_STARTED | ((e.flags & S2R_EV_RELEASE) ? S2R_VF_RELEASED : 0u);
+        v.phase[vi] = 0.0f;
+        v.lpf_last[vi] = 0.0f;
+        v.fx1[vi] = 0.0f; v.fx2[vi] = 0.0f; v.fy1[vi] = 0.0f; v.fy2[vi] = 0.0f;
+        v.seed[vi] = e.seed;
+        v.program[vi] = e.flags >> S2R_EV_PROGRAM_SHIFT;
+    } else if (e.flags & S2R_EV_RELEASE) {                       // synth.rs:74-75
+        const uint32_t fl = v.flags[vi];
+        if ((fl & S2R_VF_STARTED) && !(fl & S2R_VF_RELEASED)) {
+            v.release[vi] = v.offset[vi];
+            v.flags[vi] = fl | S2R_VF_RELEASED;
+        }
+    }
+}
+}  // namespace
+
+hipError_t s2r_launch_onepole_osc0(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
+hipError_t s2r_launch_onepole_osc1(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
+hipError_t s2r_launch_onepole_osc2(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
+hipError_t s2r_launch_onepole_osc3(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
+hipError_t s2r_launch_general_osc0(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
+hipError_t s2r_launch_general_osc1(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
+hipError_t s2r_launch_general_osc2(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
+hipError_t s2r_launch_general_osc3(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
+hipError_t s2r_launch_general_osc4(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);   // the patch bank
+
+hipError_t s2r_launch_tables(const S2rTabBuild &b, hipStream_t stream) {
+    if (b.n_entries == 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(s2r_table_kernel, dim3((b.n_entries + 255u) / 256u), dim3(256), 0, stream, b);
+    return hipGetLastError();
+}
+
+hipError_t s2r_launch_render(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream) {
+    const S2rRenderParams &p = a.p;
+    if (p.n_voices == 0 || p.frames == 0) return hipSuccess;
+    if (block_voices < 64 || block_voices > 1024 || (block_voices & 63u)) return hipErrorInvalidValue;
+    if (p.bank_size > 1) return s2r_launch_general_osc4(a, block_voices, stream);
+    const bool general = p.lpf_kind != S2R_FILT_ONEPOLE;
+    switch (p.osc_kind) {
+    case S2R_OSC_SQUARE: return general ? s2r_launch_general_osc0(a, block_voices, stream) : s2r_launch_onepole_osc0(a, block_voices, stream);
+    case S2R_OSC_SAW: return general ? s2r_launch_general_osc1(a, block_voices, stream) : s2r_launch_onepole_osc1(a, block_voices, stream);
+    case S2R_OSC_TRIANGLE: return general ? s2r_launch_general_osc2(a, block_voices, stream) : s2r_launch_onepole_osc2(a, block_voices, stream);
+    case S2R_OSC_SINE: return general ? s2r_launch_general_osc3(a, block_voices, stream) : s2r_launch_onepole_osc3(a, block_voices, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t s2r_launch_mix(const S2rMixParams &m, hipStream_t stream) {
+    if (m.frames == 0) return hipSuccess;
+    const uint32_t runs_per_group = (m.blocks_per_group + kMixRun - 1) / kMixRun;
+    const size_t lds = (size_t)runs_per_group * m.n_groups * 16u * sizeof(float);
+    if (lds > 64u * 1024u) return hipErrorInvalidValue;          // > 16 k workgroups in one shard
+    hipLaunchKernelGGL(s2r_mix_kernel, dim3((m.frames + 15) / 16), dim3(256), lds, stream, m);
+    return hipGetLastError();
+}
+
+hipError_t s2r_launch_events(const S2rVoiceArrays &v, const S2rVoiceEvent *dev_events, uint32_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(s2r_events_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, v, dev_events, n);
+    return hipGetLastError();
+}
+
+hipError_t s2r_launch_tev_heads(int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(s2r_tev_heads_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, heads, tev, tev_copy, n);
+    return hipGetLastError();
+}
+
+hipError_t s2r_launch_decimate4(float *x_with_history, const float *taps, uint32_t n_out, float *out, hipStream_t stream) {
+    if (n_out == 0) return hipSuccess;
+    hipLaunchKernelGGL(s2r_decimate4_kernel, dim3((n_out + 255) / 256), dim3(256), 0, stream, x_with_history, taps, n_out, out);
+    hipLaunchKernelGGL(s2r_decimate4_history_kernel, dim3(1), dim3(64), 0, stream, x_with_history, n_out);
+    return hipGetLastError();
+}
+
+hipError_t s2r_launch_sum_rows(const float *rows, uint32_t n_rows, uint32_t frames, float *out, hipStream_t stream) {
+    if (frames == 0) return hipSuccess;
+    hipLaunchKernelGGL(s2r_sum_rows_kernel, dim3((frames + 255) / 256), dim3(256), 0, stream, rows, n_rows, frames, out);
+    return hipGetLastError();
+}

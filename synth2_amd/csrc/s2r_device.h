@@ -52,6 +52,32 @@ struct S2rBankEntry {
 
 struct S2rTimedEvent;
 
+// Coefficient tables of ONE patch at one sample rate.  The x16 ADSR (old/simdtest.rs:270-331) makes
+// the mod envelope's value a function of the frame offset t alone while the voice is in its attack or decay stage
+// (the release offset is clamped to attack + decay, simdtest.rs:283), of t alone in a release that starts at that
+// clamp, and of d = t - release_offset alone in a later release; in sustain and after the end it is a constant.  So
+// the chain behind it — sleef pow -> * freq -> filter coefficients (process.rs:146-152,231-250; filters.rs:20-24 or
+// dsp_filters.rs) — is tabulated once per (patch, sample rate) by s2r_table_kernel with the very routines the render
+// kernels would run per voice and frame, and a voice reads its coefficients at base[idx + (offset & mask)].
+// Planes (each `plane` floats apart): one-pole: x = exp(-2 pi f / sr), 1 - x; dsp_filters.rs kinds / SVF: alpha,
+// beta, gamma; then, under oscillator FM, pow(2, mod * mod_env_to_osc_freq).
+// Valid for offsets below 2^24 (where (offset as f32) is exact); older voices compute in-lane.
+struct S2rTabRef {
+    const float *base;    // plane 0, entry 0; nullptr: no tables (too long an envelope, or switched off)
+    uint32_t plane;       // floats per plane
+    int32_t ad;           // attack + decay:      entry ad + t,              0 <= t < attack + decay
+    int32_t rc;           // release at the clamp: entry rc + (t - rc_t0),   rc_t0 = ceil(attack + decay)
+    uint32_t rc_t0;
+    int32_t ru;           // later release:       entry ru + (t - release_frame_offset)
+    int32_t sus;          // 16 equal entries: the sustain stage's constant
+    int32_t end;          // 16 equal entries: after the release
+    int32_t dead;         // 16 equal entries: x = 1, 1 - x = 0 — what makes a lane without a started voice put +0.0
+                          // into the mix without a select (one-pole kernel)
+    uint32_t fm_plane;    // index of the pow(2, mod * mod_env_to_osc_freq) plane (2 or 3), 0 = none
+};
+#define S2R_TAB_PAD 16u          // entries a 16-frame chunk may read past a region's last used one
+#define S2R_TAB_MAX_ENTRIES (1u << 22)
+
 struct S2rRenderParams {
     // patch (static_config.rs:4-44), shared by every voice
     int32_t osc_kind;
@@ -67,7 +93,7 @@ struct S2rRenderParams {
     float sr;             // sample_rate as f32 (units.rs:21)
     float rcp_sr;         // RN(1/sr)
     int32_t fast_div_sr;  // 1 => x/sr may use the 3-op exact quotient (rate verified exhaustively)
-    int32_t no_flat_shortcut;  // 1 => always recompute the LPF coefficient (measurement knob)
+    int32_t no_flat_shortcut;  // 1 => always recompute the filter coefficient per frame, in-lane (measurement knob)
     uint32_t frames;      // this fill
     uint32_t n_voices;    // shard voices
     uint32_t frames_stride; // row stride of block_partials / per_voice (== max_frames or frames)
@@ -79,16 +105,9 @@ struct S2rRenderParams {
     int32_t direct_stereo;   // interleaved L,R
     float *per_voice;        // [n_voices][frames] or nullptr (mix-disabled debug/parity path)
     const float *sin_table;  // 1024 floats (tables.rs)
-    // coefficient stream: LPF coefficients of the 64-voice groups whose mod
-    // envelope moves during this fill, computed ahead of the render kernel by s2r_coeff_kernel
-    int32_t use_coeff;          // 0: never look at the stream
-    const int32_t *group_slot;  // [n_groups64] stream slot of each 64-voice group, -1 = none
-    int32_t *group_slot_w;      // same array, writable (classify kernel)
-    uint32_t *slot_group;       // [coeff_capacity] inverse map
-    uint32_t *coeff_count;      // [2] slots handed out this fill (index = coeff_parity), next fill's is zeroed
-    uint32_t coeff_parity;
-    uint32_t coeff_capacity;    // slots the stream buffer holds; more moving groups => in-lane path
-    float *coeff;               // [slot][quad][64][4]
+    // coefficient tables: everything of a frame that depends on the mod envelope alone, as a
+    // function of the envelope's own clock — shared by every voice that plays this patch
+    S2rTabRef tab;
     // timed events of this fill (nullptr: none)
     const S2rTimedEvent *tev;
     int32_t *voice_ev_head;     // [padded voices] index of the voice's first timed event, -1 = none
@@ -126,17 +145,30 @@ struct S2rTimedEvent {
 };
 #define S2R_TEV_FIRST 0x100u
 
-// Events + classification in one launch: the fill's folded note events ride in
-// the kernel arguments (no trip to host memory); every 64-voice group applies the ones that hit
-// it and classifies itself on the result.
-#define S2R_PREP_MAX_EVENTS 288u
-struct S2rPrepParams {
+// The fill's folded note events ride in the render kernel's own arguments when there are few of them (no trip to
+// host memory, no launch of their own): every wave picks the records that hit its 64 voices and applies them before it
+// loads its state.
+#define S2R_ARG_MAX_EVENTS 288u
+struct S2rRenderArgs {
     S2rRenderParams p;
     uint32_t n_events;
     uint32_t _pad;
-    uint32_t ev[3 * S2R_PREP_MAX_EVENTS];   // voice, S2rVoiceEvent.flags, pitch bits
+    uint32_t ev[3 * S2R_ARG_MAX_EVENTS];   // voice, S2rVoiceEvent.flags, pitch bits
 };
-static_assert(sizeof(S2rPrepParams) <= 4096, "kernel arguments are limited to 4 KiB");
+static_assert(sizeof(S2rRenderArgs) <= 4096, "kernel arguments are limited to 4 KiB");
+
+// what s2r_table_kernel needs: the patch resolved for a sample rate and where the planes go
+struct S2rTabBuild {
+    S2rEnv mod;
+    float lpf_freq, amt_lpf, amt_osc, sr, rcp_sr;
+    int32_t fast_div_sr;
+    int32_t lpf_kind;
+    float lpf_damping;
+    float *base;
+    uint32_t plane, n_ad, n_rel, n_entries;   // region lengths incl. padding; entries per plane
+    uint32_t rc_t0;
+    uint32_t fm_plane;
+};
 
 struct S2rMixParams {
     const float *block_partials;  // [n_blocks][frames_stride]
@@ -150,10 +182,8 @@ struct S2rMixParams {
     float *out;
 };
 
-hipError_t s2r_launch_coeff(const S2rRenderParams &p, hipStream_t stream);   // classify + coefficient pass
-hipError_t s2r_launch_prep(const S2rPrepParams &a, hipStream_t stream);      // events + classify in one launch, then the coefficient pass
-hipError_t s2r_launch_render(const S2rRenderParams &p, uint32_t block_voices, uint32_t lanes_per_voice, hipStream_t stream);
-bool s2r_lane_variants_built();      // the 2- and 4-lanes-per-voice kernels exist only in builds with -DS2R_WITH_LANE_VARIANTS
+hipError_t s2r_launch_tables(const S2rTabBuild &b, hipStream_t stream);
+hipError_t s2r_launch_render(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
 hipError_t s2r_launch_mix(const S2rMixParams &p, hipStream_t stream);
 hipError_t s2r_launch_events(const S2rVoiceArrays &v, const S2rVoiceEvent *dev_events, uint32_t n, hipStream_t stream);
 hipError_t s2r_launch_tev_heads(int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n, hipStream_t stream);

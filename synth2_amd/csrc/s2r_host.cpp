@@ -132,10 +132,12 @@ struct s2r_synth {
     float *os_buf = nullptr, *os_taps = nullptr; // 4x oversampling: [62 history + max_frames] mix at 4x rate, 63 taps
     float *sin_dev = nullptr;
     float *per_voice_dev = nullptr; size_t per_voice_cap = 0;
-    // coefficient stream (s2r_kernels.hip)
-    int32_t *group_slot = nullptr; uint32_t *slot_group = nullptr; uint32_t *coeff_count = nullptr; float *coeff = nullptr;
-    uint32_t coeff_capacity = 0, coeff_parity = 0; bool use_coeff = true, use_prep = true, force_stream = false;
-    uint32_t coeff_vecs = 1;                     // vectors per quad the stream buffer is sized for (3 once an FM patch streams)
+    // coefficient tables of the patch (S2rTabRef): rebuilt on the device when the patch or the sample
+    // rate changes
+    float *tab_dev = nullptr; size_t tab_cap = 0;        // floats
+    S2rTabRef tab{};
+    bool tab_dirty = true; uint32_t tab_rate = 0;
+    bool use_tab = true, use_arg_events = true;
     float pitch_table[256];
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool timing = false, timed = false, no_flat_shortcut = false;
@@ -272,14 +274,52 @@ int check_fill(s2r_synth *s, size_t frames, uint32_t sample_rate) {
     return S2R_OK;
 }
 
-// The coefficient stream (and with it the classification launch) pays when a fill has many chunks
-// and the shard many waves; a 16-frame fill of a handful of voices — s2_bin's own call pattern,
-// main.rs:138-143 — is quicker without the two extra launches (28 -> 22 us per call).  Only where it is
-// defined: a single patch (the dsp_filters.rs kinds with workgroups of up to 256 voices), the flat-envelope logic enabled.
-bool stream_wanted(const s2r_synth *s, size_t frames) {
-    return s->use_coeff && !s->no_flat_shortcut && s->coeff != nullptr && s->bank.size() == 1 &&
-           (s->bank[0].lpf_kind == S2R_FILT_ONEPOLE || s->block_voices <= 256u) &&
-           (s->force_stream || (frames >= 128 && s->shard_voices >= 1024u));
+// Coefficient tables exist for a single patch (the one-pole kernel, and the dsp_filters.rs kinds with workgroups of up
+// to 256 voices) while the flat-envelope logic is enabled.
+bool tables_wanted(const s2r_synth *s) {
+    return s->use_tab && !s->no_flat_shortcut && s->bank.size() == 1 &&
+           (s->bank[0].lpf_kind == S2R_FILT_ONEPOLE || s->block_voices <= 256u);
+}
+
+// (Re)builds the patch's coefficient tables for this sample rate on `stream` when the patch or the rate changed.
+// Envelopes too long to tabulate (attack + decay or release beyond S2R_TAB_MAX_ENTRIES frames) leave tab.base null:
+// such a patch computes in-lane.
+int ensure_tables(s2r_synth *s, const S2rRenderParams &p, uint32_t sample_rate, hipStream_t stream) {
+    if (!tables_wanted(s)) { return S2R_OK; }
+    if (!s->tab_dirty && s->tab_rate == sample_rate) return S2R_OK;
+    s->tab = S2rTabRef{};
+    s->tab_dirty = false; s->tab_rate = sample_rate;
+    const S2rEnv &e = p.mod;
+    if (!(e.sus_off >= 0.0f && e.sus_off < (float)S2R_TAB_MAX_ENTRIES && e.R >= 0.0f && e.R < (float)S2R_TAB_MAX_ENTRIES)) return S2R_OK;
+    S2rTabBuild b{};
+    b.mod = e;
+    b.lpf_freq = p.lpf_freq; b.amt_lpf = p.amt_lpf; b.amt_osc = p.amt_osc; b.sr = p.sr; b.rcp_sr = p.rcp_sr;
+    b.fast_div_sr = p.fast_div_sr; b.lpf_kind = p.lpf_kind; b.lpf_damping = p.lpf_damping;
+    b.rc_t0 = (uint32_t)std::ceil((double)e.sus_off);
+    b.n_ad = b.rc_t0 + 1u + S2R_TAB_PAD;
+    b.n_rel = (uint32_t)std::ceil((double)e.R) + 2u + S2R_TAB_PAD;
+    b.n_entries = b.n_ad + 2u * b.n_rel + 48u;
+    b.plane = (b.n_entries + 3u) & ~3u;
+    const bool onepole = p.lpf_kind == S2R_FILT_ONEPOLE;
+    const uint32_t n_planes = (onepole ? 2u : 3u) + (p.amt_osc != 0.0f ? 1u : 0u);
+    b.fm_plane = p.amt_osc != 0.0f ? (onepole ? 2u : 3u) : 0u;
+    const size_t need = (size_t)b.plane * n_planes;
+    if (need > s->tab_cap) {
+        // earlier fills (other streams included) may still read the old planes
+        S2R_HIP(s, hipStreamSynchronize(stream));
+        S2R_HIP(s, hipStreamSynchronize(s->stream));
+        if (s->tab_dev) { S2R_HIP(s, hipFree(s->tab_dev)); s->tab_dev = nullptr; s->tab_cap = 0; }
+        S2R_HIP(s, hipMalloc((void **)&s->tab_dev, need * sizeof(float)));
+        s->tab_cap = need;
+    }
+    b.base = s->tab_dev;
+    S2R_HIP(s, s2r_launch_tables(b, stream));
+    S2rTabRef &t = s->tab;
+    t.base = s->tab_dev; t.plane = b.plane;
+    t.ad = 0; t.rc = (int32_t)b.n_ad; t.rc_t0 = b.rc_t0; t.ru = (int32_t)(b.n_ad + b.n_rel);
+    t.sus = (int32_t)(b.n_ad + 2u * b.n_rel); t.end = t.sus + 16; t.dead = t.sus + 32;
+    t.fm_plane = b.fm_plane;
+    return S2R_OK;
 }
 
 S2rRenderParams make_params(s2r_synth *s, size_t frames, uint32_t sample_rate) {
@@ -307,29 +347,22 @@ S2rRenderParams make_params(s2r_synth *s, size_t frames, uint32_t sample_rate) {
     p.block_partials = s->block_partials;
     p.per_voice = nullptr;
     p.sin_table = s->sin_dev;
-    // stream only where it is defined: one-pole patch, the flat-envelope logic enabled
-    p.use_coeff = stream_wanted(s, frames) ? 1 : 0;
     p.bank = s->bank_dev;
     p.bank_size = (uint32_t)s->bank.size();
-    p.group_slot = s->group_slot; p.group_slot_w = s->group_slot; p.slot_group = s->slot_group;
-    p.coeff_count = s->coeff_count; p.coeff_parity = s->coeff_parity; p.coeff_capacity = s->coeff_capacity;
-    p.coeff = s->coeff;
     return p;
 }
 
 // events -> render -> (mix) on `stream`; the partial or final mix lands in `dev_out`
 int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t stream, float *dev_out,
                  bool root_add, bool stereo, float *per_voice_dev) {
-    // The common case — a one-pole patch without oscillator FM, a handful of untimed events without
-    // seed overrides — is prepared by two launches (events + classification with the events in the
-    // kernel arguments, then the coefficient pass) instead of three.
-    bool one_launch = s->use_prep && stream_wanted(s, frames) && frames >= 16 && s->tpending.empty() &&
-                      s->pending.size() <= S2R_PREP_MAX_EVENTS;
-    if (one_launch)
-        for (const S2rVoiceEvent &e : s->pending) if (e.seed != 0u) { one_launch = false; break; }
+    // The common case — a handful of untimed events without seed overrides — needs no launch for them: they ride in
+    // the render kernel's arguments and every wave applies the ones that hit its voices before it loads its state.
+    bool arg_events = s->use_arg_events && s->tpending.empty() && s->pending.size() <= S2R_ARG_MAX_EVENTS;
+    if (arg_events)
+        for (const S2rVoiceEvent &e : s->pending) if (e.seed != 0u) { arg_events = false; break; }
     EventSlot *timed_slot = nullptr;
     const S2rTimedEvent *tev_dev = nullptr;
-    if (!one_launch) {
+    if (!arg_events) {
         int rc = flush_events(s, stream, &timed_slot, &tev_dev);
         if (rc != S2R_OK) return rc;
     }
@@ -350,45 +383,32 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
         S2R_HIP(s, hipStreamSynchronize(stream));
         s->bank_dirty = false; s->bank_rate = sample_rate;
     }
-    const uint32_t vecs_needed = (s->bank[0].lpf_kind != S2R_FILT_ONEPOLE ? 3u : 1u) + (s->bank[0].mod_env_to_osc_freq != 0.0f ? 2u : 0u);
-    if (stream_wanted(s, frames) && s->coeff_vecs < vecs_needed) {
-        // first streamed fill of a patch that needs more per frame than the one-pole's coefficient: three filter
-        // coefficients for the dsp_filters.rs kinds / the SVF, the period and its reciprocal under oscillator FM
-        S2R_HIP(s, hipStreamSynchronize(stream));
-        S2R_HIP(s, hipStreamSynchronize(s->stream));
-        S2R_HIP(s, hipFree(s->coeff)); s->coeff = nullptr;
-        S2R_HIP(s, hipMalloc((void **)&s->coeff, (size_t)vecs_needed * s->coeff_capacity * s->cfg.max_frames * 64 * sizeof(float)));
-        s->coeff_vecs = vecs_needed;
+    static thread_local S2rRenderArgs a;             // 4 KiB of kernel arguments, copied by the launch
+    S2rRenderParams &p = a.p;
+    p = make_params(s, frames, sample_rate);
+    {
+        int rc = ensure_tables(s, p, sample_rate, stream);
+        if (rc != S2R_OK) return rc;
     }
-    S2rRenderParams p = make_params(s, frames, sample_rate);
+    if (tables_wanted(s)) p.tab = s->tab;
     p.per_voice = per_voice_dev;
     p.tev = tev_dev;
     p.voice_ev_head = s->voice_ev_head;
-    if (one_launch) {
-        static thread_local S2rPrepParams a;         // 4 KiB of kernel arguments, copied by the launch
-        a.p = p;
-        a.p.use_coeff = 1;
+    a.n_events = 0;
+    if (arg_events) {
         a.n_events = (uint32_t)s->pending.size();
         for (uint32_t i = 0; i < a.n_events; i++) {
             const S2rVoiceEvent &e = s->pending[i];
             a.ev[3u * i] = e.voice; a.ev[3u * i + 1u] = e.flags; a.ev[3u * i + 2u] = s2r_f2u(e.pitch);
         }
-        S2R_HIP(s, s2r_launch_prep(a, stream));
-        s->coeff_parity ^= 1u;
-        p.use_coeff = 1;
         for (const S2rVoiceEvent &e : s->pending) s->pending_slot[e.voice] = -1;
         s->pending.clear();
-    } else if (p.use_coeff && frames >= 16) {
-        S2R_HIP(s, s2r_launch_coeff(p, stream));
-        s->coeff_parity ^= 1u;
-    } else {
-        p.use_coeff = 0;       // nothing was prepared for this fill
     }
     // a shard of one workgroup needs no mix launch: its only partial row, root-added, is the output
     const bool direct = dev_out != nullptr && root_add && s->n_blocks == 1;
     if (direct) { p.direct_out = dev_out; p.direct_stereo = stereo ? 1 : 0; }
     if (s->timing) S2R_HIP(s, hipEventRecord(s->t0, stream));      // brackets the render kernel alone
-    S2R_HIP(s, s2r_launch_render(p, s->block_voices, s->lanes, stream));
+    S2R_HIP(s, s2r_launch_render(a, s->block_voices, stream));
     if (s->timing) { S2R_HIP(s, hipEventRecord(s->t1, stream)); s->timed = true; }
     if (timed_slot) {                     // the render kernel was the last reader of the slot's records
         S2R_HIP(s, hipEventRecord(timed_slot->done, stream));
@@ -448,10 +468,7 @@ void release_all(s2r_synth *s) {
     if (s->per_voice_dev) (void)hipFree(s->per_voice_dev);
     if (s->voice_ev_head) (void)hipFree(s->voice_ev_head);
     if (s->tev_copy) (void)hipFree(s->tev_copy);
-    if (s->group_slot) (void)hipFree(s->group_slot);
-    if (s->slot_group) (void)hipFree(s->slot_group);
-    if (s->coeff_count) (void)hipFree(s->coeff_count);
-    if (s->coeff) (void)hipFree(s->coeff);
+    if (s->tab_dev) (void)hipFree(s->tab_dev);
     if (s->t0) (void)hipEventDestroy(s->t0);
     if (s->t1) (void)hipEventDestroy(s->t1);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -516,18 +533,10 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
     s->n_blocks = (shard_voices + bv - 1) / bv;
     s->padded_voices = s->n_blocks * bv;
     s->mix_groups = cfg->mix_groups ? cfg->mix_groups : 1u;
-    {
-        // lanes per voice: one.  Spreading a voice over 2 or 4 lanes (more waves for small pools) was
-        // the faster shape before the 4-frame vectors and the branch-free runs, which exist for one lane
-        // per voice only; since then L = 1 wins at every pool size (1024 voices x 1024 frames: 0.064 ms
-        // against 0.175 ms at L = 4).  2 and 4 remain as a bit-identical knob.
-        uint32_t l = cfg->lanes_per_voice;
-        if (l == 0) l = 1u;
-        if ((l == 2 || l == 4) && !s2r_lane_variants_built()) l = 1u;   // same bits; those kernels are an opt-in of the build
-        while (l > 1 && (bv * l > 1024u || (l == 2 && bv > 256u))) l >>= 1;
-        if (l != 1 && l != 2 && l != 4) { delete s; return S2R_ERR_INVALID; }
-        s->lanes = l;
-    }
+    // lanes per voice: one.  (Round 1 also built kernels that spread a voice over 2 or 4 lanes; bit-identical and
+    // slower at every pool size once the branch-free runs existed, they are gone — 2 and 4 are accepted and mean 1.)
+    if (cfg->lanes_per_voice != 0 && cfg->lanes_per_voice != 1 && cfg->lanes_per_voice != 2 && cfg->lanes_per_voice != 4) { delete s; return S2R_ERR_INVALID; }
+    s->lanes = 1;
     s->bank.resize(1);
     s2r_default_patch(&s->bank[0]);
     s->pool.reset(new S2rVoicePool(cfg->total_voices));
@@ -580,21 +589,6 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
     CREATE_HIP(hipMalloc((void **)&s->voice_ev_head, pv * sizeof(int32_t)));
     CREATE_HIP(hipMalloc((void **)&s->tev_copy, (size_t)s->tev_capacity * sizeof(S2rTimedEvent)));
     CREATE_HIP(hipMemsetAsync(s->voice_ev_head, 0xff, pv * sizeof(int32_t), s->stream));
-    {
-        // coefficient stream: room for half of the 64-voice groups (beyond that the in-lane path is
-        // at least as good); [slot][max_frames/4][64] float4
-        const uint32_t n_groups64 = (shard_voices + 63u) / 64u;
-        s->coeff_capacity = n_groups64;          // a slot for every group: the stream never overflows
-        // one entry per 64 lanes of the PADDED voice range: the render kernel's padding waves look
-        // their (non-existent) group up too and must find -1
-        const size_t n_slots_padded = s->padded_voices / 64u + 1u;
-        CREATE_HIP(hipMalloc((void **)&s->group_slot, n_slots_padded * sizeof(int32_t)));
-        CREATE_HIP(hipMemsetAsync(s->group_slot, 0xff, n_slots_padded * sizeof(int32_t), s->stream));
-        CREATE_HIP(hipMalloc((void **)&s->slot_group, s->coeff_capacity * sizeof(uint32_t)));
-        CREATE_HIP(hipMalloc((void **)&s->coeff_count, 2 * sizeof(uint32_t)));
-        CREATE_HIP(hipMemsetAsync(s->coeff_count, 0, 2 * sizeof(uint32_t), s->stream));
-        CREATE_HIP(hipMalloc((void **)&s->coeff, (size_t)s->coeff_capacity * cfg->max_frames * 64 * sizeof(float)));
-    }
     CREATE_HIP(hipEventCreate(&s->t0));
     CREATE_HIP(hipEventCreate(&s->t1));
     {
@@ -622,7 +616,7 @@ int s2r_set_patch(s2r_synth *s, const s2r_patch *patch) {
     int rc = s2r_validate_patch(patch, &err);
     if (rc != S2R_OK) return set_err(s, rc, "%s", err.c_str());
     s->bank[0] = *patch;
-    s->bank_dirty = true;
+    s->bank_dirty = true; s->tab_dirty = true;
     return S2R_OK;
 }
 
@@ -636,7 +630,7 @@ int s2r_set_patch_bank(s2r_synth *s, const s2r_patch *patches, uint32_t n) {
     }
     s->bank.assign(patches, patches + n);
     if (s->program >= n) s->program = 0;
-    s->bank_dirty = true;
+    s->bank_dirty = true; s->tab_dirty = true;
     return S2R_OK;
 }
 
@@ -662,7 +656,7 @@ int s2r_load_patch(s2r_synth *s, const char *text, size_t len) {
     int rc = s2r_parse_patch(text ? text : "", len, &p, nullptr, &err);
     if (rc != S2R_OK) return set_err(s, rc, "%s", err.c_str());
     s->bank[0] = p;
-    s->bank_dirty = true;
+    s->bank_dirty = true; s->tab_dirty = true;
     return S2R_OK;
 }
 
@@ -945,9 +939,8 @@ int s2r_set_flat_shortcut(s2r_synth *s, int enabled) {
 
 int s2r_set_coeff_stream(s2r_synth *s, int enabled) {
     if (!s) return S2R_ERR_INVALID;
-    s->use_coeff = enabled != 0;
-    s->use_prep = enabled != 2 && enabled != 4;   // 2, 4: coefficient stream through the separate kernels only
-    s->force_stream = enabled >= 3;               // 3, 4: also for short fills and small shards (tests)
+    s->use_tab = enabled != 0;                    // 0: coefficients in-lane; else from the patch's tables
+    s->use_arg_events = enabled != 2 && enabled != 4;   // 2, 4: note events through their own launch, never in the kernel arguments
     return S2R_OK;
 }
 

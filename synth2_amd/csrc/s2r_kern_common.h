@@ -1,0 +1,768 @@
+// s2r_kern_common.h — device code shared by the gfx950 render kernels (one translation unit per oscillator kind, so
+// that they compile in parallel: synth2_amd/build.py).  Included inside each .hip file; everything here is
+// file-local.
+//
+// One voice per lane.  Per-voice recurrence state (phase, LPF history, frame offset) is loaded coalesced from the SoA
+// arrays in HBM into registers, the frames of the fill are walked serially (phase accumulation and the one-pole LPF
+// are recurrences over time), and the cross-voice mixdown is an LDS transpose-and-add per wave (16 voices in index
+// order, the reference's own order) -> LDS across the waves of a workgroup -> one partial row per workgroup in HBM ->
+// the rows added in a fixed order.  No MFMA: this is a scalar-per-voice recurrence.
+//
+// Everything arithmetic follows the reference op for op (citations relative to
+// /root/reference/components/s2_lib/src/); compile with -ffp-contract=off and without fast-math.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include "s2r_device.h"
+#include "s2r_math.h"
+
+namespace {
+
+__constant__ uint64_t c_exp2f_table[S2R_EXP2F_N] = S2R_EXP2F_TABLE_INIT;
+
+constexpr int kChunk = 16;         // the reference's x16 chunk (synth.rs:158, process.rs:25)
+constexpr uint32_t kSuperMax = 256; // frames between two cross-wave combines: 256 (small workgroups) or 64
+constexpr int kP = 4;              // frames whose closed-form work one lane carries at once (ILP)
+
+// The closed-form part of kP = 4 consecutive frames is evaluated together on 4-wide vectors.
+// Measured on MI355X (tools/ubench/issue_rates.hip): a SIMD retires one DEPENDENT VALU op per
+// ~4.4 cycles however many waves it holds, but ~2.2-2.8 cycles per op once each wave offers two
+// to four independent instructions — so the parallelism has to come from inside the wave.
+// Element-wise vector code is exactly that (and the add/mul/fma halves become v_pk_*_f32).
+// Each lane of every vector op is the same IEEE operation as the scalar code in s2r_math.h.
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef int i4 __attribute__((ext_vector_type(4)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long ul4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f4 vfma(f4 a, f4 b, f4 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ d4 vfma(d4 a, d4 b, d4 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f4 splat(float x) { return (f4)(x); }
+
+// s2r_pow2_sleef_core (s2r_math.h) on four lanes
+__device__ __forceinline__ f4 pow2_sleef_core4(f4 y) {
+    const f4 Lh = splat(0.69314718246459960938f), Ll = splat(-1.904654323148236017e-09f);
+    const f4 dx = Lh * y;
+    const f4 dy = vfma(Ll, y, vfma(Lh, y, -dx));
+    const f4 R_LN2f = splat(1.442695040888963407359924681001892137426645954152985934135449406931f);
+    const f4 L2Uf = splat(0.693145751953125f), L2Lf = splat(1.428606765330187045e-06f);
+    f4 u = (dx + dy) * R_LN2f;
+    const f4 qf = __builtin_elementwise_rint(u);
+    const i4 q = __builtin_convertvector(qf, i4);
+    f4 a = qf * -L2Uf;
+    f4 sx = dx + a, v = sx - dx;
+    f4 sy = ((dx - (sx - v)) + (a - v)) + dy;
+    a = qf * -L2Lf;
+    f4 tx = sx + a; v = tx - sx;
+    f4 ty = ((sx - (tx - v)) + (a - v)) + sy;
+    sx = tx + ty; sy = (tx - sx) + ty;
+    u = splat(0.00136324646882712841033936f);
+    u = vfma(u, sx, splat(0.00836596917361021041870117f));
+    u = vfma(u, sx, splat(0.0416710823774337768554688f));
+    u = vfma(u, sx, splat(0.166665524244308471679688f));
+    u = vfma(u, sx, splat(0.499999850988388061523438f));
+    const f4 wx = sx * sx;
+    const f4 wy = vfma(sx + sx, sy, vfma(sx, sx, -wx));
+    const f4 mx = wx * u;
+    const f4 my = vfma(wy, u, vfma(wx, u, -mx));
+    tx = sx + mx; v = tx - sx;
+    ty = ((sx - (tx - v)) + (mx - v)) + (sy + my);
+    const f4 ox = splat(1.0f) + tx;
+    const f4 oy = ((splat(1.0f) - ox) + tx) + ty;
+    u = ox + oy;
+    const i4 q1 = q >> 1, q2 = q - q1;
+    u = u * (f4)((u4)(q1 + 127) << 23) * (f4)((u4)(q2 + 127) << 23);
+    u = (dx < splat(-104.0f)) ? splat(0.0f) : u;
+    return (y == splat(0.0f)) ? splat(1.0f) : u;
+}
+
+// s2r_div_const_nocheck on four lanes
+__device__ __forceinline__ f4 div_const_nocheck4(f4 x, float c, float rc) {
+    const f4 q0 = x * splat(rc);
+    const f4 e = vfma(-q0, splat(c), x);
+    return vfma(e, splat(rc), q0);
+}
+
+// s2r_expf on four lanes: the four LDS table reads are independent and issued together
+__device__ __forceinline__ f4 expf4(f4 x, const uint64_t *T) {
+    const d4 xd = __builtin_convertvector(x, d4);
+    const d4 InvLn2N = (d4)(0x1.71547652b82fep+0 * S2R_EXP2F_N);
+    const d4 Shift = (d4)(0x1.8p+52);
+    const d4 C0 = (d4)(0x1.c6af84b912394p-5 / S2R_EXP2F_N / S2R_EXP2F_N / S2R_EXP2F_N);
+    const d4 C1 = (d4)(0x1.ebfce50fac4f3p-3 / S2R_EXP2F_N / S2R_EXP2F_N);
+    const d4 C2 = (d4)(0x1.62e42ff0c52d6p-1 / S2R_EXP2F_N);
+    const d4 z0 = InvLn2N * xd;
+    d4 kd = z0 + Shift;
+    const ul4 ki = (ul4)kd;
+    kd = kd - Shift;
+    const d4 r = vfma(InvLn2N, xd, -kd);
+    ul4 t;
+    t.x = T[ki.x % S2R_EXP2F_N]; t.y = T[ki.y % S2R_EXP2F_N];
+    t.z = T[ki.z % S2R_EXP2F_N]; t.w = T[ki.w % S2R_EXP2F_N];
+    t += ki << (52 - 5);
+    const d4 s = (d4)t;
+    const d4 z = vfma(C0, r, C1);
+    const d4 r2 = r * r;
+    d4 y = vfma(C2, r, (d4)(1.0));
+    y = vfma(z, r2, y);
+    y = y * s;
+    f4 res = __builtin_convertvector(y, f4);
+    // |x| >= 88 or NaN in any lane: redo those lanes with the scalar routine (rare)
+    const u4 abstop = (((u4)x) >> 20) & 0x7ffu;
+    const i4 special = abstop >= 0x42bu;
+    if (__builtin_expect((special.x | special.y | special.z | special.w) != 0, 0)) {
+        if (special.x) res.x = s2r_expf(x.x, T);
+        if (special.y) res.y = s2r_expf(x.y, T);
+        if (special.z) res.z = s2r_expf(x.z, T);
+        if (special.w) res.w = s2r_expf(x.w, T);
+    }
+    return res;
+}
+
+// ---------------------------------------------------------------------------------------
+// per-voice registers
+// ---------------------------------------------------------------------------------------
+struct VoiceRegs {
+    float pitch;
+    uint32_t offset;          // current_frame_offset at the start of the fill
+    uint32_t release_u;
+    bool released;
+    float phase;              // OscillatorState.phase_accum (None == 0.0)
+    float last;               // LowPassFilterState.last
+    uint32_t seed_rot;        // rotl(seed, 5), hashnoise.rs:61-63
+    // x16 ADSR per-voice constants (simdtest.rs:283-286)
+    float ro_a, end_a, ro_m, end_m;
+};
+
+// The x16 ADSR (old/simdtest.rs:270-331) is a cascade of four `t < threshold` tests selecting one
+// of five expressions.  A stage, once entered, lasts until t reaches its end threshold: keep the
+// ACTIVE stage's line  slope * (t - base) + y0  and that threshold in registers and re-run the
+// cascade only when t reaches it.  (t only grows within a fill; thresholds never precede the
+// stage they end, so "t < thr of the stage found at an earlier t" implies the same stage now.)
+// The value produced is the reference's selected expression, operation for operation.
+struct EnvRun {
+    float slope, base, y0, thr;
+    int stage;      // 0 attack, 1 decay, 2 sustain, 3 release, 4 end
+};
+
+// the cascade of simdtest.rs:288-292 for one frame offset t, from scratch: the first stage whose
+// `t < threshold` test holds (0 attack, 1 decay, 2 sustain, 3 release, 4 end), returned as that
+// stage's line and end threshold.  Straight-line selects only, so everything stays in registers.
+__device__ __forceinline__ EnvRun env_stage_at(const S2rEnv &e, float ro, float end, float t) {
+    const bool s0 = t < e.A;
+    const bool s1 = !s0 && t < e.sus_off;
+    const bool s2 = !s0 && !s1 && t < ro;
+    const bool s3 = !s0 && !s1 && !s2 && t < end;
+    EnvRun s;
+    //  0: (1/A) * t + 0        1: ((S-1)/D) * (t-A) + 1     2: S  (0*t + S == S)
+    //  3: (-S/R) * (t-ro) + S  4: 0
+    s.slope = s0 ? e.slope_att : s1 ? e.slope_dec : s3 ? e.slope_rel : 0.0f;
+    s.base  = s1 ? e.A : s3 ? ro : 0.0f;
+    s.y0    = s1 ? 1.0f : (s2 || s3) ? e.S : 0.0f;
+    s.thr   = s0 ? e.A : s1 ? e.sus_off : s2 ? ro : s3 ? end : __builtin_inff();
+    s.stage = s0 ? 0 : s1 ? 1 : s2 ? 2 : s3 ? 3 : 4;
+    return s;
+}
+
+__device__ __forceinline__ float env_value(const EnvRun &s, float t) {
+    return s.slope * (t - s.base) + s.y0;       // mul then add, separately rounded (simdtest.rs:247-261)
+}
+
+// math.rs:11-19 with feature fma: slope = rise / run; slope.mul_add(x, y0)
+__device__ __forceinline__ float line_fma(float rise, float run, float x, float y0) {
+    return __builtin_fmaf(rise / run, x, y0);
+}
+
+// envelopes.rs:21-150 Adsr::sample (scalar tail path)
+__device__ __forceinline__ float adsr_scalar(const S2rEnv &e, float t, float release_offset) {
+    const float decay_offset = e.A, sustain_offset = e.sus_off;
+    const float end_offset = release_offset + e.R;
+    const bool in_release = t >= release_offset && t < end_offset;
+    const bool in_end = t >= end_offset;
+    const bool in_attack = !in_release && !in_end && t < decay_offset;
+    const bool in_decay = !in_release && !in_end && !in_attack && t < sustain_offset;
+    const bool in_sustain = !in_release && !in_end && !in_attack && !in_decay && t < release_offset;
+    float rss;                                                         // release_start_sample, :57-93
+    if (release_offset < decay_offset) rss = line_fma(1.0f, e.A, release_offset, 0.0f);
+    else if (release_offset < sustain_offset) rss = line_fma(e.S - 1.0f, e.D, release_offset - decay_offset, 1.0f);
+    else rss = e.S;
+    if (in_attack) return line_fma(1.0f, e.A, t, 0.0f);
+    if (in_decay) return line_fma(e.S - 1.0f, e.D, t - decay_offset, 1.0f);
+    if (in_sustain) return e.S;
+    if (in_release) return line_fma(-rss, e.R, t - release_offset, rss);
+    return 0.0f;
+}
+
+// hashnoise.rs:33-51 (x16) == :14-27 (scalar): stateless noise at one frame offset
+__device__ __forceinline__ float hash_noise(uint32_t seed_rot, float t) {
+    const uint32_t off = s2r_f32_as_u32(t);                     // offset.cast::<u32>()
+    // hash_word_x16, :57-68, then cast::<u16>(): the low 16 bits of (seed_rot ^ off) * 0x9e3779b9
+    // depend only on the low 16 bits of both factors
+    const uint16_t h = (uint16_t)((uint16_t)(seed_rot ^ off) * (uint16_t)0x79b9u);
+    const float value = (float)h;                               // cast::<f32>()
+    const float q = s2r_div_u16_by_65535(value);                // value / u16_max, correctly rounded
+    return __builtin_fmaf(q, 2.0f, -1.0f);                      // (q * 2) is exact, then - 1
+}
+
+// Per-frame oscillator constants.  With mod_env_to_osc_freq == 0 they never change and live
+// in VoiceRegs; with FM they are part of the frame's closed-form work.
+struct OscK {
+    float period, inv_period;
+    float a, b, c;      // SAW: a = -2/period | SQUARE: a = period/2 | TRIANGLE: a = period/2, b = -2/a, c = 2/a
+};
+
+template <int OSC>
+__device__ __forceinline__ OscK make_osck(float period) {
+    OscK k;
+    k.period = period;
+    // One division: RN(c / period) for c = -2, -4, 4 is c/1 times RN(1 / period) exactly (a power of two commutes
+    // with rounding), and period / 2 is exact, so -2 / (period / 2) == RN(-4 / period).
+    k.inv_period = 1.0f / period;                                // oscillators.rs:378
+    k.a = k.b = k.c = 0.0f;
+    if (OSC == S2R_OSC_SAW) k.a = -2.0f * k.inv_period;          // -2.0 / period                  oscillators.rs:107-112
+    if (OSC == S2R_OSC_SQUARE) k.a = period * 0.5f;              // period / 2.0                   :68-69
+    if (OSC == S2R_OSC_TRIANGLE) { k.a = period * 0.5f; k.b = -4.0f * k.inv_period; k.c = 4.0f * k.inv_period; }   // -2.0 / half, 2.0 / half   :156-172
+    return k;
+}
+
+// SIN_TABLE in LDS as pairs: entry i2 holds (SIN_TABLE[(i2 - 1) mod 1024], SIN_TABLE[i2]), so the two
+// neighbours a lookup interpolates between (lookup.rs:64-72: i1 and i2 = (i1 + 1) mod 1024) come with one read
+__device__ __forceinline__ float2 sin_pair(const float *sSin, uint32_t i2) {
+    return *reinterpret_cast<const float2 *>(sSin + 2u * i2);
+}
+
+// oscillators.rs basic::{Square,Saw,Triangle,Table}Oscillator[X16]::sample given the phased offset
+template <int OSC>
+__device__ __forceinline__ float osc_value(const OscK &k, float off, const float *sSin) {
+    // offset % period: `off` itself while 0 <= off < period (one unsigned compare on the bit
+    // patterns, see s2r_fmod_period); the exact library fmodf only if some lane of the wave needs it
+    float x = off;
+    const bool slow = !(s2r_f2u(off) < s2r_f2u(k.period) && k.period > 0.0f);
+    if (__builtin_expect(__ballot(slow) != 0ull, 0)) { if (slow) x = ::fmodf(off, k.period); }
+    if (OSC == S2R_OSC_SAW) {
+        return __builtin_fmaf(k.a, x, 1.0f);
+    } else if (OSC == S2R_OSC_SQUARE) {
+        return x < k.a ? 1.0f : -1.0f;
+    } else if (OSC == S2R_OSC_TRIANGLE) {
+        const float first = __builtin_fmaf(k.b, x, 1.0f);
+        const float second = __builtin_fmaf(k.c, x - k.a, -1.0f);
+        return x < k.a ? first : second;
+    } else {
+        // lookup.rs:46-85 table_lookup_exclusive_x16 on SIN_TABLE (len 1024)
+        const float tv = x * 1024.0f / k.period;                // :63
+        const uint32_t i1 = s2r_f32_as_u32(tv);                 // :64
+        const uint32_t i2 = (i1 + 1u) & 1023u;                  // :67  (% 1024, wrapping add)
+        const float2 pr = sin_pair(sSin, i2);                   // one 8-byte LDS read: SIN_TABLE[i2 - 1], SIN_TABLE[i2]
+        const float s1 = i1 < 1024u ? pr.x : 0.0f;              // :72 gather_or_default
+        const float s2 = pr.y;
+        return __builtin_fmaf((s2 - s1) / 1.0f, tv - (float)i1, s1);   // :75-84
+    }
+}
+
+// OSC == S2R_OSC_ANY: the oscillator kind is a per-lane run-time value (patch banks)
+constexpr int S2R_OSC_ANY = 4;
+
+template <int OSC>
+__device__ __forceinline__ OscK make_osck_any(int kind, float period) {
+    if (OSC != S2R_OSC_ANY) return make_osck<OSC>(period);
+    OscK k;
+    k.period = period;
+    k.inv_period = 1.0f / period;
+    k.a = k.b = k.c = 0.0f;
+    if (kind == S2R_OSC_SAW) k.a = -2.0f * k.inv_period;
+    if (kind == S2R_OSC_SQUARE || kind == S2R_OSC_TRIANGLE) k.a = period * 0.5f;
+    if (kind == S2R_OSC_TRIANGLE) { k.b = -4.0f * k.inv_period; k.c = 4.0f * k.inv_period; }
+    return k;
+}
+
+template <int OSC>
+__device__ __forceinline__ float osc_value_any(int kind, const OscK &k, float off, const float *sSin) {
+    if (OSC != S2R_OSC_ANY) return osc_value<(OSC == S2R_OSC_ANY ? 0 : OSC)>(k, off, sSin);
+    if (kind == S2R_OSC_SAW) return osc_value<S2R_OSC_SAW>(k, off, sSin);
+    if (kind == S2R_OSC_SQUARE) return osc_value<S2R_OSC_SQUARE>(k, off, sSin);
+    if (kind == S2R_OSC_TRIANGLE) return osc_value<S2R_OSC_TRIANGLE>(k, off, sSin);
+    return osc_value<S2R_OSC_SINE>(k, off, sSin);
+}
+
+// filters.rs:20-21: x = exp(-2 pi f / sr)
+template <bool FASTDIV, class P = S2rRenderParams>
+__device__ __forceinline__ float lpf_arg(const P &p, float f_lpf) {
+    const float num = (-2.0f * 3.14159274101257324f) * f_lpf;   // -2.0 * pi * freq
+    return FASTDIV ? s2r_div_const_nocheck(num, p.sr, p.rcp_sr) : (num / p.sr);
+}
+template <bool FASTDIV, class P = S2rRenderParams>
+__device__ __forceinline__ float lpf_coeff(const P &p, float f_lpf, const uint64_t *sT) {
+    return s2r_expf(lpf_arg<FASTDIV, P>(p, f_lpf), sT);
+}
+
+// filters.rs:23-33: out = a0.mul_add(input, -b1 * last) with a0 = 1 - x, b1 = -x
+__device__ __forceinline__ float lpf_apply(float x, float in, float &last) {
+    const float a0 = 1.0f - x;
+    const float out = __builtin_fmaf(a0, in, x * last);
+    last = out;
+    return out;
+}
+
+// The part of a frame that is closed-form in the frame offset (no recurrence): envelopes,
+// filter coefficient, noise (+ the oscillator constants under FM).  process.rs:137-174 and
+// the noise/LPF-coefficient halves of process.rs:306-379.  One scalar frame:
+struct FrameCF {
+    float amp;       // amp envelope                         process.rs:144
+    float xc;        // exp(-2 pi f_lpf / sr)                filters.rs:21
+    float nz;        // noise(offset) + noise level          process.rs:347-356 (ADD)
+};
+// ... and kP = 4 consecutive frames at once:
+struct FrameCF4 { f4 amp, xc, nz; };
+struct OscK4 { f4 period, inv_period, a, b, c; };
+
+template <int OSC>
+__device__ __forceinline__ OscK4 make_osck4(f4 period) {
+    OscK4 k;
+    k.period = period;
+    k.inv_period = splat(1.0f) / period;                         // oscillators.rs:378 (the one division, see make_osck)
+    k.a = k.b = k.c = splat(0.0f);
+    if (OSC == S2R_OSC_SAW) k.a = splat(-2.0f) * k.inv_period;   // oscillators.rs:107-112
+    if (OSC == S2R_OSC_SQUARE) k.a = period * splat(0.5f);       // :68-69
+    if (OSC == S2R_OSC_TRIANGLE) { k.a = period * splat(0.5f); k.b = splat(-4.0f) * k.inv_period; k.c = splat(4.0f) * k.inv_period; }
+    return k;
+}
+
+// s2r_div_u16_by_65535 on four lanes
+__device__ __forceinline__ f4 div_u16_by_65535_4(f4 value) {
+    return vfma(value, splat(0x1.0001p-32f), value * splat(0x1p-16f));
+}
+
+// hashnoise.rs:33-51 on four offsets
+__device__ __forceinline__ f4 hash_noise4(uint32_t seed_rot, f4 t) {
+    u4 off;
+    off.x = s2r_f32_as_u32(t.x); off.y = s2r_f32_as_u32(t.y); off.z = s2r_f32_as_u32(t.z); off.w = s2r_f32_as_u32(t.w);
+    // only the low 16 bits of the product are used (cast::<u16>()), and they depend only on the low
+    // 16 bits of the factors: a full-rate 16-bit multiply instead of the quarter-rate 32-bit one
+    const us4 h = __builtin_convertvector(off ^ seed_rot, us4) * (unsigned short)0x79b9u;
+    const f4 value = __builtin_convertvector(h, f4);
+    return vfma(div_u16_by_65535_4(value), splat(2.0f), splat(-1.0f));
+}
+
+// The same for four offsets below 2^24, given as the low 16 bits of two pairs of them: there (offset as f32) as u32
+// is the offset itself (hashnoise.rs:37 casts a value that is exact), and the hash's low 16 bits need only the low
+// 16 bits of offset and seed.  Two frames per 32-bit register: one xor and one packed 16-bit multiply per pair, no
+// conversions of the offset.  `seed_pair` holds the low half of rotl(seed, 5) in both halves.
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b));
+}
+__device__ __forceinline__ f4 hash_noise4_low16(uint32_t seed_pair, uint32_t off01, uint32_t off23) {
+    const us2 h01 = __builtin_bit_cast(us2, off01 ^ seed_pair) * (unsigned short)0x79b9u;
+    const us2 h23 = __builtin_bit_cast(us2, off23 ^ seed_pair) * (unsigned short)0x79b9u;
+    const f4 value = {(float)h01.x, (float)h01.y, (float)h23.x, (float)h23.y};
+    return vfma(div_u16_by_65535_4(value), splat(2.0f), splat(-1.0f));
+}
+
+// While the mod envelope sits in a stage whose slope is zero (sustain, end, or a degenerate
+// decay/release) its value is the constant y0, so everything derived from it alone — the LPF
+// coefficient exp(-2 pi f / sr) and, under FM, the oscillator period constants — is the same
+// number frame after frame.  It is computed once when the stage is entered (scalar routines,
+// bit-identical to the vector ones) and reused while EVERY voice of the wave is in such a stage.
+struct FlatCache {
+    float xc;
+    OscK k;
+};
+
+template <int OSC, bool FM>
+__device__ __forceinline__ FlatCache refresh_flat(const S2rRenderParams &p, const VoiceRegs &r, const EnvRun em,
+                                                  const uint64_t *sT, FlatCache fc) {
+    if (em.slope == 0.0f) {
+        const float mod = em.y0;                                          // 0 * (t - base) + y0 == y0
+        const float f_lpf = s2r_pow2_sleef_core(mod * p.amt_lpf) * p.lpf_freq;
+        fc.xc = s2r_expf(p.fast_div_sr ? lpf_arg<true>(p, f_lpf) : lpf_arg<false>(p, f_lpf), sT);
+        if (FM) fc.k = make_osck<OSC>(p.sr / (s2r_pow2_sleef_core(mod * p.amt_osc) * r.pitch));
+    }
+    return fc;
+}
+
+// frames oi .. oi+3 of one voice
+template <int OSC, bool FM>
+__device__ __forceinline__ void closed_form_x4(const S2rRenderParams &p, const VoiceRegs &r, EnvRun &ea, EnvRun &em,
+                                               float &thr_min, FlatCache &fc, uint32_t oi, const uint64_t *sT,
+                                               FrameCF4 &cf, OscK4 &k) {
+    const u4 ou = (u4)(oi) + (u4){0u, 1u, 2u, 3u};               // offsets_x16: wrapping u32 add (process.rs:213-219)
+    const f4 t = __builtin_convertvector(ou, f4);                // offsets as f32 (simdtest.rs:277-279, process.rs:348)
+    // fast path first: the active stages' lines for all four frames
+    f4 amp = splat(ea.slope) * (t - splat(ea.base)) + splat(ea.y0);           // process.rs:144
+    f4 mod = splat(em.slope) * (t - splat(em.base)) + splat(em.y0);           // process.rs:145
+    bool moving = p.no_flat_shortcut != 0;
+    const bool cold = !(t.w < thr_min);
+    if (__builtin_expect(__ballot(cold) != 0ull, 0)) {      // wave-uniform branch: no exec juggling when nobody is cold
+        if (cold) {
+            // an envelope stage ends inside these four frames: walk them one by one
+            moving = true;
+#define S2R_ENV_STEP(C)                                                                   \
+            {                                                                             \
+                const float tj = t.C;                                                     \
+                if (!(tj < thr_min)) {                                                    \
+                    ea = env_stage_at(p.amp, r.ro_a, r.end_a, tj);                        \
+                    em = env_stage_at(p.mod, r.ro_m, r.end_m, tj);                        \
+                    thr_min = __builtin_fminf(ea.thr, em.thr);                            \
+                }                                                                         \
+                amp.C = env_value(ea, tj);                                                \
+                mod.C = env_value(em, tj);                                                \
+            }
+            S2R_ENV_STEP(x) S2R_ENV_STEP(y) S2R_ENV_STEP(z) S2R_ENV_STEP(w)
+#undef S2R_ENV_STEP
+            fc = refresh_flat<OSC, FM>(p, r, em, sT, fc);
+        }
+    }
+    cf.amp = amp;
+    cf.nz = hash_noise4(r.seed_rot, t) + splat(p.noise_level);   // process.rs:347-356 (ADD)
+    moving = moving || em.slope != 0.0f;
+    if (__ballot(moving) == 0ull) {
+        // every voice of this wave has a flat mod envelope over these four frames
+        cf.xc = splat(fc.xc);
+        if (FM) { k.period = splat(fc.k.period); k.inv_period = splat(fc.k.inv_period);
+                  k.a = splat(fc.k.a); k.b = splat(fc.k.b); k.c = splat(fc.k.c); }
+        return;
+    }
+    const f4 f_lpf = pow2_sleef_core4(mod * splat(p.amt_lpf)) * splat(p.lpf_freq);   // process.rs:148-152
+    const f4 num = splat(-2.0f * 3.14159274101257324f) * f_lpf;  // -2.0 * pi * freq   (filters.rs:21)
+    const f4 arg = p.fast_div_sr ? div_const_nocheck4(num, p.sr, p.rcp_sr) : (num / splat(p.sr));   // wave-uniform choice
+    cf.xc = expf4(arg, sT);
+    if (FM) {
+        const f4 f_osc = pow2_sleef_core4(mod * splat(p.amt_osc)) * splat(r.pitch);  // process.rs:146-147,231-250
+        k = make_osck4<OSC>(splat(p.sr) / f_osc);                // units.rs:32-42
+    }
+}
+
+// The recurrence step of a frame: phase accumulation, oscillator, LPF, gain.
+template <int OSC>
+__device__ __forceinline__ float recur_x16(const S2rRenderParams &p, VoiceRegs &r, const FrameCF &cf, const OscK &k,
+                                           const float *sSin) {
+    const float ph = r.phase;                                    // oscillators.rs:391-400
+    r.phase = s2r_fmod1(ph + k.inv_period);
+    const float off = __builtin_fmaf(k.period, ph, 0.0f);        // phased_offset_x16, :235
+    const float osc = osc_value<OSC>(k, off, sSin);
+    const float s = (osc + p.osc_gain) + cf.nz;                  // process.rs:342-345 (ADD), :358
+    const float y = lpf_apply(cf.xc, s, r.last);                 // process.rs:363-371
+    return y * cf.amp;                                           // process.rs:373-376
+}
+
+// dsp_filters.rs:12-17,82-89: the delayed inputs / outputs of the first- and second-order filters
+struct Filt2 { float x1, x2, y1, y2; };
+
+// dsp_filters.rs:25-45 (LP1), :60-80 (HP1), :99-130 (LP2), :149-180 (HP2), :199-230 (BP2): one step at cutoff f.
+// That file has no `fma` switch: every operation is rounded separately, in Rust's evaluation
+// order; sin/cos are the libm routines (s2r_sinf/s2r_cosf, bit-exact for every finite theta).
+struct FiltCoef { float alpha, beta, gamma, k; };
+
+__device__ __forceinline__ FiltCoef dsp_filter_coef(int kind, float damping, float sr, float cutoff) {
+    const float theta = 2.0f * 3.14159274101257324f * cutoff / sr;           // 2.0 * PI * cutoff_freq / sample_rate
+    FiltCoef c;
+    c.k = 0.0f;
+    if (kind >= S2R_FILT_SVF_LP) {
+        // build-defined trapezoidal SVF (oracle/s2_oracle.c s2o_dsp_filter_process):
+        // alpha, beta, gamma hold a1, a2, a3; damping == q
+        const float fcl = __builtin_fminf(cutoff, 0.49f * sr);  // below Nyquist: g > 0, unconditionally stable
+        const float g = s2r_tanf(3.14159274101257324f * fcl / sr);
+        c.k = 1.0f / damping;
+        c.alpha = 1.0f / (1.0f + g * (g + c.k));
+        c.beta = g * c.alpha;
+        c.gamma = g * c.beta;
+        return c;
+    }
+    const float cs = s2r_cosf(theta);
+    if (kind == S2R_FILT_BP2) {                                  // dsp_filters.rs:204-209; damping == quality_factor
+        const float tq = s2r_tanf(theta / (2.0f * damping));
+        c.beta = 0.5f * ((1.0f - tq) / (1.0f + tq));
+        c.gamma = (0.5f + c.beta) * cs;
+        c.alpha = (0.5f - c.beta) / 2.0f;
+        return c;
+    }
+    const float sn = s2r_sinf(theta);
+    if (kind == S2R_FILT_LP1 || kind == S2R_FILT_HP1) {
+        c.beta = 0.0f;
+        c.gamma = cs / (1.0f + sn);
+        c.alpha = (kind == S2R_FILT_LP1) ? (1.0f - c.gamma) / 2.0f : (1.0f + c.gamma) / 2.0f;
+        return c;
+    }
+    const float hd = damping / 2.0f;
+    c.beta = 0.5f * ((1.0f - hd * sn) / (1.0f + hd * sn));
+    c.gamma = (0.5f + c.beta) * cs;
+    c.alpha = (kind == S2R_FILT_LP2) ? (0.5f + c.beta - c.gamma) / 4.0f : (0.5f + c.beta + c.gamma) / 4.0f;
+    return c;
+}
+
+__device__ __forceinline__ float dsp_filter_apply(int kind, const FiltCoef &c, float x, Filt2 &f) {
+    float y;
+    if (kind >= S2R_FILT_SVF_LP) {                               // x1, x2: the two integrator states
+        const float v3 = x - f.x2;
+        const float v1 = c.alpha * f.x1 + c.beta * v3;
+        const float v2 = f.x2 + c.beta * f.x1 + c.gamma * v3;
+        f.x1 = 2.0f * v1 - f.x1;
+        f.x2 = 2.0f * v2 - f.x2;
+        return kind == S2R_FILT_SVF_LP ? v2 : kind == S2R_FILT_SVF_BP ? v1 : x - c.k * v1 - v2;
+    }
+    if (kind == S2R_FILT_LP1 || kind == S2R_FILT_HP1) {
+        const float xs = (kind == S2R_FILT_LP1) ? x + f.x1 : x - f.x1;
+        y = c.alpha * xs + c.gamma * f.y1;
+        f.x1 = x; f.y1 = y;
+        return y;
+    }
+    const float px1 = f.x1, px2 = f.x2, py1 = f.y1, py2 = f.y2;
+    const float xs = (kind == S2R_FILT_LP2) ? (x + 2.0f * px1 + px2)
+                   : (kind == S2R_FILT_HP2) ? (x - 2.0f * px1 + px2) : (x - px2);         // BP2: dsp_filters.rs:217-221
+    y = 2.0f * (c.alpha * xs + c.gamma * py1 - c.beta * py2);
+    f.x2 = px1; f.x1 = x; f.y2 = py1; f.y1 = y;
+    return y;
+}
+
+__device__ __forceinline__ float dsp_filter_step(int kind, float damping, float sr, float cutoff, float x, Filt2 &f) {
+    const FiltCoef c = dsp_filter_coef(kind, damping, sr, cutoff);
+    return dsp_filter_apply(kind, c, x, f);
+}
+
+// One frame of process_layer (scalar "sisd" path: process.rs:101-135,252-304).  DSPF: the layer's
+// filter is one of dsp_filters.rs (state in *f2) instead of the one-pole of filters.rs.
+template <int OSC, bool DSPF = false, class P = S2rRenderParams>
+__device__ __forceinline__ float frame_sisd(const P &p, VoiceRegs &r, uint32_t oi,
+                            const uint64_t *sT, const float *sSin, Filt2 *f2 = nullptr) {
+    const float t = (float)oi;
+    const float rel = r.released ? (float)r.release_u : 4294967296.0f;   // envelopes.rs:35
+    const float amp = adsr_scalar(p.amp, t, rel);
+    const float mod = adsr_scalar(p.mod, t, rel);
+    const float f_osc = s2r_pow2_libm(mod * p.amt_osc, sT) * r.pitch;    // process.rs:221-229
+    const float f_lpf = s2r_pow2_libm(mod * p.amt_lpf, sT) * p.lpf_freq;
+    const OscK k = make_osck_any<OSC>(p.osc_kind, p.sr / f_osc);
+    const float ph = r.phase;
+    const float off = __builtin_fmaf(k.period, ph, 0.0f);                // oscillators.rs:212
+    const float osc = osc_value_any<OSC>(p.osc_kind, k, off, sSin);
+    r.phase = s2r_fmod1(ph + k.inv_period);                              // oscillators.rs:377-381
+    const float osc_s = osc * p.osc_gain;                                // process.rs:287 (MULTIPLY)
+    const float noise_s = (hash_noise(r.seed_rot, t)) * p.noise_level;   // process.rs:292 (MULTIPLY)
+    const float s = osc_s + noise_s;
+    if (DSPF) return dsp_filter_step(p.lpf_kind, p.lpf_damping, p.sr, f_lpf, s, *f2) * amp;
+    const float x = lpf_coeff<false, P>(p, f_lpf, sT);
+    const float y = lpf_apply(x, s, r.last);
+    return y * amp;
+}
+
+
+// 16-byte load from a dword-aligned address (global_load_dwordx4 needs no more on gfx950)
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ f4 load_f4u(const float *p) { return *reinterpret_cast<const f4u *>(p); }
+
+// Where a lane's coefficients for frame offset `o` sit in the tables: entry idx + (o & mask) (S2rTabRef).  `stage` is
+// the mod envelope's active stage; a release that starts at the clamp attack + decay (simdtest.rs:283) is indexed by
+// the offset, a later one by the frames since the release.
+struct TabCur { int32_t idx; uint32_t mask; };
+__device__ __forceinline__ TabCur tab_cursor(const S2rTabRef &t, int stage, bool late_release, uint32_t release_u, bool live) {
+    TabCur c;
+    const bool moving = stage <= 1 || stage == 3;
+    c.mask = (live && moving) ? 0xffffffffu : 0u;
+    const int32_t rel = late_release ? t.ru - (int32_t)release_u : t.rc - (int32_t)t.rc_t0;
+    const int32_t idx = stage <= 1 ? t.ad : stage == 2 ? t.sus : stage == 3 ? rel : t.end;
+    c.idx = live ? idx : t.dead;
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------
+// The fill's note events when they ride in the kernel arguments (S2rRenderArgs): every wave looks at 64 records per
+// step, one per lane; the few that hit one of its 64 voices are handed to their lane, which rewrites its voice's
+// words in HBM — restart: *voice = Voice { .. } (synth.rs:63-69), release: release_frame_offset = current_frame_offset
+// (synth.rs:74-75) — before the kernel loads its state.  The host folds a fill's events to at most one record per
+// voice (s2r_host.cpp push_event), so no two lanes of the grid write the same voice.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void apply_arg_events(const S2rRenderArgs &a, uint32_t vi, uint32_t lane) {
+    const S2rRenderParams &p = a.p;
+    if (a.n_events == 0u) return;
+    const uint32_t group = __builtin_amdgcn_readfirstlane(vi >> 6);
+    uint32_t my_flags = 0u, my_pitch = 0u;
+    for (uint32_t k0 = 0; k0 < a.n_events; k0 += 64u) {          // wave-uniform
+        const uint32_t i = k0 + lane;
+        const bool have = i < a.n_events;
+        const uint32_t ev_voice = have ? a.ev[3u * i] : 0xffffffffu;
+        const uint32_t ev_flags = have ? a.ev[3u * i + 1u] : 0u;
+        const uint32_t ev_pitch = have ? a.ev[3u * i + 2u] : 0u;
+        uint64_t hits = __ballot(ev_voice != 0xffffffffu && (ev_voice >> 6) == group);
+        while (hits) {                                           // wave-uniform
+            const int src = __builtin_ctzll(hits);
+            hits &= hits - 1ull;
+            const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)ev_voice, src);
+            const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)ev_flags, src);
+            const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane((int)ev_pitch, src);
+            if ((v & 63u) == lane) { my_flags = f; my_pitch = pb; }
+        }
+    }
+    if (my_flags == 0u || vi >= p.n_voices) return;
+    if (my_flags & S2R_EV_RESTART) {
+        p.v.pitch[vi] = s2r_u2f(my_pitch);
+        p.v.offset[vi] = 0u;
+        p.v.release[vi] = 0u;                                    // a release right after the on is at offset 0
+        p.v.flags[vi] = S2R_VF_STARTED | ((my_flags & S2R_EV_RELEASE) ? S2R_VF_RELEASED : 0u);
+        p.v.phase[vi] = 0.0f;
+        p.v.lpf_last[vi] = 0.0f;
+        p.v.fx1[vi] = 0.0f; p.v.fx2[vi] = 0.0f; p.v.fy1[vi] = 0.0f; p.v.fy2[vi] = 0.0f;
+        p.v.seed[vi] = 0u;                                       // this path carries no seed overrides
+        p.v.program[vi] = my_flags >> S2R_EV_PROGRAM_SHIFT;
+    } else if (my_flags & S2R_EV_RELEASE) {
+        const uint32_t fl = p.v.flags[vi];
+        if ((fl & S2R_VF_STARTED) && !(fl & S2R_VF_RELEASED)) {
+            p.v.release[vi] = p.v.offset[vi];
+            p.v.flags[vi] = fl | S2R_VF_RELEASED;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------
+// The branch-free 16-frame chunk.  Measured (ablated builds): with the rare branches (envelope
+// stage change, fmodf slow path, coefficient-source selection) inside the per-quad loop the
+// SAME executed work takes almost twice as long — every one is a basic-block boundary the
+// scheduler cannot move work across, and a taken branch is an instruction-fetch bubble for the
+// single wave a SIMD holds.  So the decision is taken once per chunk, wave-uniformly, and the
+// common case runs this straight-line code: 4 quads, closed-form part on 4-vectors, then the
+// recurrence, all in one basic block.
+//   Preconditions (checked by the caller for the whole wave): no envelope threshold inside the
+//   chunk; period > 0 and 0 <= phase < 1 (then fmodf(period*phase, period) is `off` itself unless
+//   off == period, where it is +0); no oscillator FM.
+//   SRC: 0 = every voice flat (constant coefficient), 1 = coefficient tables (`tab`: this lane's entry for the chunk's
+//        first frame, S2rTabRef), 2 = compute in-lane.
+// ---------------------------------------------------------------------------------------
+//   FILT != 0 (general kernel, flat stages only): the layer's filter is dsp_filters.rs' / the SVF with the
+//   constant coefficients `fcoef`, state in *f2, instead of the one-pole.
+//   FMV (with SRC == 1, oscillator FM): the tables' last plane is pow(2, mod * mod_env_to_osc_freq); the period
+//   sr / (that * pitch) and its reciprocal are per-frame values (process.rs:146-147, units.rs:32-42, oscillators.rs:378).
+//   SMALL (one-pole kernel): every lane's offsets of the chunk are below 2^24, so the f32 offsets are exact sums and
+//   the noise hash works on their low 16 bits (hash_noise4_low16), and the patch's noise level is 0.0, so adding it
+//   (process.rs:353-356) changes nothing: the noise value itself is never +-0 (v / 65535 == 0.5 has no integer
+//   solution), and n + 0.0 == n for every other n.
+//   AFLAT (with SMALL): every started voice of the wave sits in an amplitude stage of slope +-0 (sustain, end) for
+//   the whole run, so slope * (t - base) + y0 is (+-0) + y0 with the product's sign fixed by the slope's (t >= base
+//   inside a stage): one evaluation per chunk, at its first frame, is every frame's value bit for bit.
+template <int OSC, int SRC, int FILT = 0, bool FMV = false, bool SMALL = false, bool AFLAT = false>
+__device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &r, const EnvRun &ea, const EnvRun &em,
+                                           const FlatCache &fc, const OscK &k, uint32_t o_chunk, const float *tab,
+                                           const uint64_t *sT, const float *sSin, bool live, float *tile_col,
+                                           uint32_t tile_stride, float *pv_dst,
+                                           const FiltCoef *fcoef = nullptr, Filt2 *f2 = nullptr) {
+    // table planes: the filter's coefficients (x and 1 - x for the one-pole, alpha / beta / gamma for the others), then
+    // under FM pow(2, mod * amt_osc).  Four 16-byte loads per plane (dword-aligned: the index follows the voice's
+    // offset), issued first and used last
+    f4 xq[4], bq[4], gq[4], pq[4], iq[4];
+    if (SRC == 1) {
+        const uint32_t plane = p.tab.plane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            xq[q] = load_f4u(tab + 4 * q);
+            bq[q] = load_f4u(tab + plane + 4 * q);               // one-pole: a0 = 1 - x
+            if (FILT != 0) gq[q] = load_f4u(tab + 2u * plane + 4 * q);
+            if (FMV) pq[q] = load_f4u(tab + p.tab.fm_plane * plane + 4 * q);
+        }
+    }
+    const double rcp_period = (OSC == S2R_OSC_SINE && !FMV) ? s2r_rcp_f64(k.period) : 0.0;   // constant over the run: hoisted by the compiler
+    // a lane without a started voice: see a0 / ampq below.  Its filter history must be 0 for that (frames
+    // of the general path, which selects per frame instead, leave a running value in it)
+    // — and its amplitude line is 0 * (t - 0) + 0 = +0 and, where the coefficient is the run's constant, x = 1
+    // (a0 = 1 - 1 = 0): selected once per chunk instead of per quad
+    // (selects, not a branch: control flow here would split the chunk's basic block)
+    r.last = live ? r.last : 0.0f;
+    const float ea_slope = live ? ea.slope : 0.0f, ea_base = live ? ea.base : 0.0f, ea_y0 = live ? ea.y0 : 0.0f;
+    const float xc0 = live ? fc.xc : 1.0f;
+    f4 amp[4], nz[4];
+    const float t_chunk = (float)o_chunk;
+    // SMALL: the low 16 bits of the chunk's first four offsets as two pairs, and of rotl(seed, 5) twice
+    const uint32_t o_lo = o_chunk & 0xffffu;
+    uint32_t o01 = pk_add_u16(o_lo | (o_lo << 16), 0x00010000u), o23 = pk_add_u16(o01, 0x00020002u);
+    const uint32_t seed_pair = (r.seed_rot & 0xffffu) | (r.seed_rot << 16);
+    f4 t_small = splat(t_chunk) + (f4){0.0f, 1.0f, 2.0f, 3.0f};      // exact below 2^24, as are the + 4 steps
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f4 t;
+        if (SMALL) {
+            // stepping (one inline constant, one scalar literal) instead of 4 q + k per quad (a scalar move per literal)
+            t = t_small;
+            nz[q] = hash_noise4_low16(seed_pair, o01, o23);
+            t_small = t_small + splat(4.0f);
+            o01 = pk_add_u16(o01, 0x00040004u); o23 = pk_add_u16(o23, 0x00040004u);
+        } else {
+            const u4 ou = (u4)(o_chunk + 4u * q) + (u4){0u, 1u, 2u, 3u};
+            t = __builtin_convertvector(ou, f4);
+            nz[q] = hash_noise4(r.seed_rot, t) + splat(p.noise_level);
+        }
+        if (AFLAT) amp[q] = splat(ea_slope * (t_chunk - ea_base) + ea_y0);
+        else amp[q] = splat(ea_slope) * (t - splat(ea_base)) + splat(ea_y0);
+        if (SRC == 0) xq[q] = splat(xc0);
+        if (SRC == 1 && FMV) {
+            const f4 f_osc = pq[q] * splat(r.pitch);             // pow(2, mod * amount) * freq   process.rs:146-147,231-250
+            pq[q] = splat(p.sr) / f_osc;                         // units.rs:32-42
+            iq[q] = splat(1.0f) / pq[q];                         // oscillators.rs:378
+        }
+        if (SRC == 2) {
+            const f4 mod = splat(em.slope) * (t - splat(em.base)) + splat(em.y0);
+            const f4 f_lpf = pow2_sleef_core4(mod * splat(p.amt_lpf)) * splat(p.lpf_freq);
+            const f4 num = splat(-2.0f * 3.14159274101257324f) * f_lpf;
+            const f4 arg = p.fast_div_sr ? div_const_nocheck4(num, p.sr, p.rcp_sr) : (num / splat(p.sr));
+            xq[q] = expf4(arg, sT);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        // filters.rs:23.  A lane without a started voice must put +0.0 into the mix (synth.rs:178 skips
+        // it): with a0 = 0 and last = 0 its y is 0*s + x*0 = +0 for every finite s and x >= 0, and
+        // (+0) * (amp = +0) = +0 — no select per frame
+        f4 a0 = (SRC == 1 && FILT == 0) ? bq[q] : splat(1.0f) - xq[q];   // (the tables carry 1 - x next to x)
+        const f4 ampq = amp[q];
+        if (SRC == 2 && !live) a0 = splat(0.0f);                 // SRC 1: such a lane reads the tables' x = 1, 1 - x = 0 entries
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // the frame's oscillator constants: the run's (k), or under FM this frame's period and 1/period (from the table's pow2 plane) with
+            // the rest by exact scalings (make_osck)
+            const float period = FMV ? pq[q][j] : k.period, inv_period = FMV ? iq[q][j] : k.inv_period;
+            const float ka = !FMV ? k.a : (OSC == S2R_OSC_SAW ? -2.0f * inv_period : period * 0.5f);
+            const float kb = !FMV ? k.b : -4.0f * inv_period, kc = !FMV ? k.c : 4.0f * inv_period;
+            const float ph = r.phase;
+            const float nx = ph + inv_period;                    // oscillators.rs:377-381; 0 <= nx < 2
+            // fmodf(nx, 1) for nx >= 0 is its fractional part, which is exact; v_fract_f32 returns
+            // min(nx - floor(nx), 0x1.fffffep-1) and the clamp cannot bind for nx < 2^23
+            r.phase = __builtin_amdgcn_fractf(nx);
+            const float off = period * ph;                       // fma(period, ph, +0) with a product >= +0
+            // fmodf(off, period) on [0, period] (off == period -> 0): both are non-negative floats, so
+            // bits(off) - bits(period) is negative exactly when off < period (the compiler turns this into an
+            // integer compare + select on an SGPR pair, cheaper here than the float compare through VCC)
+            const int32_t keep = ((int32_t)s2r_f2u(off) - (int32_t)s2r_f2u(period)) >> 31;
+            const float x = s2r_u2f(s2r_f2u(off) & (uint32_t)keep);
+            float osc;
+            if (OSC == S2R_OSC_SAW) osc = __builtin_fmaf(ka, x, 1.0f);
+            else if (OSC == S2R_OSC_SQUARE) osc = x < ka ? 1.0f : -1.0f;
+            else if (OSC == S2R_OSC_TRIANGLE) {
+                const float first = __builtin_fmaf(kb, x, 1.0f), second = __builtin_fmaf(kc, x - ka, -1.0f);
+                osc = x < ka ? first : second;
+            } else {
+                // x * 1024 / period: through the run's double reciprocal, exactly (s2r_math.h); a true division when
+                // the period changes every frame
+                const float tv = FMV ? x * 1024.0f / period : s2r_div_by_rcp64(x * 1024.0f, rcp_period);
+                const uint32_t i1 = s2r_f32_as_u32(tv), i2 = (i1 + 1u) & 1023u;
+                const float2 pr = sin_pair(sSin, i2);
+                const float s1 = i1 < 1024u ? pr.x : 0.0f, s2 = pr.y;
+                osc = __builtin_fmaf((s2 - s1) / 1.0f, tv - (float)i1, s1);
+            }
+            const float s = (osc + p.osc_gain) + nz[q][j];
+            float out;
+            if (FILT == 0) {
+                const float y = __builtin_fmaf(a0[j], s, xq[q][j] * r.last);
+                r.last = y;
+                out = y * ampq[j];
+            } else {
+                // (a dead lane's filter state may run away on its made-up input: select per frame here)
+                FiltCoef cj = *fcoef;                            // the run's constants, or this frame's from the tables
+                if (SRC == 1) { cj.alpha = xq[q][j]; cj.beta = bq[q][j]; cj.gamma = gq[q][j]; }
+                const float y = dsp_filter_apply(FILT, cj, s, *f2);
+                out = live ? y * amp[q][j] : 0.0f;
+            }
+            tile_col[(4 * q + j) * tile_stride] = out;
+            if (pv_dst) pv_dst[4 * q + j] = out;
+        }
+    }
+}
+
+}  // namespace

@@ -1,0 +1,3 @@
+// the one-pole render kernel for the triangle oscillator (static_config.rs:26-32); see s2r_render_onepole.inc
+#define S2R_TU_OSC 2
+#include "s2r_render_onepole.inc"

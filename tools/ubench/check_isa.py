@@ -14,7 +14,9 @@ obj = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "_build", "issue_
 MNEMONIC = {"fma": "v_fma_f32", "add": "v_add_f32", "mul": "v_mul_f32", "pkfma": "v_pk_fma_f32", "pkmul": "v_pk_mul_f32",
             "pkadd": "v_pk_add_f32", "fract": "v_fract_f32", "cvtu": "v_cvt_f32_u32", "xor": "v_xor_b32", "addu": "v_add_u32",
             "ashr": "v_ashrrev_i32", "mullo": "v_mul_lo_u32", "pkmullo16": "v_pk_mul_lo_u16", "pkaddu16": "v_pk_add_u16",
-            "cndmask": "v_cndmask_b32", "cmp": "v_cmp_lt_f32", "rcp": "v_rcp_f32", "fma64": "v_fma_f64", "readlane": "v_readlane_b32"}
+            "cndmask": "v_cndmask_b32", "cmp": "v_cmp_lt_f32", "rcp": "v_rcp_f32", "fma64": "v_fma_f64", "readlane": "v_readlane_b32", "max3": "v_max3_f32", "salu": "s_add_u32", "fma_salu": "s_add_u32",
+            "cmp_sor": "v_cmp_eq_f32", "cnd_sgpr": "v_cndmask_b32", "ldsw": "ds_write_b32", "fma_ldsw": "ds_write_b32",
+            "fma3_ldsw": "ds_write_b32", "fma_pkfma": "v_pk_fma_f32"}
 UNROLL = 16
 dis = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", obj], capture_output=True, text=True, check=True).stdout
 kern = None
@@ -29,7 +31,7 @@ for line in dis.splitlines():
         counts[kern][m.group(1)] += 1
 bad = 0
 for k in sorted(counts):
-    m = re.search(r"ub_(\w+?)_ilp(\d+)", k)
+    m = re.search(r"ub_(\w+)_ilp(\d+)", k)
     if not m:
         continue
     name, ilp = m.group(1), int(m.group(2))

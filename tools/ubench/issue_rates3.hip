@@ -41,7 +41,10 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define DECL_REGS(ILP)                                                                                  \
     float x[ILP]; f2 y[ILP]; unsigned w[ILP];                                                           \
     for (int j = 0; j < ILP; j++) { x[j] = threadIdx.x * 1e-3f + j; y[j] = (f2){x[j], x[j] + 1.0f}; w[j] = threadIdx.x * 77u + j; } \
-    f2 a2 = {a, a}, b2 = {b, b}; (void)a2; (void)b2; (void)w;
+    f2 a2 = {a, a}, b2 = {b, b}; (void)a2; (void)b2; (void)w;                                           \
+    unsigned sreg[ILP]; for (int j = 0; j < ILP; j++) sreg[j] = m + j; (void)sreg;                       \
+    __shared__ float lds_buf[1024]; const unsigned lds_addr = (unsigned)(size_t)(lds_buf) + threadIdx.x * 4u; (void)lds_addr; \
+    asm volatile("s_mov_b64 s[24:25], exec\n s_mov_b64 s[22:23], 0" : : : "s22", "s23", "s24", "s25");
 
 #define FORMS(ILP)                                                                                                    \
     S2R_UB_KERNEL(fma, ILP, DECL_REGS(ILP), asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[j]) : "v"(a), "v"(b));)   \
@@ -62,7 +65,19 @@ typedef float f2 __attribute__((ext_vector_type(2)));
     S2R_UB_KERNEL(cmp, ILP, DECL_REGS(ILP), asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(x[j]), "v"(a) : "vcc");)   \
     S2R_UB_KERNEL(rcp, ILP, DECL_REGS(ILP), asm volatile("v_rcp_f32 %0, %0" : "+v"(x[j]));)                            \
     S2R_UB_KERNEL(fma64, ILP, DECL_REGS(ILP), asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(y[j]) : "v"(a2), "v"(b2));) \
-    S2R_UB_KERNEL(readlane, ILP, DECL_REGS(ILP), { unsigned s_; asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(s_) : "v"(w[j])); })
+    S2R_UB_KERNEL(readlane, ILP, DECL_REGS(ILP), { unsigned s_; asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(s_) : "v"(w[j])); }) \
+    S2R_UB_KERNEL(max3, ILP, DECL_REGS(ILP), asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(x[j]) : "v"(a), "v"(b));)  \
+    /* a scalar instruction alone, and between two vector ones: does it take one of the wave's issue turns? */          \
+    S2R_UB_KERNEL(salu, ILP, DECL_REGS(ILP), asm volatile("s_add_u32 %0, %0, 7" : "+s"(sreg[j]) : : "scc");)            \
+    S2R_UB_KERNEL(fma_salu, ILP, DECL_REGS(ILP), asm volatile("v_fma_f32 %0, %0, %2, %3\n s_add_u32 %1, %1, 7" : "+v"(x[j]), "+s"(sreg[j]) : "v"(a), "v"(b) : "scc");) \
+    /* a compare into an SGPR pair + the scalar OR that collects it; a select on an SGPR-pair mask */                  \
+    S2R_UB_KERNEL(cmp_sor, ILP, DECL_REGS(ILP), asm volatile("v_cmp_eq_f32 s[20:21], %0, %1\n s_or_b64 s[22:23], s[22:23], s[20:21]" : : "v"(x[j]), "v"(a) : "s20", "s21", "s22", "s23", "scc");) \
+    S2R_UB_KERNEL(cnd_sgpr, ILP, DECL_REGS(ILP), asm volatile("v_cndmask_b32 %0, %0, %1, s[24:25]" : "+v"(x[j]) : "v"(a) : "s24", "s25");) \
+    /* LDS stores and loads alone and between vector instructions */                                                    \
+    S2R_UB_KERNEL(ldsw, ILP, DECL_REGS(ILP), asm volatile("ds_write_b32 %0, %1" : : "v"(lds_addr), "v"(x[j]) : "memory");)  \
+    S2R_UB_KERNEL(fma_ldsw, ILP, DECL_REGS(ILP), asm volatile("v_fma_f32 %0, %0, %2, %3\n ds_write_b32 %1, %0" : "+v"(x[j]) : "v"(lds_addr), "v"(a), "v"(b) : "memory");) \
+    S2R_UB_KERNEL(fma3_ldsw, ILP, DECL_REGS(ILP), asm volatile("v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %0, %0, %2, %3\n ds_write_b32 %1, %0" : "+v"(x[j]) : "v"(lds_addr), "v"(a), "v"(b) : "memory");) \
+    S2R_UB_KERNEL(fma_pkfma, ILP, DECL_REGS(ILP), asm volatile("v_fma_f32 %0, %0, %2, %3\n v_pk_fma_f32 %1, %1, %4, %5" : "+v"(x[j]), "+v"(y[j]) : "v"(a), "v"(b), "v"(a2), "v"(b2));)
 
 FORMS(1)
 FORMS(4)
@@ -75,7 +90,8 @@ struct Row { const char *name; kern_t k1, k4, k8; };
 int main(int argc, char **argv) {
     const Row rows[] = {ROW(fma), ROW(add), ROW(mul), ROW(pkfma), ROW(pkmul), ROW(pkadd), ROW(fract), ROW(cvtu), ROW(xor),
                         ROW(addu), ROW(ashr), ROW(mullo), ROW(pkmullo16), ROW(pkaddu16), ROW(cndmask), ROW(cmp), ROW(rcp),
-                        ROW(fma64), ROW(readlane)};
+                        ROW(fma64), ROW(readlane), ROW(max3), ROW(salu), ROW(fma_salu), ROW(cmp_sor), ROW(cnd_sgpr), ROW(ldsw),
+                        ROW(fma_ldsw), ROW(fma3_ldsw), ROW(fma_pkfma)};
     unsigned long long *ticks; float *sink;
     hipMalloc(&ticks, 256 * 16 * sizeof(unsigned long long));
     hipMalloc(&sink, 256 * 1024 * sizeof(float));
@@ -84,11 +100,11 @@ int main(int argc, char **argv) {
     printf("# 256 workgroups (one per CU); %d statements per chain per iteration, %d iterations\n", kUnroll, kIters);
     printf("%-10s %4s %5s %5s | %8s %8s\n", "instr", "ilp", "w/SIMD", "exec", "per wave", "per SIMD");
     for (const Row &r : rows) {
-        for (int ilp : {1, 4, 8}) {
+        for (int ilp : {1, 8}) {
             kern_t k = ilp == 1 ? r.k1 : ilp == 4 ? r.k4 : r.k8;
             for (int waves : {1, 2, 4}) {
                 for (int half : {0, 1}) {
-                    if (half && ilp == 1) continue;
+                    if (half && (ilp != 8 || waves != 4)) continue;      // (round 2, first run: a half-empty EXEC costs the same everywhere)
                     const int threads = 256 * waves;
                     hipLaunchKernelGGL(k, dim3(256), dim3(threads), 0, 0, ticks, sink, 1.0001f, 0.5f, 0x1234567u, half);
                     hipLaunchKernelGGL(k, dim3(256), dim3(threads), 0, 0, ticks, sink, 1.0001f, 0.5f, 0x1234567u, half);
@@ -97,6 +113,7 @@ int main(int argc, char **argv) {
                     hipMemcpy(h.data(), ticks, n_w * sizeof(unsigned long long), hipMemcpyDeviceToHost);
                     std::sort(h.begin(), h.begin() + n_w);
                     const double cyc = (double)h[n_w / 2] / ((double)kIters * kUnroll * ilp);
+                    // (rows that name several instructions: cycles per STATEMENT, i.e. per group of them)
                     printf("%-10s %4d %5d %5s | %8.2f %8.2f\n", r.name, ilp, waves, half ? "0-31" : "all", cyc, cyc / waves);
                 }
             }
