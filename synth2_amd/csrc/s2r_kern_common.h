@@ -614,6 +614,35 @@ __device__ __forceinline__ void apply_arg_events(const S2rRenderArgs &a, uint32_
 }
 
 // ---------------------------------------------------------------------------------------
+
+// Four frames of one quad into the wave's [16 frames][64 voices + 1] transpose tile, voice per lane: frame f of lane l
+// goes to tile[f * 65 + l].  ds_write_addtid_b32 (LDS address = M0 + offset + 4 * lane, no address register) costs a
+// lone wave 8 cycles of issue where ds_write_b32 costs 16 (tools/ubench/issue_rates3.hip) — with one wave per SIMD
+// the store of every voice-frame is a sixth of the chunk otherwise.  tile_set_base() puts the tile's LDS byte address
+// (wave-uniform) into M0 once per chunk; nothing the compiler generates for these kernels touches M0 in between
+// (tests/test_abi_c.py::test_m0_is_ours_between_the_tile_stores checks the disassembly).
+__device__ __forceinline__ void tile_set_base(uint32_t tile_m0) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(tile_m0) : "memory");
+}
+__device__ __forceinline__ void tile_store4(int q, f4 v) {
+#define S2R_ST4(Q)                                                                                              \
+    asm volatile("ds_write_addtid_b32 %0 offset:%c4\n\tds_write_addtid_b32 %1 offset:%c5\n\t"                     \
+                 "ds_write_addtid_b32 %2 offset:%c6\n\tds_write_addtid_b32 %3 offset:%c7"                          \
+                 : : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "n"((4 * Q) * 260), "n"((4 * Q + 1) * 260),         \
+                     "n"((4 * Q + 2) * 260), "n"((4 * Q + 3) * 260) : "memory")
+    switch (q) { case 0: S2R_ST4(0); break; case 1: S2R_ST4(1); break; case 2: S2R_ST4(2); break; default: S2R_ST4(3); break; }
+#undef S2R_ST4
+}
+
+// v_pk_add_f32 on a pair (the compiler splits some of the chunk's packed adds into two scalar ones)
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f4 pk_add4(f4 a, f4 b) {
+    f2 lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(a.xy), "v"(b.xy));
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(a.zw), "v"(b.zw));
+    return (f4){lo.x, lo.y, hi.x, hi.y};
+}
+
 // ---------------------------------------------------------------------------------------
 // The branch-free 16-frame chunk.  Measured (ablated builds): with the rare branches (envelope
 // stage change, fmodf slow path, coefficient-source selection) inside the per-quad loop the
@@ -632,19 +661,27 @@ __device__ __forceinline__ void apply_arg_events(const S2rRenderArgs &a, uint32_
 //   constant coefficients `fcoef`, state in *f2, instead of the one-pole.
 //   FMV (with SRC == 1, oscillator FM): the tables' last plane is pow(2, mod * mod_env_to_osc_freq); the period
 //   sr / (that * pitch) and its reciprocal are per-frame values (process.rs:146-147, units.rs:32-42, oscillators.rs:378).
-//   SMALL (one-pole kernel): every lane's offsets of the chunk are below 2^24, so the f32 offsets are exact sums and
+//   NZ >= 1 "SMALL" (one-pole kernel): every lane's offsets of the chunk are below 2^24, so the f32 offsets are exact sums and
 //   the noise hash works on their low 16 bits (hash_noise4_low16), and the patch's noise level is 0.0, so adding it
 //   (process.rs:353-356) changes nothing: the noise value itself is never +-0 (v / 65535 == 0.5 has no integer
 //   solution), and n + 0.0 == n for every other n.
+//   NZ == 2 "ALIGNED" (on top of SMALL): the chunk starts on a multiple of 16 frames and rotl(seed, 5) has a zero low
+//   nibble on every lane (the reference's seed is always 0, state.rs:18-21, and s2_bin renders 16 frames at a time,
+//   main.rs:138-143).  Then (seed ^ (o + j)) & 0xffff == B + j with B = (seed ^ o) & 0xffff for j = 0..15, and the
+//   hash's low 16 bits are (B * 0x79b9 + j * 0x79b9) mod 2^16: one product per chunk.  In float form
+//   u = H0 * 2^-16 + c_j * 2^-16 (exact: 17 bits), f = fract(u) = h_j * 2^-16 exactly, and the two-operation quotient
+//   h / 65535 = fma(h, 0x1.0001p-32, h * 2^-16) is fma(f, 0x1.0001p-16, f) — the same real number rounded once:
+//   2.5 instructions per frame instead of 4, no integer work (hashnoise.rs:33-51,57-68).
 //   AFLAT (with SMALL): every started voice of the wave sits in an amplitude stage of slope +-0 (sustain, end) for
 //   the whole run, so slope * (t - base) + y0 is (+-0) + y0 with the product's sign fixed by the slope's (t >= base
 //   inside a stage): one evaluation per chunk, at its first frame, is every frame's value bit for bit.
-template <int OSC, int SRC, int FILT = 0, bool FMV = false, bool SMALL = false, bool AFLAT = false>
+template <int OSC, int SRC, int FILT = 0, bool FMV = false, int NZ = 0, bool AFLAT = false>
 __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &r, const EnvRun &ea, const EnvRun &em,
                                            const FlatCache &fc, const OscK &k, uint32_t o_chunk, const float *tab,
-                                           const uint64_t *sT, const float *sSin, bool live, float *tile_col,
-                                           uint32_t tile_stride, float *pv_dst,
-                                           const FiltCoef *fcoef = nullptr, Filt2 *f2 = nullptr) {
+                                           const uint64_t *sT, const float *sSin, bool live, uint32_t tile_m0,
+                                           float *pv_dst, const FiltCoef *fcoef = nullptr, Filt2 *f2 = nullptr) {
+    constexpr bool SMALL = NZ >= 1, ALIGNED = NZ == 2;
+    tile_set_base(tile_m0);
     // table planes: the filter's coefficients (x and 1 - x for the one-pole, alpha / beta / gamma for the others), then
     // under FM pow(2, mod * amt_osc).  Four 16-byte loads per plane (dword-aligned: the index follows the voice's
     // offset), issued first and used last
@@ -675,10 +712,24 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
     uint32_t o01 = pk_add_u16(o_lo | (o_lo << 16), 0x00010000u), o23 = pk_add_u16(o01, 0x00020002u);
     const uint32_t seed_pair = (r.seed_rot & 0xffffu) | (r.seed_rot << 16);
     f4 t_small = splat(t_chunk) + (f4){0.0f, 1.0f, 2.0f, 3.0f};      // exact below 2^24, as are the + 4 steps
+    // ALIGNED: H0 * 2^-16, H0 = the hash's low 16 bits at the chunk's first frame
+    const float h0f = (float)(((r.seed_rot ^ o_chunk) * 0x79b9u) & 0xffffu) * 0x1p-16f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         f4 t;
-        if (SMALL) {
+        if (ALIGNED) {
+            t = t_small;
+            t_small = t_small + splat(4.0f);
+            // c_j * 2^-16 for j = 4q .. 4q + 3, c_j = (j * 0x79b9) mod 2^16
+            constexpr float kS = 0x1p-16f;
+            const f4 cj = {(float)(((4 * q) * 0x79b9u) & 0xffffu) * kS, (float)(((4 * q + 1) * 0x79b9u) & 0xffffu) * kS,
+                           (float)(((4 * q + 2) * 0x79b9u) & 0xffffu) * kS, (float)(((4 * q + 3) * 0x79b9u) & 0xffffu) * kS};
+            const f4 u = splat(h0f) + cj;
+            f4 f;
+            f.x = __builtin_amdgcn_fractf(u.x); f.y = __builtin_amdgcn_fractf(u.y);
+            f.z = __builtin_amdgcn_fractf(u.z); f.w = __builtin_amdgcn_fractf(u.w);
+            nz[q] = vfma(vfma(f, splat(0x1.0001p-16f), f), splat(2.0f), splat(-1.0f));
+        } else if (SMALL) {
             // stepping (one inline constant, one scalar literal) instead of 4 q + k per quad (a scalar move per literal)
             t = t_small;
             nz[q] = hash_noise4_low16(seed_pair, o01, o23);
@@ -705,63 +756,83 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
             xq[q] = expf4(arg, sT);
         }
     }
+    // ---- the recurrences.  Per quad: the four phases (serial: add + fract per frame), then everything that is
+    //      feed-forward in them on 4-vectors (one wave per SIMD issues one instruction per ~4.7 cycles whether it is
+    //      packed or not — tools/ubench/issue_rates3.hip — so a v_pk_* carries two frames for the price of one), then
+    //      the filter (serial), then the gain and the four stores.
+    //      fmodf(off, period) (oscillators.rs:66,105,154; lookup.rs:195) is `off` itself here: off = RN(period * ph)
+    //      with 0 <= ph <= 1 - 2^-24 is strictly below period for every normal period (period * 2^-24 is at least half
+    //      an ulp of period, so the product never rounds back up to it; checked exhaustively over ten binades of
+    //      periods in tests/test_oracle_known_answers.py::test_phased_offset_stays_below_the_period). ----
+    const uint32_t livemask = live ? 0xffffffffu : 0u;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         // filters.rs:23.  A lane without a started voice must put +0.0 into the mix (synth.rs:178 skips
         // it): with a0 = 0 and last = 0 its y is 0*s + x*0 = +0 for every finite s and x >= 0, and
         // (+0) * (amp = +0) = +0 — no select per frame
         f4 a0 = (SRC == 1 && FILT == 0) ? bq[q] : splat(1.0f) - xq[q];   // (the tables carry 1 - x next to x)
-        const f4 ampq = amp[q];
         if (SRC == 2 && !live) a0 = splat(0.0f);                 // SRC 1: such a lane reads the tables' x = 1, 1 - x = 0 entries
+        // the quad's oscillator constants: the run's (k), or under FM each frame's period and 1 / period (from the
+        // tables' pow2 plane) with the rest by exact scalings (make_osck)
+        const f4 period = FMV ? pq[q] : splat(k.period), inv_period = FMV ? iq[q] : splat(k.inv_period);
+        f4 ph;
+        float phc = r.phase;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            // the frame's oscillator constants: the run's (k), or under FM this frame's period and 1/period (from the table's pow2 plane) with
-            // the rest by exact scalings (make_osck)
-            const float period = FMV ? pq[q][j] : k.period, inv_period = FMV ? iq[q][j] : k.inv_period;
-            const float ka = !FMV ? k.a : (OSC == S2R_OSC_SAW ? -2.0f * inv_period : period * 0.5f);
-            const float kb = !FMV ? k.b : -4.0f * inv_period, kc = !FMV ? k.c : 4.0f * inv_period;
-            const float ph = r.phase;
-            const float nx = ph + inv_period;                    // oscillators.rs:377-381; 0 <= nx < 2
-            // fmodf(nx, 1) for nx >= 0 is its fractional part, which is exact; v_fract_f32 returns
-            // min(nx - floor(nx), 0x1.fffffep-1) and the clamp cannot bind for nx < 2^23
-            r.phase = __builtin_amdgcn_fractf(nx);
-            const float off = period * ph;                       // fma(period, ph, +0) with a product >= +0
-            // fmodf(off, period) on [0, period] (off == period -> 0): both are non-negative floats, so
-            // bits(off) - bits(period) is negative exactly when off < period (the compiler turns this into an
-            // integer compare + select on an SGPR pair, cheaper here than the float compare through VCC)
-            const int32_t keep = ((int32_t)s2r_f2u(off) - (int32_t)s2r_f2u(period)) >> 31;
-            const float x = s2r_u2f(s2r_f2u(off) & (uint32_t)keep);
-            float osc;
-            if (OSC == S2R_OSC_SAW) osc = __builtin_fmaf(ka, x, 1.0f);
-            else if (OSC == S2R_OSC_SQUARE) osc = x < ka ? 1.0f : -1.0f;
-            else if (OSC == S2R_OSC_TRIANGLE) {
-                const float first = __builtin_fmaf(kb, x, 1.0f), second = __builtin_fmaf(kc, x - ka, -1.0f);
-                osc = x < ka ? first : second;
-            } else {
-                // x * 1024 / period: through the run's double reciprocal, exactly (s2r_math.h); a true division when
-                // the period changes every frame
-                const float tv = FMV ? x * 1024.0f / period : s2r_div_by_rcp64(x * 1024.0f, rcp_period);
+            ph[j] = phc;
+            // oscillators.rs:377-381; 0 <= nx < 2: fmodf(nx, 1) for nx >= 0 is its fractional part, which is exact;
+            // v_fract_f32 returns min(nx - floor(nx), 0x1.fffffep-1) and the clamp cannot bind for nx < 2^23
+            phc = __builtin_amdgcn_fractf(phc + inv_period[j]);
+        }
+        r.phase = phc;
+        const f4 x = period * ph;                                // fma(period, ph, +0) with a product >= +0; == off % period
+        f4 osc;
+        if (OSC == S2R_OSC_SAW) {
+            const f4 ka = FMV ? splat(-2.0f) * inv_period : splat(k.a);
+            osc = vfma(ka, x, splat(1.0f));                      // oscillators.rs:107-112
+        } else if (OSC == S2R_OSC_SQUARE) {
+            // x < period / 2 ? 1 : -1 (oscillators.rs:68-76) without a compare: x - half is negative exactly when
+            // x < half (a difference of two distinct floats is never zero), so its sign bit over the bits of 1.0 is
+            // MINUS the sample
+            const f4 ka = FMV ? period * splat(0.5f) : splat(k.a);
+            const u4 d = (u4)(x - ka);
+            osc = -(f4)((d & 0x80000000u) | 0x3f800000u);
+        } else if (OSC == S2R_OSC_TRIANGLE) {
+            const f4 ka = FMV ? period * splat(0.5f) : splat(k.a);
+            const f4 kb = FMV ? splat(-4.0f) * inv_period : splat(k.b), kc = FMV ? splat(4.0f) * inv_period : splat(k.c);
+            const f4 first = vfma(kb, x, splat(1.0f)), second = vfma(kc, x - ka, splat(-1.0f));     // oscillators.rs:156-172
+            const u4 lt = (u4)((i4)(u4)(x - ka) >> 31);          // all ones where x < half
+            osc = (f4)(((u4)first & lt) | ((u4)second & ~lt));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // lookup.rs:46-85.  x * 1024 / period: through the run's double reciprocal, exactly (s2r_math.h); a true
+                // division when the period changes every frame
+                const float tv = FMV ? x[j] * 1024.0f / period[j] : s2r_div_by_rcp64(x[j] * 1024.0f, rcp_period);
                 const uint32_t i1 = s2r_f32_as_u32(tv), i2 = (i1 + 1u) & 1023u;
                 const float2 pr = sin_pair(sSin, i2);
                 const float s1 = i1 < 1024u ? pr.x : 0.0f, s2 = pr.y;
-                osc = __builtin_fmaf((s2 - s1) / 1.0f, tv - (float)i1, s1);
+                osc[j] = __builtin_fmaf((s2 - s1) / 1.0f, tv - (float)i1, s1);
             }
-            const float s = (osc + p.osc_gain) + nz[q][j];
-            float out;
+        }
+        const f4 sv = pk_add4(osc + splat(p.osc_gain), nz[q]);   // process.rs:342-345 (ADD), :358
+        f4 y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
             if (FILT == 0) {
-                const float y = __builtin_fmaf(a0[j], s, xq[q][j] * r.last);
-                r.last = y;
-                out = y * ampq[j];
+                y[j] = __builtin_fmaf(a0[j], sv[j], xq[q][j] * r.last);          // filters.rs:23-33
+                r.last = y[j];
             } else {
-                // (a dead lane's filter state may run away on its made-up input: select per frame here)
                 FiltCoef cj = *fcoef;                            // the run's constants, or this frame's from the tables
                 if (SRC == 1) { cj.alpha = xq[q][j]; cj.beta = bq[q][j]; cj.gamma = gq[q][j]; }
-                const float y = dsp_filter_apply(FILT, cj, s, *f2);
-                out = live ? y * amp[q][j] : 0.0f;
+                y[j] = dsp_filter_apply(FILT, cj, sv[j], *f2);
             }
-            tile_col[(4 * q + j) * tile_stride] = out;
-            if (pv_dst) pv_dst[4 * q + j] = out;
         }
+        f4 out = y * amp[q];                                     // process.rs:373-376
+        // (a dead lane's dsp_filters.rs state may run away on its made-up input: its output is masked to +0.0 here)
+        if (FILT != 0) out = (f4)((u4)out & livemask);
+        tile_store4(q, out);
+        if (pv_dst) { pv_dst[4 * q] = out.x; pv_dst[4 * q + 1] = out.y; pv_dst[4 * q + 2] = out.z; pv_dst[4 * q + 3] = out.w; }
     }
 }
 

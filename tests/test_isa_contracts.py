@@ -1,0 +1,84 @@
+"""Properties of the generated gfx950 code that the kernels' inline assembly relies on, checked on the disassembly of
+libs2r.so (no GPU needed: hipcc cross-compiles here)."""
+import importlib.util
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _code_objects():
+    spec = importlib.util.spec_from_file_location("code_objects", os.path.join(ROOT, "tools", "code_objects.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="module")
+def disassembly():
+    import synth2_amd as s2
+    s2.load_library()                      # builds libs2r.so if needed
+    if not os.path.exists(_code_objects().OBJDUMP):
+        pytest.skip("llvm-objdump not available")
+    from synth2_amd import build as _b
+    texts = _code_objects().disassemble(_b.LIB)
+    assert len(texts) >= 10, "expected one code object per translation unit"
+    return texts
+
+
+def test_m0_is_ours_between_the_tile_stores(disassembly):
+    """chunk_fast puts the wave's tile address into M0 once per chunk (tile_set_base) and then issues sixteen
+    ds_write_addtid_b32 (address = M0 + offset + 4 * lane) from separate asm statements: nothing the compiler emits may
+    write M0 — every M0 write in the library must be our `s_mov_b32 m0, sN` + `s_nop 0`, and nothing else may read it."""
+    n_set = n_store = 0
+    for text in disassembly:
+        lines = [l.split("//")[0].strip() for l in text.splitlines()]
+        for i, l in enumerate(lines):
+            if "ds_write_addtid_b32" in l:
+                n_store += 1
+                continue
+            if re.search(r"\bm0\b", l):
+                assert re.match(r"s_mov_b32 m0, s\d+$", l), "unexpected use of M0: %r" % l
+                assert lines[i + 1].startswith("s_nop"), "M0 write without the wait state in front of the LDS store: %r" % lines[i + 1]
+                n_set += 1
+    assert n_set > 0 and n_store == 16 * n_set, (n_set, n_store)
+
+
+def test_hot_chunk_has_no_compare_or_select(disassembly):
+    """The branch-free chunk of the saw one-pole kernel is straight-line packed arithmetic: no v_cmp / v_cndmask (8
+    cycles each for a lone wave, tools/ubench/issue_rates3.hip) inside the basic block of its steady-state variant
+    (flat envelopes, offsets below 2^24, aligned chunks), except the select of the run's dead-lane mask."""
+    best = 1 << 30
+    smallest = 1 << 30
+    seen = 0
+    for text in disassembly:
+        if "s2r_render_kernelILi1ELb0ELi0E" not in text:
+            continue
+        body = text[text.index("s2r_render_kernelILi1ELb0ELi0E"):]
+        # split into basic blocks at branch targets / branches
+        blocks, cur = [], []
+        for l in body.splitlines():
+            ins = l.split("//")[0].strip()
+            if re.match(r"^[0-9a-f]+ <", ins):
+                if cur:
+                    blocks.append(cur)
+                cur = []
+                if "s2r_render_kernelILi1ELb0ELi0E" not in ins and not ins.endswith(">:") :
+                    break
+                continue
+            if ins:
+                cur.append(ins)
+                if ins.startswith("s_cbranch") or ins.startswith("s_branch"):
+                    blocks.append(cur)
+                    cur = []
+        for b in blocks:
+            if sum("ds_write_addtid_b32" in i for i in b) == 16:
+                seen += 1
+                best = min(best, sum(i.startswith("v_cmp") or i.startswith("v_cndmask") for i in b))
+                smallest = min(smallest, len(b))
+    # (the variants for offsets beyond 2^24 convert and compare per frame; the steady-state ones must not)
+    assert seen >= 4
+    assert best <= 2, best
+    assert smallest <= 200, "the steady-state chunk grew to %d instructions (r2: 181 for 16 frames)" % smallest

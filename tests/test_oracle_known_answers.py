@@ -313,3 +313,26 @@ def test_decimator_taps_are_a_sane_lowpass():
     assert 20 * np.log10(resp.max()) < -70.0
     passband = np.abs(np.exp(-2j * np.pi * np.outer(np.linspace(0, 0.08, 50), np.arange(63))) @ h)
     assert np.all(np.abs(20 * np.log10(passband)) < 1.0)
+
+
+def test_phased_offset_stays_below_the_period():
+    """oscillators.rs:217-239 computes offset = fma(period, phase, 0) and the basic oscillators then take
+    offset % period (:66,105,154; lookup.rs:195).  For 0 <= phase <= 1 - 2^-24 (every value fmodf(.., 1.0) can return)
+    the product rounds to a float strictly below period — period * 2^-24 is at least half an ulp of period — so the
+    remainder is the offset itself: the GPU's branch-free chunk relies on it (s2r_kern_common.h chunk_fast).
+    Exhaustive over every float period of ten binades at the two largest phases, plus random pairs."""
+    big = np.float32(1.0) - np.float32(2.0 ** -24)
+    assert np.nextafter(big, np.float32(2.0)) == np.float32(1.0)
+    for e in (-20, -3, 0, 1, 5, 6, 7, 10, 20, 60):
+        bits = np.float32(2.0 ** e).view(np.uint32) + np.arange(0, 1 << 23, dtype=np.uint32)
+        period = bits.view(np.float32)
+        for ph in (big, np.nextafter(big, np.float32(0.0))):
+            off = period * ph                       # one correctly rounded float32 product == fma(period, ph, 0)
+            assert off.dtype == np.float32
+            assert not np.any(off >= period), e
+    rng = np.random.default_rng(7)
+    period = rng.uniform(0.5, 6000.0, 5_000_000).astype(np.float32)
+    ph = np.minimum(rng.uniform(0.0, 1.0, 5_000_000).astype(np.float32), big)
+    off = period * ph
+    assert not np.any(off >= period)
+    assert np.array_equal(np.fmod(off, period), off)

@@ -16,7 +16,10 @@ MNEMONIC = {"fma": "v_fma_f32", "add": "v_add_f32", "mul": "v_mul_f32", "pkfma":
             "ashr": "v_ashrrev_i32", "mullo": "v_mul_lo_u32", "pkmullo16": "v_pk_mul_lo_u16", "pkaddu16": "v_pk_add_u16",
             "cndmask": "v_cndmask_b32", "cmp": "v_cmp_lt_f32", "rcp": "v_rcp_f32", "fma64": "v_fma_f64", "readlane": "v_readlane_b32", "max3": "v_max3_f32", "salu": "s_add_u32", "fma_salu": "s_add_u32",
             "cmp_sor": "v_cmp_eq_f32", "cnd_sgpr": "v_cndmask_b32", "ldsw": "ds_write_b32", "fma_ldsw": "ds_write_b32",
-            "fma3_ldsw": "ds_write_b32", "fma_pkfma": "v_pk_fma_f32"}
+            "fma3_ldsw": "ds_write_b32", "fma_pkfma": "v_pk_fma_f32", "ldsw2": "ds_write2_b32", "ldsw64": "ds_write_b64",
+            "ldsw128": "ds_write_b128", "ldswtid": "ds_write_addtid_b32", "fma3_ldswtid": "ds_write_addtid_b32",
+            "ldsr": "ds_read_b32", "ldsr2": "ds_read2_b32", "ldsr64": "ds_read_b64", "ldsr128": "ds_read_b128",
+            "fma3_ldsr128": "ds_read_b128"}
 UNROLL = 16
 dis = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", obj], capture_output=True, text=True, check=True).stdout
 kern = None
@@ -39,6 +42,8 @@ for k in sorted(counts):
     # encodings carry a suffix (_e32, _e64, _sdwa, _dpp); the compiler may unroll the outer loop (x2, x4); the epilogue
     # (sum of the chains, cvt of y.x) may add a few of the same mnemonic
     got = sum(c for mn, c in counts[k].items() if mn == MNEMONIC[name] or mn.startswith(MNEMONIC[name] + "_e"))
+    if name.startswith("lds") or "_lds" in name:
+        got = counts[k][MNEMONIC[name]]
     ok = any(want * f <= got <= want * f + 2 * ilp + 2 for f in (1, 2, 4))
     others = sum(c for mn, c in counts[k].items() if mn.startswith("v_pk_") and not MNEMONIC[name].startswith("v_pk_"))
     ok = ok and others <= 2 * ilp + 2    # nothing packed behind the measured scalar form (the epilogue sum may pack a few)

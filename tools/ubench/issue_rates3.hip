@@ -32,18 +32,22 @@ constexpr int kIters = 256;
         }                                                                                               \
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                     \
         float s = 0.0f;                                                                                 \
-        for (int j = 0; j < ILP; j++) s += x[j] + (float)y[j].x;                                        \
+        for (int j = 0; j < ILP; j++) s += x[j] + (float)y[j].x + z[j].w;                                        \
         sink[blockIdx.x * blockDim.x + threadIdx.x] = s;                                                \
         if ((threadIdx.x & 63u) == 0) ticks[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0; \
     }
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
 #define DECL_REGS(ILP)                                                                                  \
     float x[ILP]; f2 y[ILP]; unsigned w[ILP];                                                           \
     for (int j = 0; j < ILP; j++) { x[j] = threadIdx.x * 1e-3f + j; y[j] = (f2){x[j], x[j] + 1.0f}; w[j] = threadIdx.x * 77u + j; } \
     f2 a2 = {a, a}, b2 = {b, b}; (void)a2; (void)b2; (void)w;                                           \
     unsigned sreg[ILP]; for (int j = 0; j < ILP; j++) sreg[j] = m + j; (void)sreg;                       \
-    __shared__ float lds_buf[1024]; const unsigned lds_addr = (unsigned)(size_t)(lds_buf) + threadIdx.x * 4u; (void)lds_addr; \
+    __shared__ __attribute__((aligned(16))) float lds_buf[4096 + 1024]; const unsigned lds_addr = (unsigned)(size_t)(lds_buf) + threadIdx.x * 4u; (void)lds_addr; \
+    const unsigned lds_addr8 = (unsigned)(size_t)(lds_buf) + threadIdx.x * 8u, lds_addr16 = (unsigned)(size_t)(lds_buf) + threadIdx.x * 16u; (void)lds_addr8; (void)lds_addr16; \
+    f4v z[ILP]; for (int j = 0; j < ILP; j++) z[j] = (f4v){x[j], x[j], x[j], x[j]}; (void)z;            \
+    asm volatile("s_mov_b32 m0, %0" : : "s"(__builtin_amdgcn_readfirstlane((int)((unsigned)(size_t)(lds_buf) + (threadIdx.x >> 6) * 256u))) : "m0");   \
     asm volatile("s_mov_b64 s[24:25], exec\n s_mov_b64 s[22:23], 0" : : : "s22", "s23", "s24", "s25");
 
 #define FORMS(ILP)                                                                                                    \
@@ -77,6 +81,17 @@ typedef float f2 __attribute__((ext_vector_type(2)));
     S2R_UB_KERNEL(ldsw, ILP, DECL_REGS(ILP), asm volatile("ds_write_b32 %0, %1" : : "v"(lds_addr), "v"(x[j]) : "memory");)  \
     S2R_UB_KERNEL(fma_ldsw, ILP, DECL_REGS(ILP), asm volatile("v_fma_f32 %0, %0, %2, %3\n ds_write_b32 %1, %0" : "+v"(x[j]) : "v"(lds_addr), "v"(a), "v"(b) : "memory");) \
     S2R_UB_KERNEL(fma3_ldsw, ILP, DECL_REGS(ILP), asm volatile("v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %0, %0, %2, %3\n ds_write_b32 %1, %0" : "+v"(x[j]) : "v"(lds_addr), "v"(a), "v"(b) : "memory");) \
+    /* the other LDS forms: wide stores, the address-free store (address = M0 + offset + 4 * lane), loads */             \
+    S2R_UB_KERNEL(ldsw2, ILP, DECL_REGS(ILP), asm volatile("ds_write2_b32 %0, %1, %1 offset1:65" : : "v"(lds_addr), "v"(x[j]) : "memory");) \
+    S2R_UB_KERNEL(ldsw64, ILP, DECL_REGS(ILP), asm volatile("ds_write_b64 %0, %1" : : "v"(lds_addr8), "v"(y[j]) : "memory");) \
+    S2R_UB_KERNEL(ldsw128, ILP, DECL_REGS(ILP), asm volatile("ds_write_b128 %0, %1" : : "v"(lds_addr16), "v"(z[j]) : "memory");) \
+    S2R_UB_KERNEL(ldswtid, ILP, DECL_REGS(ILP), asm volatile("ds_write_addtid_b32 %0 offset:260" : : "v"(x[j]) : "memory");) \
+    S2R_UB_KERNEL(fma3_ldswtid, ILP, DECL_REGS(ILP), asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n ds_write_addtid_b32 %0 offset:260" : "+v"(x[j]) : "v"(a), "v"(b) : "memory");) \
+    S2R_UB_KERNEL(ldsr, ILP, DECL_REGS(ILP), { float t_; asm volatile("ds_read_b32 %0, %1" : "=v"(t_) : "v"(lds_addr) : "memory"); }) \
+    S2R_UB_KERNEL(ldsr2, ILP, DECL_REGS(ILP), { f2 t_; asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(t_) : "v"(lds_addr) : "memory"); }) \
+    S2R_UB_KERNEL(ldsr64, ILP, DECL_REGS(ILP), { f2 t_; asm volatile("ds_read_b64 %0, %1" : "=v"(t_) : "v"(lds_addr8) : "memory"); }) \
+    S2R_UB_KERNEL(ldsr128, ILP, DECL_REGS(ILP), { f4v t_; asm volatile("ds_read_b128 %0, %1" : "=v"(t_) : "v"(lds_addr16) : "memory"); }) \
+    S2R_UB_KERNEL(fma3_ldsr128, ILP, DECL_REGS(ILP), { f4v t_; asm volatile("v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %0, %0, %2, %3\n ds_read_b128 %1, %4" : "+v"(x[j]), "=v"(t_) : "v"(a), "v"(b), "v"(lds_addr16) : "memory"); }) \
     S2R_UB_KERNEL(fma_pkfma, ILP, DECL_REGS(ILP), asm volatile("v_fma_f32 %0, %0, %2, %3\n v_pk_fma_f32 %1, %1, %4, %5" : "+v"(x[j]), "+v"(y[j]) : "v"(a), "v"(b), "v"(a2), "v"(b2));)
 
 FORMS(1)
@@ -91,7 +106,8 @@ int main(int argc, char **argv) {
     const Row rows[] = {ROW(fma), ROW(add), ROW(mul), ROW(pkfma), ROW(pkmul), ROW(pkadd), ROW(fract), ROW(cvtu), ROW(xor),
                         ROW(addu), ROW(ashr), ROW(mullo), ROW(pkmullo16), ROW(pkaddu16), ROW(cndmask), ROW(cmp), ROW(rcp),
                         ROW(fma64), ROW(readlane), ROW(max3), ROW(salu), ROW(fma_salu), ROW(cmp_sor), ROW(cnd_sgpr), ROW(ldsw),
-                        ROW(fma_ldsw), ROW(fma3_ldsw), ROW(fma_pkfma)};
+                        ROW(fma_ldsw), ROW(fma3_ldsw), ROW(ldsw2), ROW(ldsw64), ROW(ldsw128), ROW(ldswtid), ROW(fma3_ldswtid), ROW(ldsr),
+                        ROW(ldsr2), ROW(ldsr64), ROW(ldsr128), ROW(fma3_ldsr128), ROW(fma_pkfma)};
     unsigned long long *ticks; float *sink;
     hipMalloc(&ticks, 256 * 16 * sizeof(unsigned long long));
     hipMalloc(&sink, 256 * 1024 * sizeof(float));
@@ -99,7 +115,9 @@ int main(int argc, char **argv) {
     printf("# cycles per wave-instruction as one wave sees them (median over waves, s_memtime) | the SIMD's cycles per wave-instruction\n");
     printf("# 256 workgroups (one per CU); %d statements per chain per iteration, %d iterations\n", kUnroll, kIters);
     printf("%-10s %4s %5s %5s | %8s %8s\n", "instr", "ilp", "w/SIMD", "exec", "per wave", "per SIMD");
+    setvbuf(stdout, nullptr, _IOLBF, 0);
     for (const Row &r : rows) {
+        if (argc > 1 && !strstr(argv[1], r.name)) continue;      // run only the rows named in argv[1] ("fma,ldsw,...")
         for (int ilp : {1, 8}) {
             kern_t k = ilp == 1 ? r.k1 : ilp == 4 ? r.k4 : r.k8;
             for (int waves : {1, 2, 4}) {
