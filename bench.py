@@ -1,26 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py — voice-render throughput on MI355X (BASELINE.json metric).
+"""bench.py — voice-render throughput on MI355X (BASELINE.json metric; SURVEY.md §8(d) is the definition).
 
     python bench.py --gpus N --steps K --warmup W
 
-A *step* is one 1024-frame buffer fill of the whole voice pool: note events for the buffer
-are applied, every voice's 1024 frames are rendered (oscillator -> envelopes -> LPF) and
-mixed down.  Workload (config.workload): BASELINE config "65 536 voices ... 48 kHz on 1
-MI355X" with the reference's own patch (Synth::default_config: saw + amp/mod ADSR + the
-one-pole LPF; the reference has no SVF) — per GPU, so N GPUs render N x 65 536 voices (weak
-scaling), the pool dealt out to the ranks in runs of 64 voices, with one all-gather of the 4 KiB
-partial mixes per buffer over RCCL and a rank-ordered sum on rank 0.
+A *step* is one 1024-frame buffer of the whole voice pool: the buffer's note events are handed over
+(`s2r_note_events`), then `s2r_fill` renders every voice's 1024 frames (oscillator -> envelopes -> LPF), mixes them
+down and returns the buffer in HOST memory (events H2D and the 4 KiB mix D2H are inside the timed call, as §8(d) asks).
 
-`value` = voice-samples/s = voices x frames x steps / wall time, whole job, with the voice
-state resident in HBM and the mix left in HBM (the synchronous host-buffer API rate, which
-adds a 4 KiB D2H copy and a stream sync per buffer, is printed as `sync_fill_value`).
+Workload `c3` (default; config.workload names it): SURVEY §8(d)'s C3 — 65 536 voices per GPU, the reference's own patch
+(`example.synth2`, empty body == Synth::default_config: saw + amp/mod ADSR + the one-pole LPF; the reference has no
+SVF), `note[v] = 36 + (v mod 61)`, note-off `16 * (512 + lcg(v) mod 2048)` frames after the note-on (LCG seeded by v) —
+made PERIODIC so that the envelope-stage mix is stationary and the result does not depend on --steps / --warmup: a voice
+lives one C3 life (on -> LCG note-off -> release -> silent) every 64 buffers, the lives start 1/64 of the pool per
+buffer, in index order (the allocation policy — oldest voice, lowest index — then restarts exactly the voices whose
+turn it is).  Note-ons land on buffer starts, note-offs on their 16-frame boundary INSIDE the buffer (timed events, the
+granularity s2_bin's loop has, main.rs:138-143).  Before the warm-up the population is aged by one whole period
+(untimed set-up).  Workload `churn` is round 1's: everything on at frame 0, then 128 note-offs + 128 note-ons per
+buffer per 64 k voices.
 
-Two extra objects ride on the JSON line: `roofline` (the render kernel against the HBM
-roof, as BASELINE's north_star asks — this path is NOT HBM-bound, see DESIGN.md — plus
-`roofline_valu`, the bound that actually applies) and `cpu_baseline` (the CPU oracle, a C
-restatement of s2_lib, timed on this host on a bounded sample; rank 0, N=1 only).
+N GPUs: the pool is N x as large (weak scaling; `--voices-total` fixes the pool instead: strong scaling), dealt out to
+the ranks in runs of 64 voices; every rank sees the same event stream; per buffer one all-gather of the 4 KiB partial
+mixes over RCCL and a rank-ordered sum on rank 0, whose result is copied to host memory every buffer.
+
+`value` = voice-samples/s = voices x frames x steps / wall time of the K timed steps (max over ranks).
+Extra objects on the JSON line: `roofline` (the render kernel against the HBM roof, as BASELINE's north_star asks — this
+path is NOT HBM-bound), `roofline_valu` (the bound that applies), `cpu_baseline` (+ `cpu_baseline_legs`:
+the CPU oracle, a C restatement of s2_lib, timed on this host on bounded samples; rank 0, N = 1 only).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -34,13 +42,16 @@ if ROOT not in sys.path:
 
 SR = 48000
 FRAMES = 1024
+PERIOD = 64                     # buffers between two lives of a voice (workload c3)
 # algorithmic HBM bytes per started voice per fill: read pitch, offset, release, flags, phase,
-# lpf_last, seed (7 x 4 B) and write offset, phase, lpf_last (3 x 4 B)        (DESIGN.md §Roofline)
+# lpf_last, seed (7 x 4 B) and write offset, phase, lpf_last (3 x 4 B)        (DESIGN.md §2, §6)
 BYTES_PER_VOICE_FILL = 28 + 12
-# fp32-equivalent flops per voice-sample of the x16 path with the default patch (DESIGN.md)
+# fp32-equivalent flops per voice-sample of the x16 path with the default patch (SURVEY §8(d))
 FLOPS_PER_VOICE_SAMPLE = 250.0
 HBM_PEAK_GBS = 8000.0
 VALU_PEAK_TFLOPS = 157.3
+# one wave-instruction per SIMD per 2 cycles (SIMD-32, MI355X_MICROARCH.md): 1024 SIMDs x 2.4 GHz / 2
+VALU_ISSUE_PEAK_PER_S = 1024 * 2.4e9 / 2.0
 
 
 def lcg(x):
@@ -48,8 +59,8 @@ def lcg(x):
 
 
 def make_events(total_voices, churn_per_64k, step, rng_seed=1):
-    """Deterministic churn for one step: `churn` note-offs then `churn` note-ons over the
-    whole pool (voice stealing picks the oldest voice), notes 36..96."""
+    """workload `churn`: `churn` note-offs then `churn` note-ons over the whole pool (voice stealing picks the oldest
+    voice), notes 36..96, all at the buffer's start."""
     import synth2_amd as s2
     n = max(1, total_voices * churn_per_64k // 65536)
     ev = np.zeros(2 * n, dtype=s2.NOTE_EVENT_DTYPE)
@@ -66,8 +77,38 @@ def make_events(total_voices, churn_per_64k, step, rng_seed=1):
     return ev
 
 
-def cpu_baseline(voices, buffers, threads):
-    """The CPU oracle (test infrastructure) timed as the reported CPU baseline."""
+def make_c3_events(total_voices, period=PERIOD):
+    """workload `c3`: the event batch of every buffer of one period (the schedule repeats every `period` buffers).
+    Buffer b starts the lives of voices [b * V / period, (b + 1) * V / period) at its frame 0 and carries the note-offs
+    that fall inside it, each at its own 16-frame boundary."""
+    import synth2_amd as s2
+    v = np.arange(total_voices, dtype=np.int64)
+    note = (36 + v % 61).astype(np.uint8)
+    delay = 16 * (512 + ((1103515245 * v + 12345) % (1 << 31)) % 2048)          # frames from note-on to note-off
+    per = max(1, total_voices // period)
+    start_buf = np.minimum(v // per, period - 1)
+    off_buf = (start_buf + delay // FRAMES) % period
+    off_frame = delay % FRAMES
+    batches = []
+    for b in range(period):
+        on = np.nonzero(start_buf == b)[0]
+        off = np.nonzero(off_buf == b)[0]
+        off = off[np.argsort(off_frame[off], kind="stable")]
+        ev = np.zeros(on.size + off.size, dtype=s2.NOTE_EVENT_DTYPE)
+        ev["kind"][:on.size] = 1
+        ev["note"][:on.size] = note[on]
+        ev["velocity"][:on.size] = 1.0
+        ev["kind"][on.size:] = 0
+        ev["note"][on.size:] = note[off]
+        ev["frame"][on.size:] = off_frame[off]
+        if os.environ.get("S2R_BENCH_QUANTIZE") == "1":       # measurement aid: the note-offs moved to the buffer's start
+            ev["frame"][:] = 0
+        batches.append(ev)      # ordered by frame: the note-ons (frame 0), then the note-offs by their frame
+    return batches
+
+
+def cpu_oracle_rate(voices, buffers, threads):
+    """The CPU oracle (test infrastructure) timed as the reported CPU baseline: voices x 1024 frames x buffers."""
     from oracle import s2o
     s = s2o.OracleSynth(voices)
     for v in range(voices):
@@ -80,19 +121,58 @@ def cpu_baseline(voices, buffers, threads):
     return voices * FRAMES * buffers / dt, dt
 
 
+def cpu_baseline_legs(cores, budget_s):
+    """§8(d): (1) one thread at the reference's own pool size (NUM_VOICES = 8, synth.rs:7) and at 1 024 voices
+    (cache-resident), (2) all cores at C3's 65 536 voices.  Each leg is sized to about budget_s seconds."""
+    legs = []
+    for voices, threads in ((8, 1), (1024, 1), (65536, cores)):
+        probe, dt = cpu_oracle_rate(voices, 1, threads)
+        nb = int(max(1, min(20000, budget_s * probe / (voices * FRAMES))))
+        v, secs = cpu_oracle_rate(voices, nb, threads)
+        legs.append({"value": v, "unit": "samples/s", "cores": threads, "kind": "port", "voices": voices,
+                     "ns_per_voice_sample_per_core": 1e9 * threads / v,
+                     "sample": "%d voices x %d frames x %d buffers, default patch, all notes held (amp sustain), %.1f s" % (
+                         voices, FRAMES, nb, secs)})
+    return legs
+
+
+def kernel_source_hash():
+    """identifies the build a committed profile belongs to (the GPU box has no .git)"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "synth2_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".inc", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_profile():
+    """PMC figures of the render kernel from the committed rocprofv3 summary — only if it was taken on THIS build of
+    the kernels (same source hash); otherwise None (a stale profile is not evidence for the line being printed)."""
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r02", "c3_summary.json")))
+    except Exception:
+        return None
+    if prof.get("kernel_source_hash") != kernel_source_hash():
+        return None
+    return prof
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", choices=["c3", "churn"], default="c3")
     ap.add_argument("--voices-per-gpu", type=int, default=65536)
-    ap.add_argument("--churn", type=int, default=128, help="note-ons (and note-offs) per step per 65536 voices")
+    ap.add_argument("--voices-total", type=int, default=0, help="fix the pool (strong scaling) instead of the per-GPU share")
+    ap.add_argument("--churn", type=int, default=128, help="workload churn: note-ons (and note-offs) per step per 65536 voices")
     ap.add_argument("--block-voices", type=int, default=0)
-    ap.add_argument("--lanes", type=int, default=0, help="GPU lanes per voice (1/2/4, 0 = auto)")
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap the all-gather with the next render")
+    ap.add_argument("--reduce", action="store_true", help="N > 1: combine the partial mixes with one reduce(sum) to rank 0 instead of all-gather + rank-ordered sum")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-voices", type=int, default=16384)
-    ap.add_argument("--cpu-buffers", type=int, default=0, help="0 = sized for ~15 s")
+    ap.add_argument("--cpu-seconds", type=float, default=6.0, help="seconds per CPU-baseline leg (three legs)")
     args = ap.parse_args()
 
     import torch
@@ -122,34 +202,55 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    vpg = args.voices_per_gpu
+    strong = args.voices_total > 0
+    if strong:
+        if args.voices_total % (64 * world):
+            sys.exit("--voices-total must be a multiple of 64 x the number of GPUs")
+        vpg = args.voices_total // world
+    else:
+        vpg = args.voices_per_gpu
     total = vpg * world
     from synth2_amd.sharded import ShardedSynth
-    sh = ShardedSynth(vpg, max_frames=FRAMES, rank=rank, world=world, device=dev,
-                      block_voices=args.block_voices, lanes_per_voice=args.lanes, overlap=not args.no_overlap)
+    sh = ShardedSynth(vpg, max_frames=FRAMES, rank=rank, world=world, device=dev, block_voices=args.block_voices,
+                      overlap=not args.no_overlap, reduce_to_root=args.reduce)
     synth = sh.renderer
     sh.load_patch("synth mySynth {\n\n}\n")       # example.synth2: empty body == default patch
     if os.environ.get("S2R_COEFF_STREAM_MODE"):       # measurement aid (see s2r_set_coeff_stream); results are bit-identical
         synth.set_coeff_stream(int(os.environ["S2R_COEFF_STREAM_MODE"]))
 
-    # initial population: every voice of the pool gets a note (all ranks see the same stream)
-    init = np.zeros(total, dtype=s2.NOTE_EVENT_DTYPE)
-    init["kind"] = 1
-    init["note"] = 36 + (np.arange(total) % 61)
-    init["velocity"] = 1.0
-    sh.note_events(init)
+    # ---- the event batches (every rank sees the same stream) ----
+    if args.workload == "c3":
+        period = PERIOD if total >= PERIOD else 1
+        cyc = make_c3_events(total, period)
+        events_of = lambda k: cyc[k % period]
+        n_setup = period + 2                      # one whole period: every voice has lived once, the stage mix is stationary
+    else:
+        init = np.zeros(total, dtype=s2.NOTE_EVENT_DTYPE)
+        init["kind"] = 1
+        init["note"] = 36 + (np.arange(total) % 61)
+        init["velocity"] = 1.0
+        sh.note_events(init)
+        churn_cache = {}
+        def events_of(k):
+            if k not in churn_cache:
+                churn_cache[k] = make_events(total, args.churn, k)
+            return churn_cache[k]
+        n_setup = 12                              # past the initial 9 600-frame mod decay of the whole pool
+    n_events_per_step = float(np.mean([events_of(k).size for k in range(n_setup, n_setup + max(1, min(args.steps, 64)))]))
+    for k in range(n_setup + args.warmup + args.steps + 80):
+        events_of(k)                              # generated outside the timed region
 
-    n_steps = args.warmup + args.steps
-    events = [make_events(total, args.churn, k) for k in range(n_steps)]
-
-    stream = torch.cuda.current_stream()
-    sptr = stream.cuda_stream
-    partial = sh.partial
-    mix = sh.mix
+    out_host = np.empty(FRAMES, dtype=np.float32)
+    pinned = torch.empty(FRAMES, dtype=torch.float32).pin_memory() if world > 1 else None
 
     def step(k):
-        sh.note_events(events[k])
-        sh.fill(FRAMES, SR)
+        sh.note_events(events_of(k))
+        if world == 1:
+            synth.sample(out_host, SR)            # s2r_fill: synchronous, the mix lands in host memory
+        else:
+            sh.fill(FRAMES, SR)
+            if rank == 0:
+                sh.copy_mix_to(pinned)            # async D2H of the finished mix behind the combine
 
     def fence():
         sh.flush()
@@ -157,72 +258,87 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
+    k0 = 0
+    for k in range(n_setup):                      # untimed set-up: age the population
         step(k)
+    k0 += n_setup
+    for k in range(k0, k0 + args.warmup):
+        step(k)
+    k0 += args.warmup
     fence()
     # ---- timed region: exactly K steps ----
     t0 = time.perf_counter()
-    for k in range(args.warmup, n_steps):
+    for k in range(k0, k0 + args.steps):
         step(k)
     fence()
     dt = time.perf_counter() - t0
+    k0 += args.steps
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
-    mix_host = mix.cpu().numpy()
+    mix_host = out_host.copy() if world == 1 else sh.mix.cpu().numpy()
 
-    # ---- per-launch duration of the render kernel, HIP events on the launch stream ----
-    # (separate short loops so the events do not perturb the timed region)
-    def kernel_ms_loop():
+    # ---- the same steps without waiting for each buffer (N = 1): device-resident mix, one fence at the end ----
+    pipelined = None
+    stream = torch.cuda.current_stream()
+    sptr = stream.cuda_stream
+    if world == 1:
+        n_p = min(args.steps, 64)
+        fence()
+        t1 = time.perf_counter()
+        for k in range(k0, k0 + n_p):
+            sh.note_events(events_of(k))
+            sh.fill(FRAMES, SR)
+        fence()
+        pipelined = total * FRAMES * n_p / (time.perf_counter() - t1)
+        k0 += n_p
+
+    # ---- per-launch duration of the render kernel on the same workload, HIP events on the launch stream ----
+    # (separate steps so the events do not perturb the timed region)
+    def kernel_ms_loop(n):
+        nonlocal k0
         kms = []
         synth.set_timing(True)
-        for k in range(min(args.steps, 16)):
-            synth.fill_device(partial[0].data_ptr(), FRAMES, SR, sptr)
+        for k in range(k0, k0 + n):
+            sh.note_events(events_of(k))
+            sh.fill(FRAMES, SR)
             kms.append(synth.last_render_ms())
         synth.set_timing(False)
         fence()
+        k0 += n
         return float(np.mean(kms)) if kms else float("nan")
 
-    kernel_ms = kernel_ms_loop()
-    # the same workload with the flat-envelope coefficient reuse switched off: every frame of
-    # every voice pays the full pow/exp chain (what the kernel costs when all voices modulate)
+    kernel_ms = kernel_ms_loop(min(max(args.steps, 4), 16))
+    # the same workload with the flat-envelope coefficient reuse and the coefficient tables switched off: every frame
+    # of every voice pays the full pow/exp chain in-lane (all of SURVEY §8(d)'s ~250 flop-equivalents really executed)
     synth.set_flat_shortcut(False)
-    kernel_ms_full = kernel_ms_loop()
-    t2 = time.perf_counter()
-    n_full = min(args.steps, 32)
-    for k in range(n_full):
-        sh.fill(FRAMES, SR)
-    fence()
-    dt_full = time.perf_counter() - t2
+    kernel_ms_full = kernel_ms_loop(min(max(args.steps, 4), 16))
     synth.set_flat_shortcut(True)
 
-    # ---- synchronous host-buffer API (s2r_fill): D2H + sync per buffer ----
-    sync_rate = None
-    if world == 1:
-        buf = np.empty(FRAMES, dtype=np.float32)
-        synth.sample(buf, SR)
-        t1 = time.perf_counter()
-        for _ in range(min(args.steps, 32)):
-            synth.sample(buf, SR)
-        sync_rate = vpg * FRAMES * min(args.steps, 32) / (time.perf_counter() - t1)
-
     if rank == 0:
-        # HBM bytes per launch of the render kernel from the committed rocprofv3 PMC passes
-        # (FETCH_SIZE and WRITE_SIZE in separate passes, KiB units); dword-per-lane accesses, for
-        # which the guide's x2 FETCH_SIZE correction (16 B/lane streams) is not calibrated
-        traffic = None
-        try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01", "steady_state_summary.json")))
-            pm = prof["pmc_avg_per_dispatch"]
-            traffic = (pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
-        except Exception:
-            pass
         value = total * FRAMES * args.steps / dt_max
         kernel_s = kernel_ms * 1e-3
         hbm_gbs = BYTES_PER_VOICE_FILL * vpg / kernel_s / 1e9
         valu_tf = FLOPS_PER_VOICE_SAMPLE * vpg * FRAMES / (kernel_ms_full * 1e-3) / 1e12
+        prof = committed_profile()
+        traffic = None
+        traffic_note = "no rocprofv3 PMC summary of this build of the kernels under profiles/r02 (hash %s): omitted rather than quoted from another build" % kernel_source_hash()
+        valu_issue = None
+        if prof is not None:
+            pm = prof.get("pmc_avg_per_dispatch", {})
+            if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
+                # separate passes, KiB units; dword-per-lane accesses, for which the guide's x2 FETCH_SIZE correction
+                # (16 B/lane streams) is not calibrated: raw counter sum
+                traffic = (pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
+                traffic_note = "profiles/r02/c3_summary.json, same kernel sources (hash %s)" % kernel_source_hash()
+            if "SQ_INSTS_VALU" in pm and prof.get("dispatch", {}).get("avg_ns"):
+                per_s = pm["SQ_INSTS_VALU"] / (prof["dispatch"]["avg_ns"] * 1e-9)
+                valu_issue = {"wave_instructions_per_launch": pm["SQ_INSTS_VALU"],
+                              "per_voice_frame": pm["SQ_INSTS_VALU"] * 64.0 / (vpg * FRAMES),
+                              "frac_of_issue_peak": per_s / VALU_ISSUE_PEAK_PER_S,
+                              "note": "SQ_INSTS_VALU per launch / launch time vs one wave-instruction per SIMD per 2 cycles"}
         out = {
             "metric": "voice-samples/sec (mono) at 64k voices per GPU, 48 kHz, 1024-frame buffers",
             "value": value,
@@ -232,43 +348,47 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt_max * 1e3 / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "%d voices per GPU, default patch (example.synth2 empty body: saw + amp/mod ADSR + one-pole LPF), "
-                                   "48 kHz, 1024-frame buffers, %d note-on + %d note-off per buffer per 64k voices" % (vpg, args.churn, args.churn),
+            "config": {"workload": ("C3 (SURVEY 8d), periodic: %d voices per GPU, default patch (example.synth2 empty body: saw + amp/mod ADSR + "
+                                    "one-pole LPF), 48 kHz, 1024-frame buffers; every voice lives one C3 life (note-on, note-off after "
+                                    "16*(512 + lcg(v) mod 2048) frames, release) per %d buffers, lives staggered 1/%d of the pool per buffer; "
+                                    "%.0f events per buffer, note-offs as timed events on their 16-frame boundary; population aged one period "
+                                    "before the warm-up" % (vpg, PERIOD, PERIOD, n_events_per_step)) if args.workload == "c3" else
+                                   ("churn: %d voices per GPU, default patch, 48 kHz, 1024-frame buffers, all on at frame 0, then %d note-off + %d "
+                                    "note-on per buffer per 64k voices" % (vpg, args.churn, args.churn)),
+                       "timed_call": "s2r_note_events + s2r_fill (synchronous; events H2D and the 4 KiB mix D2H inside)" if world == 1 else
+                                     "s2r_note_events + s2r_fill_device per rank, all-gather, rank-ordered sum, D2H of the mix on rank 0",
                        "voices_total": total, "frames": FRAMES, "sample_rate": SR,
-                       "parallelism": "voice-shard x%d, all-gather of partial mixes" % world,
-                       "block_voices": synth.block_voices, "lanes_per_voice": synth.lanes_per_voice},
+                       "parallelism": "voice-shard x%d, %s of partial mixes" % (world, "reduce(sum) to rank 0" if args.reduce else "all-gather + rank-ordered sum"),
+                       "block_voices": synth.block_voices},
             "msamples_per_s": value / 1e6,
             "realtime_factor_64k_voices": value / (65536.0 * SR),
             "roofline": {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": "s2r_render_kernel", "kernel_ms": kernel_ms,
-                         "note": "algorithmic bytes = %d B per voice per fill; the path is VALU-bound, see roofline_valu" % BYTES_PER_VOICE_FILL},
+                         "note": "algorithmic bytes = %d B per voice per fill; the path is VALU-issue-bound, see roofline_valu" % BYTES_PER_VOICE_FILL},
             "roofline_valu": {"bound": "valu-fp32", "achieved": valu_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": valu_tf / VALU_PEAK_TFLOPS,
                               "flops_per_voice_sample": FLOPS_PER_VOICE_SAMPLE, "kernel_ms": kernel_ms_full,
-                              "note": "launch time with the flat-envelope coefficient reuse OFF, i.e. all 250 flop-eq per voice-sample executed"},
-            "value_all_voices_modulating": total * FRAMES * n_full / dt_full if world == 1 else None,
+                              "issue_slots": valu_issue,
+                              "note": "launch time with the flat-envelope reuse and the coefficient tables OFF, i.e. all 250 flop-eq per voice-sample executed in-lane"},
+            "value_pipelined": pipelined,
+            "value_kernel_only": vpg * FRAMES / kernel_s,
             "mix_checksum": float(np.abs(mix_host).sum()),
         }
-        if sync_rate is not None:
-            out["sync_fill_value"] = sync_rate
+        if world > 1:
+            out["multi_gpu_note"] = ("the RCCL collective of this path has not been verified on hardware by its authors (no multi-GPU box "
+                                     "was available to them): tests cover it with gloo only")
         if world == 1 and not args.no_cpu_baseline:
-            threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            threads = max(1, min(threads, 64))
-            if args.cpu_buffers:
-                nb = args.cpu_buffers
-            else:
-                probe, _ = cpu_baseline(args.cpu_voices, 1, threads)
-                nb = int(max(2, min(400, 15.0 * probe / (args.cpu_voices * FRAMES))))
-            v, secs = cpu_baseline(args.cpu_voices, nb, threads)
-            out["cpu_baseline"] = {"value": v, "unit": "samples/s", "cores": threads, "kind": "port",
-                                   "sample": "%d voices x %d frames x %d buffers, default patch, same note map; "
-                                             "C restatement of s2_lib (oracle/), not rustc output; %.1f s" % (
-                                                 args.cpu_voices, FRAMES, nb, secs)}
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cores = max(1, min(cores, 64))
+            legs = cpu_baseline_legs(cores, args.cpu_seconds)
+            out["cpu_baseline"] = dict(legs[-1])                  # all cores at C3's pool size
+            out["cpu_baseline"]["sample"] += "; C restatement of s2_lib (oracle/), not rustc output"
+            out["cpu_baseline_legs"] = legs
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -20,7 +20,7 @@ SOURCES = ["s2r_render_onepole_square.hip", "s2r_render_onepole_saw.hip", "s2r_r
            "s2r_aux.hip", "s2r_host.cpp", "s2r_patch.cpp", "s2r_stream.cpp"]
 HEADERS = ["s2r_device.h", "s2r_math.h", "s2r_patch.h", "s2r_voices.h", "s2r_kern_common.h", "s2r_render_onepole.inc",
            "s2r_render_general.inc"]
-OBJ_DIR = os.path.join(HERE, "_build")
+
 # -amdgpu-sched-strategy=max-ilp: the render kernels run one wavefront per SIMD (64 k voices =
 # 1024 waves), so nothing hides a dependent instruction's latency except independent work of the
 # same wave; the default (occupancy-driven) scheduler lines the recurrences up back to back
@@ -33,10 +33,17 @@ FLAGS = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fn
          "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
-# S2R_WITH_LANE_VARIANTS=1 in the environment also builds the 2- and 4-lanes-per-voice render kernels (48 more
-# kernels, +50 % build time): bit-identical to one lane per voice and slower, kept for experiments
-if os.environ.get("S2R_WITH_LANE_VARIANTS") == "1":
-    FLAGS = FLAGS + ["-DS2R_WITH_LANE_VARIANTS"]
+# S2R_STAMPS=1 in the environment builds the DIAGNOSTIC library (its own file, libs2r_stamps.so): the one-pole render
+# kernel writes s_memtime stamps at its phase boundaries (tools/stamps.py).  Never the product build.
+if os.environ.get("S2R_STAMPS") == "1":
+    FLAGS = FLAGS + ["-DS2R_STAMPS"]
+    LIB = os.path.join(HERE, "libs2r_stamps.so")
+    OBJ_DIR_NAME = "_build_stamps"
+else:
+    OBJ_DIR_NAME = "_build"
+
+
+OBJ_DIR = os.path.join(HERE, OBJ_DIR_NAME)
 
 
 def _hipcc():

@@ -111,6 +111,8 @@ struct S2rRenderParams {
     // timed events of this fill (nullptr: none)
     const S2rTimedEvent *tev;
     int32_t *voice_ev_head;     // [padded voices] index of the voice's first timed event, -1 = none
+    // diagnostic builds only (-DS2R_STAMPS, tools/stamps.py): [waves][16] s_memtime stamps of the render kernel's phases
+    unsigned long long *stamps;
     // patch bank (bank_size > 1: s2r_render_general_kernel<ANY, true>; the fields above then hold patch 0)
     const S2rBankEntry *bank;
     uint32_t bank_size;

@@ -137,6 +137,7 @@ struct s2r_synth {
     float *tab_dev = nullptr; size_t tab_cap = 0;        // floats
     S2rTabRef tab{};
     bool tab_dirty = true; uint32_t tab_rate = 0;
+    unsigned long long *stamps_dev = nullptr;            // diagnostic builds (-DS2R_STAMPS): per-wave phase stamps of the last fill
     bool use_tab = true, use_arg_events = true;
     float pitch_table[256];
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -391,6 +392,7 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
         if (rc != S2R_OK) return rc;
     }
     if (tables_wanted(s)) p.tab = s->tab;
+    p.stamps = s->stamps_dev;
     p.per_voice = per_voice_dev;
     p.tev = tev_dev;
     p.voice_ev_head = s->voice_ev_head;
@@ -469,6 +471,7 @@ void release_all(s2r_synth *s) {
     if (s->voice_ev_head) (void)hipFree(s->voice_ev_head);
     if (s->tev_copy) (void)hipFree(s->tev_copy);
     if (s->tab_dev) (void)hipFree(s->tab_dev);
+    if (s->stamps_dev) (void)hipFree(s->stamps_dev);
     if (s->t0) (void)hipEventDestroy(s->t0);
     if (s->t1) (void)hipEventDestroy(s->t1);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -960,6 +963,29 @@ float s2r_last_render_ms(s2r_synth *s) {
 }
 
 const char *s2r_last_error(const s2r_synth *s) { return s ? s->err.c_str() : "null handle"; }
+
+// Diagnostic builds only (-DS2R_STAMPS; tools/stamps.py): copies the last fill's per-wave phase stamps ([waves][16]
+// s_memtime ticks) to `out`; returns the number of waves, 0 in a product build.  Not declared in s2r.h.
+extern "C" uint32_t s2r_debug_read_stamps(s2r_synth *s, unsigned long long *out, uint32_t max_waves) {
+#if defined(S2R_STAMPS)
+    if (!s) return 0;
+    const uint32_t waves = s->padded_voices / 64u;
+    if (hipSetDevice(s->device) != hipSuccess) return 0;
+    if (!s->stamps_dev) {
+        if (hipMalloc((void **)&s->stamps_dev, (size_t)waves * 16 * sizeof(unsigned long long)) != hipSuccess) return 0;
+        (void)hipMemset(s->stamps_dev, 0, (size_t)waves * 16 * sizeof(unsigned long long));
+        return waves;                             // armed: the next fill writes them
+    }
+    if (!out) return waves;
+    const uint32_t n = waves < max_waves ? waves : max_waves;
+    (void)hipStreamSynchronize(s->stream);
+    if (hipMemcpy(out, s->stamps_dev, (size_t)n * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
+#else
+    (void)s; (void)out; (void)max_waves;
+    return 0;
+#endif
+}
 
 // ---- host-only helpers: the voice-allocation policy without a device (tests, front-ends
 // that route events to shards) ----

@@ -370,14 +370,34 @@ struct FlatCache {
     OscK k;
 };
 
+// The two values a flat mod envelope can have are the patch's sustain level S (sustain; a decay with S == 1; a release
+// with S == 0) and +0 (after the end), so what refresh_flat() hands out is one of two per-voice constants, computed when
+// the kernel starts (and again when a timed event restarts the voice with another pitch) instead of ~100 instructions
+// per stage change of any lane of the wave.
+struct FlatConsts {
+    float xc_s, xc_0;       // filter coefficient at mod == S and at mod == +0
+    OscK k_s, k_0;          // under FM: the oscillator constants at those two values
+};
+
 template <int OSC, bool FM>
-__device__ __forceinline__ FlatCache refresh_flat(const S2rRenderParams &p, const VoiceRegs &r, const EnvRun em,
-                                                  const uint64_t *sT, FlatCache fc) {
+__device__ __forceinline__ FlatConsts make_flat_consts(const S2rRenderParams &p, float pitch, const uint64_t *sT) {
+    FlatConsts c;
+    const float f_s = s2r_pow2_sleef_core(p.mod.S * p.amt_lpf) * p.lpf_freq;         // process.rs:148-152 at mod == S
+    const float f_0 = s2r_pow2_sleef_core(0.0f * p.amt_lpf) * p.lpf_freq;
+    c.xc_s = s2r_expf(p.fast_div_sr ? lpf_arg<true>(p, f_s) : lpf_arg<false>(p, f_s), sT);
+    c.xc_0 = s2r_expf(p.fast_div_sr ? lpf_arg<true>(p, f_0) : lpf_arg<false>(p, f_0), sT);
+    c.k_s = make_osck<OSC>(p.sr / (s2r_pow2_sleef_core(p.mod.S * p.amt_osc) * pitch));  // process.rs:146-147, units.rs:32-42
+    c.k_0 = make_osck<OSC>(p.sr / (s2r_pow2_sleef_core(0.0f * p.amt_osc) * pitch));
+    return c;
+}
+
+template <int OSC, bool FM>
+__device__ __forceinline__ FlatCache refresh_flat(const FlatConsts &c, const EnvRun em, FlatCache fc) {
     if (em.slope == 0.0f) {
-        const float mod = em.y0;                                          // 0 * (t - base) + y0 == y0
-        const float f_lpf = s2r_pow2_sleef_core(mod * p.amt_lpf) * p.lpf_freq;
-        fc.xc = s2r_expf(p.fast_div_sr ? lpf_arg<true>(p, f_lpf) : lpf_arg<false>(p, f_lpf), sT);
-        if (FM) fc.k = make_osck<OSC>(p.sr / (s2r_pow2_sleef_core(mod * p.amt_osc) * r.pitch));
+        // mod = 0 * (t - base) + y0 == y0, and y0 is S or +0 (or 1.0 in a decay whose slope (S - 1) / D is zero: S)
+        const bool zero = em.y0 == 0.0f;
+        fc.xc = zero ? c.xc_0 : c.xc_s;
+        if (FM) fc.k = zero ? c.k_0 : c.k_s;
     }
     return fc;
 }
@@ -385,8 +405,8 @@ __device__ __forceinline__ FlatCache refresh_flat(const S2rRenderParams &p, cons
 // frames oi .. oi+3 of one voice
 template <int OSC, bool FM>
 __device__ __forceinline__ void closed_form_x4(const S2rRenderParams &p, const VoiceRegs &r, EnvRun &ea, EnvRun &em,
-                                               float &thr_min, FlatCache &fc, uint32_t oi, const uint64_t *sT,
-                                               FrameCF4 &cf, OscK4 &k) {
+                                               float &thr_min, FlatCache &fc, const FlatConsts &fcc, uint32_t oi,
+                                               const uint64_t *sT, FrameCF4 &cf, OscK4 &k) {
     const u4 ou = (u4)(oi) + (u4){0u, 1u, 2u, 3u};               // offsets_x16: wrapping u32 add (process.rs:213-219)
     const f4 t = __builtin_convertvector(ou, f4);                // offsets as f32 (simdtest.rs:277-279, process.rs:348)
     // fast path first: the active stages' lines for all four frames
@@ -411,7 +431,7 @@ __device__ __forceinline__ void closed_form_x4(const S2rRenderParams &p, const V
             }
             S2R_ENV_STEP(x) S2R_ENV_STEP(y) S2R_ENV_STEP(z) S2R_ENV_STEP(w)
 #undef S2R_ENV_STEP
-            fc = refresh_flat<OSC, FM>(p, r, em, sT, fc);
+            fc = refresh_flat<OSC, FM>(fcc, em, fc);
         }
     }
     cf.amp = amp;
@@ -547,6 +567,22 @@ __device__ __forceinline__ float frame_sisd(const P &p, VoiceRegs &r, uint32_t o
 }
 
 
+// minimum of a value over the wavefront, in a scalar register: four DPP row shifts, two row broadcasts (the classic
+// GFX9 reduction; ~35 cycles of issue for a lone wave where a ballot round trip costs ~50 and answers less)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#define S2R_MIN_DPP(CTRL, ROWMASK)                                                                                   \
+    { const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, CTRL, ROWMASK, 0xf, false);  \
+      v = o_ < v ? o_ : v; }
+    S2R_MIN_DPP(0x111, 0xf)      // row_shr:1
+    S2R_MIN_DPP(0x112, 0xf)      // row_shr:2
+    S2R_MIN_DPP(0x114, 0xf)      // row_shr:4
+    S2R_MIN_DPP(0x118, 0xf)      // row_shr:8   -> lane 15 of each row holds the row's minimum
+    S2R_MIN_DPP(0x142, 0xa)      // row_bcast:15 into rows 1 and 3
+    S2R_MIN_DPP(0x143, 0xc)      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's minimum
+#undef S2R_MIN_DPP
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // 16-byte load from a dword-aligned address (global_load_dwordx4 needs no more on gfx950)
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 __device__ __forceinline__ f4 load_f4u(const float *p) { return *reinterpret_cast<const f4u *>(p); }
@@ -635,9 +671,9 @@ __device__ __forceinline__ void tile_store4(int q, f4 v) {
 }
 
 // v_pk_add_f32 on a pair (the compiler splits some of the chunk's packed adds into two scalar ones)
-typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float fp2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f4 pk_add4(f4 a, f4 b) {
-    f2 lo, hi;
+    fp2 lo, hi;
     asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(a.xy), "v"(b.xy));
     asm("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(a.zw), "v"(b.zw));
     return (f4){lo.x, lo.y, hi.x, hi.y};
@@ -712,22 +748,26 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
     uint32_t o01 = pk_add_u16(o_lo | (o_lo << 16), 0x00010000u), o23 = pk_add_u16(o01, 0x00020002u);
     const uint32_t seed_pair = (r.seed_rot & 0xffffu) | (r.seed_rot << 16);
     f4 t_small = splat(t_chunk) + (f4){0.0f, 1.0f, 2.0f, 3.0f};      // exact below 2^24, as are the + 4 steps
-    // ALIGNED: H0 * 2^-16, H0 = the hash's low 16 bits at the chunk's first frame
+    // ALIGNED: H0 * 2^-16, H0 = the hash's low 16 bits at the chunk's first frame, and the next frame's
     const float h0f = (float)(((r.seed_rot ^ o_chunk) * 0x79b9u) & 0xffffu) * 0x1p-16f;
+    constexpr float kK1 = (float)0x79b9u * 0x1p-16f, kK2 = (float)((2u * 0x79b9u) & 0xffffu) * 0x1p-16f;
+    fp2 fpair = {h0f, __builtin_amdgcn_fractf(h0f + kK1)};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         f4 t;
         if (ALIGNED) {
             t = t_small;
             t_small = t_small + splat(4.0f);
-            // c_j * 2^-16 for j = 4q .. 4q + 3, c_j = (j * 0x79b9) mod 2^16
-            constexpr float kS = 0x1p-16f;
-            const f4 cj = {(float)(((4 * q) * 0x79b9u) & 0xffffu) * kS, (float)(((4 * q + 1) * 0x79b9u) & 0xffffu) * kS,
-                           (float)(((4 * q + 2) * 0x79b9u) & 0xffffu) * kS, (float)(((4 * q + 3) * 0x79b9u) & 0xffffu) * kS};
-            const f4 u = splat(h0f) + cj;
+            // f_j = h_j * 2^-16 for the quad's four frames, stepped from the previous pair: h_(j+2) = h_j + 2 * 0x79b9
+            // (mod 2^16) is f_(j+2) = fract(f_j + K2) exactly (both multiples of 2^-16 below 1).  One constant instead
+            // of a table of sixteen (which the compiler rebuilt in scalar registers on every chunk).
             f4 f;
-            f.x = __builtin_amdgcn_fractf(u.x); f.y = __builtin_amdgcn_fractf(u.y);
-            f.z = __builtin_amdgcn_fractf(u.z); f.w = __builtin_amdgcn_fractf(u.w);
+            f.x = fpair.x; f.y = fpair.y;
+            fpair = fpair + (fp2){kK2, kK2};
+            fpair.x = __builtin_amdgcn_fractf(fpair.x); fpair.y = __builtin_amdgcn_fractf(fpair.y);
+            f.z = fpair.x; f.w = fpair.y;
+            fpair = fpair + (fp2){kK2, kK2};
+            fpair.x = __builtin_amdgcn_fractf(fpair.x); fpair.y = __builtin_amdgcn_fractf(fpair.y);
             nz[q] = vfma(vfma(f, splat(0x1.0001p-16f), f), splat(2.0f), splat(-1.0f));
         } else if (SMALL) {
             // stepping (one inline constant, one scalar literal) instead of 4 q + k per quad (a scalar move per literal)

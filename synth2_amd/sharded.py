@@ -11,9 +11,17 @@ rank renders a partial mix (frames x 4 B = 4 KiB at 1024 frames), the partials a
 at +0.0 (with contiguous ranges that is the association a single GPU produces with
 ``mix_groups = world``).
 
+``reduce_to_root=True`` swaps the all-gather + ordered sum for ONE ``reduce(SUM)`` to rank 0 — the portable
+fallback SURVEY §8(e) names.  The library then chooses the association, so the result is the rank-ordered sum bit for
+bit only where the order cannot matter (two ranks: a + b == b + a); with more ranks it agrees to rounding, not to the
+bit, which is why the all-gather stays the default (tests/test_sharded_gloo.py shows both facts).
+
 The renderer and the row-combine are injectable so the exchange logic can be exercised on CPU
 with gloo (tests/test_sharded_gloo.py feeds it partial rows made by the CPU oracle); the
 defaults are the HIP path and nothing else — there is no CPU fallback here.
+
+The RCCL collective itself has only ever run under gloo in this repository's tests (no multi-GPU box was available to
+the build): the first ``backend="nccl"`` execution is the driver's N-GPU bench.
 """
 import torch
 import torch.distributed as dist
@@ -23,7 +31,7 @@ from . import synth as _synth
 
 class ShardedSynth:
     def __init__(self, voices_per_rank, max_frames=1024, rank=0, world=1, device=None, renderer=None,
-                 combine=None, block_voices=0, lanes_per_voice=0, overlap=True, interleave=64):
+                 combine=None, block_voices=0, overlap=True, interleave=64, reduce_to_root=False):
         self.rank, self.world = rank, world
         self.voices_per_rank = voices_per_rank
         self.total_voices = voices_per_rank * world
@@ -37,15 +45,19 @@ class ShardedSynth:
                   else dict(shard_begin=rank * voices_per_rank, shard_voices=voices_per_rank))
             renderer = _synth.Synth(self.total_voices, max_frames=max_frames,
                                     device=self.device.index if self.device.index is not None else -1,
-                                    block_voices=block_voices, lanes_per_voice=lanes_per_voice, **kw)
+                                    block_voices=block_voices, **kw)
         self.renderer = renderer
         self.combine = combine if combine is not None else self._combine_hip
         self.overlap = overlap and world > 1
+        self.reduce_to_root = reduce_to_root and world > 1
+        # every buffer is exchanged as whole max_frames rows (4 KiB at 1024 frames: the exchange is latency-bound), so a
+        # shorter fill needs neither a temporary nor a wait; what lies behind `frames` in a row is never read
         self.partial = [torch.zeros(max_frames, dtype=torch.float32, device=self.device) for _ in range(2)]
         self.gathered = [torch.zeros((world, max_frames), dtype=torch.float32, device=self.device) for _ in range(2)]
         self.mix = torch.zeros(max_frames, dtype=torch.float32, device=self.device)
-        self._pending = None      # (work, slot, frames) of the all-gather still in flight
+        self._pending = None      # (work, slot, frames) of the exchange still in flight
         self._k = 0
+        self._host_target = None
 
     # ---- events: identical stream on every rank ----
     def note_events(self, events):
@@ -68,19 +80,27 @@ class ShardedSynth:
         return torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else None
 
     def _combine_hip(self, rows, n_rows, frames, out):
-        _synth.sum_partials_device(rows.data_ptr(), n_rows, frames, out.data_ptr(), self._stream_ptr())
+        # rows: [n_rows][max_frames]; the kernel adds whole rows (row stride = max_frames)
+        _synth.sum_partials_device(rows.data_ptr(), n_rows, self.max_frames, out.data_ptr(), self._stream_ptr())
+
+    def copy_mix_to(self, pinned_host):
+        """every finished mix is also copied (asynchronously, behind its combine) into this pinned host tensor"""
+        self._host_target = pinned_host
 
     def _finish(self, pending):
         work, slot, frames = pending
         if work is not None:
             work.wait()                      # current stream waits for the collective
         if self.rank == 0:
-            # rows are [world][max_frames]; combine wants them packed [world][frames]
-            rows = self.gathered[slot] if frames == self.max_frames else self.gathered[slot][:, :frames].contiguous()
-            self.combine(rows, self.world, frames, self.mix)
+            if self.reduce_to_root:
+                self.mix[:frames].copy_(self.partial[slot][:frames])      # reduce(SUM) left the total in rank 0's row
+            else:
+                self.combine(self.gathered[slot], self.world, frames, self.mix)
+            if self._host_target is not None:
+                self._host_target.copy_(self.mix, non_blocking=True)
 
     def fill(self, frames, sample_rate=48000):
-        """Render one buffer.  With overlap on, the all-gather of buffer k runs on RCCL's own
+        """Render one buffer.  With overlap on, the exchange of buffer k runs on the collective's own
         stream while buffer k+1 renders; call flush() before reading ``mix``."""
         slot = self._k & 1
         self._k += 1
@@ -91,28 +111,29 @@ class ShardedSynth:
             return
         self.renderer.fill_device(part.data_ptr(), frames, sample_rate, self._stream_ptr())
         if self.world == 1:
-            self.combine(part, 1, frames, self.mix)
+            self.gathered[slot][0].copy_(part)
+            self.combine(self.gathered[slot], 1, frames, self.mix)
             return
         if self._pending is not None:
             self._finish(self._pending)
             self._pending = None
         if self.device.type == "cuda" and dist.get_backend() == "gloo":
             # rehearsal of the multi-rank flow without RCCL (ranks sharing one card): the rows go through the host
-            host = part[:frames].cpu()
-            rows = torch.empty((self.world, frames), dtype=torch.float32)
-            dist.all_gather_into_tensor(rows.view(-1), host)
-            self.gathered[slot][:, :frames] = rows.to(self.device)
+            host = part.cpu()
+            if self.reduce_to_root:
+                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+                if self.rank == 0:
+                    part.copy_(host)
+            else:
+                rows = torch.empty((self.world, self.max_frames), dtype=torch.float32)
+                dist.all_gather_into_tensor(rows.view(-1), host)
+                self.gathered[slot].copy_(rows)
             self._finish((None, slot, frames))
             return
-        if frames == self.max_frames:
-            work = dist.all_gather_into_tensor(self.gathered[slot].view(-1), part, async_op=self.overlap)
+        if self.reduce_to_root:
+            work = dist.reduce(part, dst=0, op=dist.ReduceOp.SUM, async_op=self.overlap)
         else:
-            tmp = torch.zeros((self.world, frames), dtype=torch.float32, device=self.device)
-            work = dist.all_gather_into_tensor(tmp.view(-1), part[:frames].contiguous(), async_op=self.overlap)
-            if work is not None:
-                work.wait()
-                work = None
-            self.gathered[slot][:, :frames] = tmp
+            work = dist.all_gather_into_tensor(self.gathered[slot].view(-1), part, async_op=self.overlap)
         pending = (work if self.overlap else None, slot, frames)
         if self.overlap:
             self._pending = pending

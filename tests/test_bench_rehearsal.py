@@ -27,7 +27,7 @@ def test_two_rank_bench_flow_on_one_gpu():
     env = dict(os.environ, S2R_BENCH_BACKEND="gloo", S2R_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "6", "--warmup", "2", "--voices-per-gpu", "8192"]
+           "--gpus", "2", "--steps", "6", "--warmup", "2", "--voices-per-gpu", "8192", "--workload", "churn"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
