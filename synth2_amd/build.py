@@ -33,12 +33,19 @@ FLAGS = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fn
          "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
+# S2R_OPT=O3 in the environment builds the same sources at -O3 into libs2r_o3.so (tools and tests that compare the two
+# optimisation levels; the product is -O2).
+if os.environ.get("S2R_OPT") == "O3":
+    FLAGS = [("-O3" if f == "-O2" else f) for f in FLAGS]
+    LIB = os.path.join(HERE, "libs2r_o3.so")
 # S2R_STAMPS=1 in the environment builds the DIAGNOSTIC library (its own file, libs2r_stamps.so): the one-pole render
 # kernel writes s_memtime stamps at its phase boundaries (tools/stamps.py).  Never the product build.
 if os.environ.get("S2R_STAMPS") == "1":
     FLAGS = FLAGS + ["-DS2R_STAMPS"]
     LIB = os.path.join(HERE, "libs2r_stamps.so")
     OBJ_DIR_NAME = "_build_stamps"
+elif os.environ.get("S2R_OPT") == "O3":
+    OBJ_DIR_NAME = "_build_o3"
 else:
     OBJ_DIR_NAME = "_build"
 

@@ -396,6 +396,41 @@ def _full_size(voices, buffers, churn):
     exact = pv.astype(np.float64).sum(axis=0).astype(np.float32)
     print("%d voices: tree vs the reference's sequential order %d ULP; vs the exactly rounded sum: tree %d ULP, sequential %d ULP"
           % (voices, ulp_diff(o, seq), ulp_diff(o, exact), ulp_diff(seq, exact)))
+    _record_mix_deviation(voices, o, seq, exact)
+
+
+def _record_mix_deviation(voices, tree, seq, exact):
+    """north_star asks for "within 1 ULP" of the CPU path; a 64 k-term fp32 sum cannot be within 1 ULP of ANY other
+    association of itself, so the achieved distance of the GPU's tree (== the oracle's tree, asserted bit for bit above)
+    from the reference's sequential order is put on file: gpurun_out/mix_deviation.json, copied to profiles/r02/."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "mix_deviation.json")
+    try:
+        data = json.load(open(path))
+    except Exception:
+        data = {"what": "GPU mix (documented tree, bit-equal to the oracle's tree) vs the reference's sequential voice order "
+                        "(synth.rs:177-195) and vs the correctly rounded sum of the voices; last buffer of the test, 1024 frames",
+                "rows": {}}
+    peak = float(np.max(np.abs(exact)))
+    rel = np.abs(tree.astype(np.float64) - seq.astype(np.float64)) / max(peak, 1e-30)
+    data["rows"][str(voices)] = {
+        "voices": voices,
+        "tree_vs_sequential_max_ulp": ulp_diff(tree, seq),
+        "tree_vs_exact_max_ulp": ulp_diff(tree, exact),
+        "sequential_vs_exact_max_ulp": ulp_diff(seq, exact),
+        "tree_vs_sequential_max_abs_over_peak": float(rel.max()),
+        "mix_peak": peak,
+        "note": "ULP distances are per sample and large where the mix passes near zero; the last column relates the "
+                "difference to the buffer's peak",
+    }
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    json.dump(data, open(path, "w"), indent=1)
+
+
+def test_mix_deviation_1024_voices():
+    """the same record for BASELINE config 1's pool size"""
+    _full_size(1024, 2, 8)
 
 
 def test_c3_full_size_65536_voices():
