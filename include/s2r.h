@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S2R_ABI_VERSION 2
+#define S2R_ABI_VERSION 3
 
 typedef enum {
     S2R_OK = 0,
@@ -45,7 +45,10 @@ typedef enum {
 } s2r_status;
 
 /* static_config.rs:26-32 (declaration order) */
-typedef enum { S2R_OSC_SQUARE = 0, S2R_OSC_SAW = 1, S2R_OSC_TRIANGLE = 2, S2R_OSC_SINE = 3 } s2r_osc_kind;
+typedef enum { S2R_OSC_SQUARE = 0, S2R_OSC_SAW = 1, S2R_OSC_TRIANGLE = 2, S2R_OSC_SINE = 3,
+               /* build-defined alias-suppressed shapes (the reference has only the naive ones above and links to the
+                * literature, notes.md:32,79): differentiated polynomial waveforms, DESIGN.md 4.10 gives the op sequence */
+               S2R_OSC_DPW_SAW = 4, S2R_OSC_DPW_SQUARE = 5, S2R_OSC_DPW_TRIANGLE = 6 } s2r_osc_kind;
 
 /* static_config.rs:38-44  sc::Adsr  (Ms, Ms, Unipolar<1>, Ms) */
 typedef struct { float attack_ms, decay_ms, sustain, release_ms; } s2r_adsr;
@@ -128,6 +131,7 @@ typedef struct {
     uint32_t noise_seed;           /* NoiseState.seed (always 0 in the reference, synth.rs:68) */
     float velocity;                /* stored, never used in rendering (synth.rs:18,26) */
     float filt_x1, filt_x2, filt_y1, filt_y2;   /* dsp_filters.rs:12-17,82-89 filter states */
+    float osc_z;                   /* DPW oscillators: the differentiator's memory; NaN = none yet (a fresh voice) */
 } s2r_voice_state;
 
 typedef struct s2r_synth s2r_synth;

@@ -388,6 +388,29 @@ static float basic_triangle(float period, float offset) {
     return line_fma(2.0f, half_period, offset - half_period, -1.0f);
 }
 
+/* Build-defined alias-suppressed oscillators (the reference only links to the literature, notes.md:32,79):
+ * differentiated polynomial waveforms.  s = the naive saw's sample at this phase (oscillators.rs:99-119: 1 at phase 0,
+ * falling to -1); the naive shapes are functions of s — saw s, square sign(s), triangle 2|s| - 1 (== oscillators.rs:60-80,
+ * 148-183) — and F is each one's integral over s, continuous across the phase wrap: saw s^2 / 2, square |s|, triangle
+ * s (|s| - 1).  The output is F's first difference divided by s's step per frame, -2 / period:
+ *     y[n] = (-0.5 * period) * (F(s[n]) - F(s[n-1]))
+ * every operation a separately rounded f32 one, in this order; before a voice's first frame the memory holds that
+ * frame's own F (y[0] = 0).  What the differencing buys: the shapes' discontinuities (in value for saw and square, in
+ * slope for the triangle) become ones of a higher derivative of F, so their aliases fall 6 dB per octave faster. */
+static float dpw_sample(int kind, float period, float phase, s2o_layer_state *st) {
+    float offset = phased_offset(period, phase, 0.0f);
+    float x = fmodf(offset, period);
+    float s = line_fma(-2.0f, period, x, 1.0f);
+    float F;
+    if (kind == S2O_OSC_DPW_SAW) F = 0.5f * (s * s);
+    else if (kind == S2O_OSC_DPW_SQUARE) F = fabsf(s);
+    else F = s * (fabsf(s) - 1.0f);
+    float z = st->has_z ? st->dpw_z : F;
+    float c = -0.5f * period;
+    st->has_z = 1; st->dpw_z = F;
+    return c * (F - z);
+}
+
 static float osc_sample(int kind, float period, float phase, int x16, int *panicked) {
     float offset = phased_offset(period, phase, 0.0f);
     switch (kind) {
@@ -451,7 +474,8 @@ static void sample_voice_x16(const s2o_layer_cfg *c, const plan_x16 *p, s2o_laye
     float next = accum_phase_x16(init_phase, p->periods, phase);
     float samples[16];
     for (int i = 0; i < 16; i++) {
-        float osc = osc_sample(c->osc_kind, p->periods[i], phase[i], 1, panicked);
+        float osc = c->osc_kind >= S2O_OSC_DPW_SAW ? dpw_sample(c->osc_kind, p->periods[i], phase[i], st)
+                                                   : osc_sample(c->osc_kind, p->periods[i], phase[i], 1, panicked);
         float osc_plus = osc + c->osc_gain;                                  /* :342-345  ADD */
         float off_f = (float)(offset + (uint32_t)i);                         /* :347-348 */
         float noise = s2o_hash_noise(st->seed, off_f);
@@ -478,7 +502,8 @@ static float process_layer(const s2o_layer_cfg *c, s2o_layer_state *st, float pi
     float period = hz_as_samples(osc_freq, sr);
 
     float phase = st->has_phase ? st->phase_accum : 0.0f;                    /* oscillators.rs:461 */
-    float osc = osc_sample(c->osc_kind, period, phase, 0, panicked);
+    float osc = c->osc_kind >= S2O_OSC_DPW_SAW ? dpw_sample(c->osc_kind, period, phase, st)
+                                               : osc_sample(c->osc_kind, period, phase, 0, panicked);
     st->has_phase = 1; st->phase_accum = accum_phase(phase, period);         /* oscillators.rs:469 */
     float osc_sample_ = osc * c->osc_gain;                                   /* :287  MULTIPLY */
     float noise = s2o_hash_noise(st->seed, (float)offset);                   /* :289-291 */

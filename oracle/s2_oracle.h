@@ -28,7 +28,9 @@ extern "C" {
 #endif
 
 /* static_config.rs:26-32 — enum order as declared there */
-enum { S2O_OSC_SQUARE = 0, S2O_OSC_SAW = 1, S2O_OSC_TRIANGLE = 2, S2O_OSC_SINE = 3 };
+enum { S2O_OSC_SQUARE = 0, S2O_OSC_SAW = 1, S2O_OSC_TRIANGLE = 2, S2O_OSC_SINE = 3,
+       /* build-defined alias-suppressed shapes: differentiated polynomial waveforms */
+       S2O_OSC_DPW_SAW = 4, S2O_OSC_DPW_SQUARE = 5, S2O_OSC_DPW_TRIANGLE = 6 };
 
 /* static_config.rs:38-44 */
 typedef struct { float attack_ms, decay_ms, sustain, release_ms; } s2o_adsr_cfg;
@@ -63,6 +65,8 @@ typedef struct {
     uint32_t seed;
     float lpf_last;
     float x1, x2, y1, y2;        /* dsp_filters.rs:12-17,82-89 filter states */
+    int32_t has_z;               /* DPW oscillators: the differentiator's memory F(s[n-1]) (none before the first frame) */
+    float dpw_z;
 } s2o_layer_state;
 
 /* synth.rs:23-30 */

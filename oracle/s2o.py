@@ -28,7 +28,8 @@ class LayerCfg(C.Structure):
 
 class LayerState(C.Structure):
     _fields_ = [("has_phase", C.c_int32), ("phase_accum", C.c_float), ("seed", C.c_uint32), ("lpf_last", C.c_float),
-                ("x1", C.c_float), ("x2", C.c_float), ("y1", C.c_float), ("y2", C.c_float)]
+                ("x1", C.c_float), ("x2", C.c_float), ("y1", C.c_float), ("y2", C.c_float),
+                ("has_z", C.c_int32), ("dpw_z", C.c_float)]
 
 
 class Voice(C.Structure):

@@ -157,6 +157,7 @@ __global__ void s2r_events_kernel(const S2rVoiceArrays v, const S2rVoiceEvent *e
         v.fx1[vi] = 0.0f; v.fx2[vi] = 0.0f; v.fy1[vi] = 0.0f; v.fy2[vi] = 0.0f;
         v.seed[vi] = e.seed;
         v.program[vi] = e.flags >> S2R_EV_PROGRAM_SHIFT;
+        v.osc_z[vi] = s2r_u2f(S2R_OSC_Z_NONE);
     } else if (e.flags & S2R_EV_RELEASE) {                       // synth.rs:74-75
         const uint32_t fl = v.flags[vi];
         if ((fl & S2R_VF_STARTED) && !(fl & S2R_VF_RELEASED)) {
@@ -175,7 +176,7 @@ hipError_t s2r_launch_general_osc0(const S2rRenderArgs &a, uint32_t block_voices
 hipError_t s2r_launch_general_osc1(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
 hipError_t s2r_launch_general_osc2(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
 hipError_t s2r_launch_general_osc3(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
-hipError_t s2r_launch_general_osc4(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);   // the patch bank
+hipError_t s2r_launch_general_osc15(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);   // the patch bank
 
 hipError_t s2r_launch_tables(const S2rTabBuild &b, hipStream_t stream) {
     if (b.n_entries == 0) return hipErrorInvalidValue;
@@ -187,7 +188,8 @@ hipError_t s2r_launch_render(const S2rRenderArgs &a, uint32_t block_voices, hipS
     const S2rRenderParams &p = a.p;
     if (p.n_voices == 0 || p.frames == 0) return hipSuccess;
     if (block_voices < 64 || block_voices > 1024 || (block_voices & 63u)) return hipErrorInvalidValue;
-    if (p.bank_size > 1) return s2r_launch_general_osc4(a, block_voices, stream);
+    // patch banks, and the DPW oscillator shapes (which exist in that kernel only): oscillator and filter kind per lane
+    if (p.bank_size > 1 || p.osc_kind > S2R_OSC_SINE) return s2r_launch_general_osc15(a, block_voices, stream);
     const bool general = p.lpf_kind != S2R_FILT_ONEPOLE;
     switch (p.osc_kind) {
     case S2R_OSC_SQUARE: return general ? s2r_launch_general_osc0(a, block_voices, stream) : s2r_launch_onepole_osc0(a, block_voices, stream);

@@ -37,8 +37,10 @@ struct S2rVoiceArrays {
     // dsp_filters.rs:12-17,82-89 states; only touched by patches with lpf.kind != onepole
     float *fx1, *fx2, *fy1, *fy2;
     uint32_t *program;    // index into the patch bank the voice was started with (0 without a bank)
+    float *osc_z;         // DPW oscillators: the differentiator's memory F(s[n-1]); NaN in a voice that has not rendered a frame
 };
-#define S2R_VOICE_WORDS 12
+#define S2R_VOICE_WORDS 13
+#define S2R_OSC_Z_NONE 0x7fc00000u   // the bits of that NaN
 
 // One patch of the bank, resolved for the fill's sample rate (what S2rRenderParams carries for
 // the single-patch kernels).

@@ -278,7 +278,7 @@ int check_fill(s2r_synth *s, size_t frames, uint32_t sample_rate) {
 // Coefficient tables exist for a single patch (the one-pole kernel, and the dsp_filters.rs kinds with workgroups of up
 // to 256 voices) while the flat-envelope logic is enabled.
 bool tables_wanted(const s2r_synth *s) {
-    return s->use_tab && !s->no_flat_shortcut && s->bank.size() == 1 &&
+    return s->use_tab && !s->no_flat_shortcut && s->bank.size() == 1 && s->bank[0].osc_kind <= S2R_OSC_SINE &&
            (s->bank[0].lpf_kind == S2R_FILT_ONEPOLE || s->block_voices <= 256u);
 }
 
@@ -367,7 +367,11 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
         int rc = flush_events(s, stream, &timed_slot, &tev_dev);
         if (rc != S2R_OK) return rc;
     }
-    if (s->bank.size() > 1 && (s->bank_dirty || s->bank_rate != sample_rate)) {
+    // (the kernel that renders patch banks also renders single patches with a DPW oscillator: it reads its patch from the
+    // device copy of the bank)
+    bool bank_kernel = s->bank.size() > 1;
+    for (const s2r_patch &pt : s->bank) if (pt.osc_kind > S2R_OSC_SINE) bank_kernel = true;
+    if (bank_kernel && (s->bank_dirty || s->bank_rate != sample_rate)) {
         // resolve every patch for this sample rate (Ms::as_samples, units.rs:44-53) and replace the
         // device copy; rare (bank edits, rate changes), so a synchronous hand-over is fine
         std::vector<S2rBankEntry> host(s->bank.size());
@@ -575,6 +579,7 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
     s->v.fy1 = (float *)(base + 9 * pv);
     s->v.fy2 = (float *)(base + 10 * pv);
     s->v.program = base + 11 * pv;
+    s->v.osc_z = (float *)(base + 12 * pv);
     CREATE_HIP(hipMalloc((void **)&s->bank_dev, S2R_MAX_BANK * sizeof(S2rBankEntry)));
     CREATE_HIP(hipMalloc((void **)&s->block_partials, (size_t)s->n_blocks * cfg->max_frames * sizeof(float)));
     CREATE_HIP(hipMalloc((void **)&s->out_dev, (size_t)2 * cfg->max_frames * sizeof(float)));
@@ -878,6 +883,7 @@ int s2r_export_state(s2r_synth *s, s2r_voice_state *voices) {
         o.filt_x1 = s2r_u2f(h[7 * pv + i]); o.filt_x2 = s2r_u2f(h[8 * pv + i]);
         o.filt_y1 = s2r_u2f(h[9 * pv + i]); o.filt_y2 = s2r_u2f(h[10 * pv + i]);
         o.program = (uint8_t)h[11 * pv + i];
+        o.osc_z = s2r_u2f(h[12 * pv + i]);
         o.velocity = hv.velocity;
     }
     return S2R_OK;
@@ -904,6 +910,7 @@ int s2r_import_state(s2r_synth *s, const s2r_voice_state *voices) {
         h[7 * pv + i] = s2r_f2u(in.filt_x1); h[8 * pv + i] = s2r_f2u(in.filt_x2);
         h[9 * pv + i] = s2r_f2u(in.filt_y1); h[10 * pv + i] = s2r_f2u(in.filt_y2);
         h[11 * pv + i] = in.program;
+        h[12 * pv + i] = s2r_f2u(in.osc_z);
         s->pool->set_voice(to_pool(s, i), in.note, in.started != 0, in.released != 0,
                            in.current_frame_offset, in.release_frame_offset, in.velocity);
     }

@@ -262,7 +262,7 @@ __device__ __forceinline__ float osc_value(const OscK &k, float off, const float
 }
 
 // OSC == S2R_OSC_ANY: the oscillator kind is a per-lane run-time value (patch banks)
-constexpr int S2R_OSC_ANY = 4;
+constexpr int S2R_OSC_ANY = 15;      // (above every s2r_osc_kind)
 
 template <int OSC>
 __device__ __forceinline__ OscK make_osck_any(int kind, float period) {
@@ -284,6 +284,22 @@ __device__ __forceinline__ float osc_value_any(int kind, const OscK &k, float of
     if (kind == S2R_OSC_SQUARE) return osc_value<S2R_OSC_SQUARE>(k, off, sSin);
     if (kind == S2R_OSC_TRIANGLE) return osc_value<S2R_OSC_TRIANGLE>(k, off, sSin);
     return osc_value<S2R_OSC_SINE>(k, off, sSin);
+}
+
+// Build-defined alias-suppressed oscillators (s2r_osc_kind DPW_*; the oracle's dpw_sample): s is the
+// naive saw's sample at this phase, F the integral over s of the shape (saw s^2 / 2, square |s|, triangle s (|s| - 1)),
+// the output F's first difference over s's step per frame: (-0.5 * period) * (F - z).  Separately rounded f32 ops.
+__device__ __forceinline__ float dpw_value(int kind, const OscK &k, float off, float &z) {
+    float x = off;
+    const bool slow = !(s2r_f2u(off) < s2r_f2u(k.period) && k.period > 0.0f);
+    if (__builtin_expect(__ballot(slow) != 0ull, 0)) { if (slow) x = ::fmodf(off, k.period); }
+    const float s = __builtin_fmaf(-2.0f * k.inv_period, x, 1.0f);       // (-2 / period) * x + 1, oscillators.rs:107-112
+    const float a = __builtin_fabsf(s);
+    const float F = kind == S2R_OSC_DPW_SAW ? 0.5f * (s * s) : kind == S2R_OSC_DPW_SQUARE ? a : s * (a - 1.0f);
+    // (a voice's first DPW frame — its memory still the NaN that a restart leaves — differences against its own F)
+    const float y = (-0.5f * k.period) * (F - (z != z ? F : z));
+    z = F;
+    return y;
 }
 
 // filters.rs:20-21: x = exp(-2 pi f / sr)
@@ -545,7 +561,7 @@ __device__ __forceinline__ float dsp_filter_step(int kind, float damping, float 
 // filter is one of dsp_filters.rs (state in *f2) instead of the one-pole of filters.rs.
 template <int OSC, bool DSPF = false, class P = S2rRenderParams>
 __device__ __forceinline__ float frame_sisd(const P &p, VoiceRegs &r, uint32_t oi,
-                            const uint64_t *sT, const float *sSin, Filt2 *f2 = nullptr) {
+                            const uint64_t *sT, const float *sSin, Filt2 *f2 = nullptr, float *osc_z = nullptr) {
     const float t = (float)oi;
     const float rel = r.released ? (float)r.release_u : 4294967296.0f;   // envelopes.rs:35
     const float amp = adsr_scalar(p.amp, t, rel);
@@ -555,7 +571,9 @@ __device__ __forceinline__ float frame_sisd(const P &p, VoiceRegs &r, uint32_t o
     const OscK k = make_osck_any<OSC>(p.osc_kind, p.sr / f_osc);
     const float ph = r.phase;
     const float off = __builtin_fmaf(k.period, ph, 0.0f);                // oscillators.rs:212
-    const float osc = osc_value_any<OSC>(p.osc_kind, k, off, sSin);
+    float osc;
+    if (OSC == S2R_OSC_ANY && osc_z != nullptr && p.osc_kind >= S2R_OSC_DPW_SAW) osc = dpw_value(p.osc_kind, k, off, *osc_z);
+    else osc = osc_value_any<OSC>(p.osc_kind, k, off, sSin);
     r.phase = s2r_fmod1(ph + k.inv_period);                              // oscillators.rs:377-381
     const float osc_s = osc * p.osc_gain;                                // process.rs:287 (MULTIPLY)
     const float noise_s = (hash_noise(r.seed_rot, t)) * p.noise_level;   // process.rs:292 (MULTIPLY)
@@ -640,6 +658,7 @@ __device__ __forceinline__ void apply_arg_events(const S2rRenderArgs &a, uint32_
         p.v.fx1[vi] = 0.0f; p.v.fx2[vi] = 0.0f; p.v.fy1[vi] = 0.0f; p.v.fy2[vi] = 0.0f;
         p.v.seed[vi] = 0u;                                       // this path carries no seed overrides
         p.v.program[vi] = my_flags >> S2R_EV_PROGRAM_SHIFT;
+        p.v.osc_z[vi] = s2r_u2f(S2R_OSC_Z_NONE);
     } else if (my_flags & S2R_EV_RELEASE) {
         const uint32_t fl = p.v.flags[vi];
         if ((fl & S2R_VF_STARTED) && !(fl & S2R_VF_RELEASED)) {

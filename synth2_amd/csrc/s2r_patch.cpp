@@ -8,7 +8,7 @@
 //           | amp_env.attack | amp_env.decay | amp_env.sustain | amp_env.release
 //           | mod_env.attack | mod_env.decay | mod_env.sustain | mod_env.release
 //           | mod_env_to_osc_freq | mod_env_to_lpf_freq
-//   VALUE  := number | square | saw | triangle | sine        (kind names only for osc.kind)
+//   VALUE  := number | square | saw | triangle | sine | dpw_saw | dpw_square | dpw_triangle   (kind names only for osc.kind)
 //           | onepole | lp1 | hp1 | lp2 | hp2 | bp2 | svf_lp | svf_bp | svf_hp   (only for lpf.kind)
 //
 // Units follow static_config.rs: *.attack/decay/release in ms (Ms), lpf.freq in Hz,
@@ -77,7 +77,7 @@ int fail(std::string *err, int code, const std::string &msg) { if (err) *err = m
 }  // namespace
 
 int s2r_validate_patch(const s2r_patch *p, std::string *err) {
-    if (p->osc_kind < S2R_OSC_SQUARE || p->osc_kind > S2R_OSC_SINE) return fail(err, S2R_ERR_PATCH_RANGE, "osc.kind out of range");
+    if (p->osc_kind < S2R_OSC_SQUARE || p->osc_kind > S2R_OSC_DPW_TRIANGLE) return fail(err, S2R_ERR_PATCH_RANGE, "osc.kind out of range");
     if (!in_range(p->osc_gain, 0.0f, 1.0f)) return fail(err, S2R_ERR_PATCH_RANGE, "osc.gain outside Unipolar<1> [0,1]");
     if (!in_range(p->noise, 0.0f, 1.0f)) return fail(err, S2R_ERR_PATCH_RANGE, "noise outside Unipolar<1> [0,1]");
     if (!std::isfinite(p->lpf_freq) || p->lpf_freq < 0.0f) return fail(err, S2R_ERR_PATCH_RANGE, "lpf.freq must be a finite, non-negative Hz value");
@@ -120,6 +120,9 @@ int s2r_parse_patch(const char *text, size_t len, s2r_patch *out, std::string *n
                 else if (kind == "saw") p.osc_kind = S2R_OSC_SAW;
                 else if (kind == "triangle") p.osc_kind = S2R_OSC_TRIANGLE;
                 else if (kind == "sine") p.osc_kind = S2R_OSC_SINE;
+                else if (kind == "dpw_saw") p.osc_kind = S2R_OSC_DPW_SAW;
+                else if (kind == "dpw_square") p.osc_kind = S2R_OSC_DPW_SQUARE;
+                else if (kind == "dpw_triangle") p.osc_kind = S2R_OSC_DPW_TRIANGLE;
                 else return fail(err, S2R_ERR_PATCH_SYNTAX, at("unknown oscillator kind " + kind));
             } else if (lx.number(&num)) {
                 p.osc_kind = (int32_t)num;

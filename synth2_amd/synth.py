@@ -22,6 +22,7 @@ import numpy as np
 from . import build as _build
 
 OSC_SQUARE, OSC_SAW, OSC_TRIANGLE, OSC_SINE = 0, 1, 2, 3
+OSC_DPW_SAW, OSC_DPW_SQUARE, OSC_DPW_TRIANGLE = 4, 5, 6      # build-defined alias-suppressed shapes
 
 S2R_OK = 0
 S2R_ERR_INVALID = -1
@@ -70,14 +71,16 @@ class VoiceState(C.Structure):
                 ("current_frame_offset", C.c_uint32), ("release_frame_offset", C.c_uint32),
                 ("pitch_hz", C.c_float), ("phase_accum", C.c_float), ("lpf_last", C.c_float),
                 ("noise_seed", C.c_uint32), ("velocity", C.c_float),
-                ("filt_x1", C.c_float), ("filt_x2", C.c_float), ("filt_y1", C.c_float), ("filt_y2", C.c_float)]
+                ("filt_x1", C.c_float), ("filt_x2", C.c_float), ("filt_y1", C.c_float), ("filt_y2", C.c_float),
+                ("osc_z", C.c_float)]
 
 
 VOICE_STATE_DTYPE = np.dtype([("note", np.uint8), ("started", np.uint8), ("released", np.uint8), ("program", np.uint8),
                               ("current_frame_offset", np.uint32), ("release_frame_offset", np.uint32),
                               ("pitch_hz", np.float32), ("phase_accum", np.float32), ("lpf_last", np.float32),
                               ("noise_seed", np.uint32), ("velocity", np.float32),
-                              ("filt_x1", np.float32), ("filt_x2", np.float32), ("filt_y1", np.float32), ("filt_y2", np.float32)])
+                              ("filt_x1", np.float32), ("filt_x2", np.float32), ("filt_y1", np.float32), ("filt_y2", np.float32),
+                              ("osc_z", np.float32)])
 assert VOICE_STATE_DTYPE.itemsize == C.sizeof(VoiceState)
 NOTE_EVENT_DTYPE = np.dtype([("kind", np.uint8), ("note", np.uint8), ("frame", np.uint16), ("velocity", np.float32)])
 assert NOTE_EVENT_DTYPE.itemsize == 8

@@ -19,7 +19,7 @@ def random_patch(rng):
     def ms():
         r = rng.rand()
         return 0.0 if r < 0.15 else float(rng.choice([0.5, 3.0, 20.0, 100.0, 250.0])) * float(rng.uniform(0.5, 1.5))
-    p = make_patch(osc_kind=int(rng.randint(0, 4)), osc_gain=float(rng.choice([0.0, 0.3, 1.0])),
+    p = make_patch(osc_kind=int(rng.choice([0, 1, 2, 3, 0, 1, 2, 3, 4, 5, 6])), osc_gain=float(rng.choice([0.0, 0.3, 1.0])),
                    noise=float(rng.choice([0.0, 0.0, 0.2, 1.0])),
                    lpf_freq=float(np.exp(rng.uniform(np.log(20.0), np.log(20000.0)))),
                    mod_env_to_osc_freq=float(rng.choice([0.0, 0.0, 0.0, 1.5, -3.0, 10.0])),
@@ -55,7 +55,8 @@ def test_fuzz(seed):
     pr.gpu.set_coeff_stream(int(rng.choice([1, 3, 3, 4, 0])))
     sr = int(rng.choice([48000, 48000, 44100, 96000, 22050, 12345, 8000, 192000, 384000]))
     held = []
-    what = "seed %d: %d voices, block %d, lanes %d, groups %d, %d patches, sr %d" % (seed, voices, block, lanes, groups, len(bank), sr)
+    what = "seed %d: %d voices, block %d, lanes %d, groups %d, %d patches (osc/filter %s), sr %d" % (
+        seed, voices, block, lanes, groups, len(bank), " ".join("%d/%d" % (q.osc_kind, q.lpf_kind) for q in bank), sr)
     rng_age = np.random.RandomState(int(os.environ.get("S2R_FUZZ_BASE", "1000")) * 31 + 7 + seed)   # its own stream: the cases above stay what they were
     for b in range(7):
         if b and rng.rand() < 0.15:                      # checkpoint round trip between two buffers
@@ -75,6 +76,7 @@ def test_fuzz(seed):
         if b and len(bank) == 1 and rng.rand() < 0.15:   # the patch is swapped under sounding voices
             bank = [random_patch(rng)]
             pr.gpu.set_patch(bank[0]); pr.cpu.config = oracle_cfg_from_patch(bank[0])
+            what += " -> %d/%d at buffer %d" % (bank[0].osc_kind, bank[0].lpf_kind, b)
         frames = int(rng.choice([1024, 1024, 1000, 512, 256, 100, 17, 16, max_frames, 1]))
         timed = len(bank) >= 1 and rng.rand() < 0.35 and frames >= 32
         n_ev = int(rng.randint(0, 30)) if b else int(rng.randint(voices // 2, voices + 5))

@@ -1034,3 +1034,81 @@ def test_timed_events_with_the_coefficient_stream(patch_kw):
             pv[:, c:c + n] = pr.cpu.render_voices(n, threads=8)
         assert k == n_ev
         assert_bits_equal(g, s2o.mix_tree(pv, pr.block_voices, 1), "timed events + stream, %s, buffer %d" % (patch_kw, b))
+
+
+# ---------------------------------------------------------------------------------------------
+# alias-suppressed (DPW) oscillators — build-defined, self-oracle (BASELINE config [4])
+# ---------------------------------------------------------------------------------------------
+DPW_KINDS = [s2.OSC_DPW_SAW, s2.OSC_DPW_SQUARE, s2.OSC_DPW_TRIANGLE]
+
+
+@pytest.mark.parametrize("osc", DPW_KINDS)
+@pytest.mark.parametrize("filt,fm", [(s2.FILT_ONEPOLE, 0.0), (s2.FILT_SVF_LP, 0.0), (s2.FILT_LP2, 2.5), (s2.FILT_ONEPOLE, -1.5)])
+def test_dpw_oscillators_per_voice(osc, filt, fm):
+    patch = make_patch(osc_kind=osc, lpf_kind=filt, lpf_freq=3000.0, lpf_q=2.0, mod_env_to_osc_freq=fm, noise=0.0, osc_gain=0.0)
+    pr = Pair(96, patch, max_frames=1024)
+    for v in range(80):
+        pr.note_on(30 + (v * 5) % 90)
+    for k, frames in enumerate((1024, 1000, 16, 1024)):          # a ragged fill: the scalar tail carries the state too
+        g, o = pr.render_voices(frames)
+        assert_bits_equal(g, o, "dpw osc %d filt %d fm %g, fill %d" % (osc, filt, fm, k))
+        if k == 1:
+            for n in range(30, 120, 7):
+                pr.note_off(n)
+            pr.note_on(64); pr.note_on(65)                       # restarts: the differentiator's memory starts over
+    g, want, _ = pr.sample(512)
+    assert_bits_equal(g, want, "mix")
+
+
+def test_dpw_with_timed_events_and_checkpoint():
+    patch = make_patch(osc_kind=s2.OSC_DPW_SAW, lpf_kind=s2.FILT_SVF_LP, lpf_freq=5000.0, lpf_q=1.5)
+    pr = Pair(40, patch, max_frames=1024)
+    rng = np.random.RandomState(11)
+    for b in range(4):
+        n_ev = 12
+        times = np.sort(rng.randint(0, 64, n_ev)) * 16
+        ev = np.zeros(n_ev, dtype=s2.NOTE_EVENT_DTYPE)
+        ev["kind"] = rng.randint(0, 2, n_ev) | (b == 0); ev["note"] = rng.randint(50, 70, n_ev); ev["frame"] = times; ev["velocity"] = 1.0
+        pr.gpu.note_events(ev)
+        g = pr.gpu.sample(np.empty(1024, dtype=np.float32))
+        pv = np.zeros((40, 1024), dtype=np.float32)
+        k = 0
+        for c in range(0, 1024, 16):
+            while k < n_ev and ev["frame"][k] == c:
+                (pr.cpu.note_on if ev["kind"][k] else pr.cpu.note_off)(int(ev["note"][k])); k += 1
+            pv[:, c:c + 16] = pr.cpu.render_voices(16, SR)
+        assert_bits_equal(g, s2o.mix_tree(pv, pr.block_voices, 1), "buffer %d" % b)
+        if b == 1:                                               # checkpoint round trip keeps the memory (osc_z)
+            st = pr.gpu.export_state()
+            pr.gpu.import_state(st)
+
+
+def test_config4_share_32768_voices_4x_oversampled_dpw_svf():
+    """BASELINE config [4]'s per-GPU share at full size: 262 144 voices / 8 GPUs = 32 768 voices, alias-suppressed
+    oscillator + SVF, 4x oversampled (rendered at 192 kHz, decimated to 48 kHz).  The oracle is too slow for the pool, so:
+    (a) a 1 024-voice window of per-voice rows at the 4x rate bit for bit against the oracle, (b) the 4x-rate mix equals
+    the documented tree over the GPU's own rows, (c) the decimated output equals the oracle's decimator applied to that
+    mix (the summation order and the decimator are size-independent)."""
+    voices, frames_out = 32768, 256
+    patch = make_patch(osc_kind=s2.OSC_DPW_SAW, lpf_kind=s2.FILT_SVF_LP, lpf_freq=4000.0, lpf_q=1.2, mod_env_to_lpf_freq=2.0)
+    a = s2.Synth(voices, max_frames=4 * frames_out)
+    b = s2.Synth(voices, max_frames=4 * frames_out)
+    c = s2.Synth(voices, max_frames=4 * frames_out)
+    ev = np.zeros(voices, dtype=s2.NOTE_EVENT_DTYPE)
+    ev["kind"] = 1; ev["note"] = (np.arange(voices) * 13) % 90 + 24; ev["velocity"] = 1.0
+    for s in (a, b, c):
+        s.set_patch(patch); s.note_events(ev)
+    ora = s2o.OracleSynth(1024)
+    ora.config = __import__("helpers").oracle_cfg_from_patch(patch)
+    for i in range(1024):
+        ora.note_on(int(ev["note"][i]))
+    hist = np.zeros(62, dtype=np.float32)
+    for k in range(2):
+        mix4 = a.sample(np.empty(4 * frames_out, dtype=np.float32), 4 * SR)
+        pv = b.render_voices(4 * frames_out, 4 * SR)
+        assert_bits_equal(pv[:1024], ora.render_voices(4 * frames_out, 4 * SR, threads=8), "first 1024 voices at 192 kHz, buffer %d" % k)
+        assert_bits_equal(mix4, s2o.mix_tree(pv, a.block_voices, 1), "4x-rate mix vs tree over GPU rows, buffer %d" % k)
+        out = c.sample_oversampled(frames_out, SR)
+        x = np.concatenate([hist, mix4])
+        assert_bits_equal(out, s2o.decimate4(x, frames_out), "decimated output, buffer %d" % k)
+        hist = x[-62:]

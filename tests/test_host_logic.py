@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_loads_and_exports_every_declared_symbol():
     L = s2.load_library()
-    assert L.s2r_abi_version() == 2
+    assert L.s2r_abi_version() == 3
     hdr = open(os.path.join(ROOT, "include", "s2r.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     names = sorted(set(re.findall(r"\b(s2r_[a-z0-9_]+)\s*\(", hdr)))
