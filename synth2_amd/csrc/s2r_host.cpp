@@ -117,6 +117,7 @@ struct s2r_synth {
     // timed events (take effect inside the next fill at a 16-frame boundary)
     std::vector<S2rTimedEvent> tpending;
     std::vector<int32_t> tlast;                  // shard-local voice -> its last timed event this fill, -1
+    std::vector<int32_t> tfirst;                 // scratch of flush_events: shard-local voice -> its first timed event, -1
     uint32_t fill_time = 0;                      // frames of the next fill the pool clock has already moved
     uint32_t tev_capacity = 0;
     int32_t *voice_ev_head = nullptr;
@@ -204,6 +205,26 @@ int flush_events(s2r_synth *s, hipStream_t stream, EventSlot **timed_slot, const
     EventSlot &sl = s->slots[s->next_slot];
     s->next_slot = (s->next_slot + 1) % kEventSlots;
     if (sl.in_flight) { S2R_HIP(s, hipEventSynchronize(sl.done)); sl.in_flight = false; }
+    if (!s->pending.empty() && !s->tpending.empty()) {
+        // The fill has timed events anyway (the render kernel will walk per-voice event chains): the events of its first
+        // frame join them as frame-0 records at the head of their voice's chain — one launch (the chain heads) instead
+        // of two.  A folded record is "restart, then maybe release" or "release" (push_event), which is what one timed
+        // record expresses too.
+        std::vector<int32_t> &first = s->tfirst;
+        for (size_t i = 0; i < s->tpending.size(); i++)
+            if (s->tpending[i].flags & S2R_TEV_FIRST) first[s->tpending[i].voice] = (int32_t)i;
+        for (const S2rVoiceEvent &e : s->pending) {
+            S2rTimedEvent te{};
+            te.voice = e.voice; te.frame = 0; te.flags = (e.flags & (S2R_EV_RESTART | S2R_EV_RELEASE)) | S2R_TEV_FIRST;
+            te.pitch = e.pitch; te.seed = e.seed; te.program = e.flags >> S2R_EV_PROGRAM_SHIFT;
+            te.next = first[e.voice];
+            if (te.next >= 0) s->tpending[(size_t)te.next].flags &= ~S2R_TEV_FIRST;
+            s->tpending.push_back(te);
+        }
+        for (const S2rTimedEvent &e : s->tpending) first[e.voice] = -1;
+        for (const S2rVoiceEvent &e : s->pending) s->pending_slot[e.voice] = -1;
+        s->pending.clear();
+    }
     const uint32_t n = (uint32_t)s->pending.size();
     if (n) {
         std::memcpy(sl.host, s->pending.data(), n * sizeof(S2rVoiceEvent));
@@ -587,6 +608,7 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
     CREATE_HIP(hipHostGetDevicePointer((void **)&s->out_host_dev, s->out_host, 0));
     s->tev_capacity = shard_voices < 4096u ? 4096u : shard_voices;
     s->tlast.assign(shard_voices, -1);
+    s->tfirst.assign(shard_voices, -1);
     for (EventSlot &sl : s->slots) {
         CREATE_HIP(hipHostMalloc((void **)&sl.host, (size_t)shard_voices * sizeof(S2rVoiceEvent), hipHostMallocMapped));
         CREATE_HIP(hipHostGetDevicePointer((void **)&sl.dev, sl.host, 0));

@@ -108,6 +108,8 @@ class ShardedSynth:
         if self.world == 1 and hasattr(self.renderer, "fill_device_root") and self.combine == self._combine_hip:
             # one shard: its mix kernel roots the sum itself ((+0.0) + total), no combine pass
             self.renderer.fill_device_root(self.mix.data_ptr(), frames, sample_rate, self._stream_ptr())
+            if self._host_target is not None:
+                self._host_target.copy_(self.mix, non_blocking=True)
             return
         self.renderer.fill_device(part.data_ptr(), frames, sample_rate, self._stream_ptr())
         if self.world == 1:
