@@ -6,9 +6,11 @@
 A *step* is one 1024-frame buffer of the whole voice pool: the buffer's note events are handed over
 (`s2r_note_events`), the fill renders every voice's 1024 frames (oscillator -> envelopes -> LPF) and mixes them down, and
 the 4 KiB mix is copied to (pinned) host memory — every buffer, inside the timed region, like the events' H2D.  The steps
-are queued back to back (`s2r_fill_device_root` + an asynchronous D2H; one fence before and one after the K steps, as the
-bench contract prescribes); the strictly synchronous host API (`s2r_fill`: the caller's thread waits for every buffer,
-SURVEY §8(d)'s wording) is timed on the same workload and printed as `value_host_api_sync`.
+run through the host-buffer API with TWO buffers in flight (`s2r_fill_begin` / `s2r_fill_end`: buffer k is queued, then
+buffer k - 1 is waited for and copied into the caller's memory — the arrangement s2_bin itself uses between its synth and
+audio threads, audio_player.rs:56-60), one fence before and one after the K steps as the bench contract prescribes; the
+strictly one-at-a-time form (`s2r_fill`: the caller waits for every buffer before it hands over the next events) is timed
+on the same workload and printed as `value_host_api_sync`.
 
 Workload `c3` (default; config.workload names it): SURVEY §8(d)'s C3 — 65 536 voices per GPU, the reference's own patch
 (`example.synth2`, empty body == Synth::default_config: saw + amp/mod ADSR + the one-pole LPF; the reference has no
@@ -248,11 +250,25 @@ def main():
     if rank == 0:
         sh.copy_mix_to(pinned)                    # every finished mix is copied to host memory behind its combine (async D2H)
 
+    in_flight = [0]
+
     def step(k):
         sh.note_events(events_of(k))
-        sh.fill(FRAMES, SR)
+        if world == 1:
+            # the host-buffer API with two buffers in flight, as s2_bin keeps them (audio_player.rs:56-60): buffer k is
+            # queued, then buffer k - 1 is waited for and copied into the caller's memory
+            synth.sample_begin(FRAMES, SR)
+            in_flight[0] += 1
+            if in_flight[0] == 2:
+                synth.sample_end(out_host)
+                in_flight[0] -= 1
+        else:
+            sh.fill(FRAMES, SR)
 
     def fence():
+        while in_flight[0]:
+            synth.sample_end(out_host)
+            in_flight[0] -= 1
         sh.flush()
         if world > 1:
             dist.barrier()
@@ -278,7 +294,7 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
-    mix_host = pinned.numpy().copy() if rank == 0 else None
+    mix_host = (out_host.copy() if world == 1 else pinned.numpy().copy()) if rank == 0 else None
 
     # ---- the same steps through the synchronous host API (N = 1): s2r_fill returns each buffer in host memory ----
     host_api_sync = None
@@ -356,7 +372,7 @@ def main():
                                     "before the warm-up" % (vpg, PERIOD, PERIOD, n_events_per_step)) if args.workload == "c3" else
                                    ("churn: %d voices per GPU, default patch, 48 kHz, 1024-frame buffers, all on at frame 0, then %d note-off + %d "
                                     "note-on per buffer per 64k voices" % (vpg, args.churn, args.churn)),
-                       "timed_call": "s2r_note_events + s2r_fill_device_root + async D2H of the 4 KiB mix, queued back to back (voice state resident in HBM; events H2D inside)" if world == 1 else
+                       "timed_call": "s2r_note_events + s2r_fill_begin / s2r_fill_end: the host-buffer API with two buffers in flight (s2_bin's own arrangement); voice state resident in HBM, events H2D and every mix's D2H into the caller's buffer inside the timed region" if world == 1 else
                                      "s2r_note_events + s2r_fill_device per rank, all-gather, rank-ordered sum, async D2H of the mix on rank 0",
                        "voices_total": total, "frames": FRAMES, "sample_rate": SR,
                        "parallelism": "voice-shard x%d, %s of partial mixes" % (world, "reduce(sum) to rank 0" if args.reduce else "all-gather + rank-ordered sum"),

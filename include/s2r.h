@@ -186,6 +186,14 @@ int s2r_note_events(s2r_synth *s, const s2r_note_event *events, size_t n);
  * (synth.rs:158, process.rs:25-48).  Output = the mix of this handle's shard, root-added to
  * +0.0 (synth.rs:176). */
 int s2r_fill(s2r_synth *s, float *mono_out, size_t frames, uint32_t sample_rate_hz);
+/* s2r_fill in two halves, for a caller that keeps TWO buffers in flight the way s2_bin does (its synth thread fills one
+ * buffer while the audio thread plays the other: audio_player.rs:56-60 pre-sends two, main.rs:135-149 refills whichever
+ * comes back).  s2r_fill_begin applies the events handed over so far and queues the fill; s2r_fill_end waits for the
+ * OLDEST fill begun and not yet ended and copies its `frames` samples to mono_out.  At most two fills may be in flight;
+ * between a begin and its end the caller may hand over the next buffer's events and begin that fill.  s2r_fill is
+ * begin + end. */
+int s2r_fill_begin(s2r_synth *s, size_t frames, uint32_t sample_rate_hz);
+int s2r_fill_end(s2r_synth *s, float *mono_out);
 /* The audio callback's mono -> every channel copy (s2_bin/src/audio_player.rs:224-228),
  * done on device: interleaved L,R with L == R. */
 int s2r_fill_stereo(s2r_synth *s, float *interleaved_lr_out, size_t frames, uint32_t sample_rate_hz);

@@ -130,6 +130,11 @@ struct s2r_synth {
     float *out_dev = nullptr;
     float *out_host = nullptr;                   // pinned and device-mapped, 2*max_frames
     float *out_host_dev = nullptr;               // the device's view of out_host
+    // s2r_fill_begin / s2r_fill_end: two more mapped output buffers, the fills in flight (oldest first)
+    float *ring_host[2] = {nullptr, nullptr}, *ring_dev[2] = {nullptr, nullptr};
+    hipEvent_t ring_done[2] = {nullptr, nullptr};
+    size_t ring_frames[2] = {0, 0};
+    uint32_t ring_head = 0, ring_count = 0;
     float *os_buf = nullptr, *os_taps = nullptr; // 4x oversampling: [62 history + max_frames] mix at 4x rate, 63 taps
     float *sin_dev = nullptr;
     float *per_voice_dev = nullptr; size_t per_voice_cap = 0;
@@ -491,6 +496,10 @@ void release_all(s2r_synth *s) {
     if (s->block_partials) (void)hipFree(s->block_partials);
     if (s->out_dev) (void)hipFree(s->out_dev);
     if (s->out_host) (void)hipHostFree(s->out_host);
+    for (int k = 0; k < 2; k++) {
+        if (s->ring_host[k]) (void)hipHostFree(s->ring_host[k]);
+        if (s->ring_done[k]) (void)hipEventDestroy(s->ring_done[k]);
+    }
     if (s->sin_dev) (void)hipFree(s->sin_dev);
     if (s->per_voice_dev) (void)hipFree(s->per_voice_dev);
     if (s->voice_ev_head) (void)hipFree(s->voice_ev_head);
@@ -606,6 +615,11 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
     CREATE_HIP(hipMalloc((void **)&s->out_dev, (size_t)2 * cfg->max_frames * sizeof(float)));
     CREATE_HIP(hipHostMalloc((void **)&s->out_host, (size_t)2 * cfg->max_frames * sizeof(float), hipHostMallocMapped));
     CREATE_HIP(hipHostGetDevicePointer((void **)&s->out_host_dev, s->out_host, 0));
+    for (int k = 0; k < 2; k++) {
+        CREATE_HIP(hipHostMalloc((void **)&s->ring_host[k], (size_t)cfg->max_frames * sizeof(float), hipHostMallocMapped));
+        CREATE_HIP(hipHostGetDevicePointer((void **)&s->ring_dev[k], s->ring_host[k], 0));
+        CREATE_HIP(hipEventCreateWithFlags(&s->ring_done[k], hipEventDisableTiming));
+    }
     s->tev_capacity = shard_voices < 4096u ? 4096u : shard_voices;
     s->tlast.assign(shard_voices, -1);
     s->tfirst.assign(shard_voices, -1);
@@ -793,6 +807,35 @@ int s2r_note_events(s2r_synth *s, const s2r_note_event *events, size_t n) {
 
 int s2r_fill(s2r_synth *s, float *mono_out, size_t frames, uint32_t sample_rate_hz) {
     return fill_host(s, mono_out, frames, sample_rate_hz, false);
+}
+
+int s2r_fill_begin(s2r_synth *s, size_t frames, uint32_t sample_rate_hz) {
+    int rc = check_fill(s, frames, sample_rate_hz);
+    if (rc != S2R_OK) return rc;
+    if (s->ring_count >= 2) return set_err(s, S2R_ERR_INVALID, "two fills are already in flight: s2r_fill_end first");
+    S2R_HIP(s, hipSetDevice(s->device));
+    const uint32_t slot = (s->ring_head + s->ring_count) & 1u;
+    if (frames) {
+        // the last kernel of the fill writes the mix straight into this slot's mapped host buffer
+        rc = enqueue_fill(s, frames, sample_rate_hz, s->stream, s->ring_dev[slot], true, false, nullptr);
+        if (rc != S2R_OK) return rc;
+    }
+    S2R_HIP(s, hipEventRecord(s->ring_done[slot], s->stream));
+    s->ring_frames[slot] = frames;
+    s->ring_count++;
+    return S2R_OK;
+}
+
+int s2r_fill_end(s2r_synth *s, float *mono_out) {
+    if (!s) return S2R_ERR_INVALID;
+    if (s->ring_count == 0) return set_err(s, S2R_ERR_INVALID, "no fill in flight");
+    const uint32_t slot = s->ring_head;
+    if (s->ring_frames[slot] && !mono_out) return set_err(s, S2R_ERR_INVALID, "null output buffer");
+    S2R_HIP(s, hipEventSynchronize(s->ring_done[slot]));
+    if (s->ring_frames[slot]) std::memcpy(mono_out, s->ring_host[slot], s->ring_frames[slot] * sizeof(float));
+    s->ring_head ^= 1u;
+    s->ring_count--;
+    return S2R_OK;
 }
 
 int s2r_fill_stereo(s2r_synth *s, float *interleaved_lr_out, size_t frames, uint32_t sample_rate_hz) {

@@ -746,8 +746,9 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             xq[q] = load_f4u(tab + 4 * q);
-            bq[q] = load_f4u(tab + plane + 4 * q);               // one-pole: a0 = 1 - x
-            if (FILT != 0) gq[q] = load_f4u(tab + 2u * plane + 4 * q);
+            // (the one-pole's 1 - x is two packed subtractions per quad: cheaper for a lone wave than a second load,
+            // ~20 cycles of issue each)
+            if (FILT != 0) { bq[q] = load_f4u(tab + plane + 4 * q); gq[q] = load_f4u(tab + 2u * plane + 4 * q); }
             if (FMV) pq[q] = load_f4u(tab + p.tab.fm_plane * plane + 4 * q);
         }
     }
@@ -800,7 +801,7 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
             nz[q] = hash_noise4(r.seed_rot, t) + splat(p.noise_level);
         }
         if (AFLAT) amp[q] = splat(ea_slope * (t_chunk - ea_base) + ea_y0);
-        else amp[q] = splat(ea_slope) * (t - splat(ea_base)) + splat(ea_y0);
+        else amp[q] = splat(ea_slope) * pk_add4(t, splat(-ea_base)) + splat(ea_y0);     // t - base, packed
         if (SRC == 0) xq[q] = splat(xc0);
         if (SRC == 1 && FMV) {
             const f4 f_osc = pq[q] * splat(r.pitch);             // pow(2, mod * amount) * freq   process.rs:146-147,231-250
@@ -829,7 +830,7 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
         // filters.rs:23.  A lane without a started voice must put +0.0 into the mix (synth.rs:178 skips
         // it): with a0 = 0 and last = 0 its y is 0*s + x*0 = +0 for every finite s and x >= 0, and
         // (+0) * (amp = +0) = +0 — no select per frame
-        f4 a0 = (SRC == 1 && FILT == 0) ? bq[q] : splat(1.0f) - xq[q];   // (the tables carry 1 - x next to x)
+        f4 a0 = splat(1.0f) - xq[q];
         if (SRC == 2 && !live) a0 = splat(0.0f);                 // SRC 1: such a lane reads the tables' x = 1, 1 - x = 0 entries
         // the quad's oscillator constants: the run's (k), or under FM each frame's period and 1 / period (from the
         // tables' pow2 plane) with the rest by exact scalings (make_osck)

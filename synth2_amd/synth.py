@@ -143,6 +143,8 @@ def load_library():
         "s2r_note_off": (C.c_int, [H, C.c_uint8]),
         "s2r_note_events": (C.c_int, [H, C.c_void_p, C.c_size_t]),
         "s2r_fill": (C.c_int, [H, _f32p, C.c_size_t, C.c_uint32]),
+        "s2r_fill_begin": (C.c_int, [H, C.c_size_t, C.c_uint32]),
+        "s2r_fill_end": (C.c_int, [H, _f32p]),
         "s2r_fill_stereo": (C.c_int, [H, _f32p, C.c_size_t, C.c_uint32]),
         "s2r_fill_oversampled": (C.c_int, [H, _f32p, C.c_size_t, C.c_uint32]),
         "s2r_fill_device": (C.c_int, [H, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
@@ -336,6 +338,16 @@ class Synth:
             buffer = np.empty(buffer, dtype=np.float32)
         assert buffer.dtype == np.float32 and buffer.flags["C_CONTIGUOUS"] and buffer.ndim == 1
         self._check(self.L.s2r_fill(self.h, buffer.ctypes.data_as(_f32p), buffer.size, int(sample_rate)))
+        return buffer
+
+    def sample_begin(self, frames, sample_rate=SampleRateKhz(48000)):
+        """first half of sample(): queue the fill (at most two in flight, like s2_bin's two buffers)"""
+        self._check(self.L.s2r_fill_begin(self.h, int(frames), int(sample_rate)))
+
+    def sample_end(self, buffer):
+        """second half: wait for the oldest fill in flight and copy it into ``buffer``"""
+        assert buffer.dtype == np.float32 and buffer.flags["C_CONTIGUOUS"] and buffer.ndim == 1
+        self._check(self.L.s2r_fill_end(self.h, buffer.ctypes.data_as(_f32p)))
         return buffer
 
     def sample_oversampled(self, frames, sample_rate=SampleRateKhz(48000)):

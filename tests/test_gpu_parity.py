@@ -1112,3 +1112,32 @@ def test_config4_share_32768_voices_4x_oversampled_dpw_svf():
         x = np.concatenate([hist, mix4])
         assert_bits_equal(out, s2o.decimate4(x, frames_out), "decimated output, buffer %d" % k)
         hist = x[-62:]
+
+
+def test_fill_begin_end_two_buffers_in_flight():
+    """s2r_fill_begin / s2r_fill_end (two buffers in flight, s2_bin's arrangement) return what s2r_fill returns"""
+    a = s2.Synth(300, max_frames=512)
+    b = s2.Synth(300, max_frames=512)
+    rng = np.random.RandomState(5)
+    want, got = [], []
+    buf = np.empty(512, dtype=np.float32)
+    for k in range(7):
+        ev = np.zeros(20, dtype=s2.NOTE_EVENT_DTYPE)
+        ev["kind"] = rng.randint(0, 2, 20) | (k == 0); ev["note"] = rng.randint(40, 90, 20); ev["velocity"] = 1.0
+        ev["frame"] = np.sort(rng.randint(0, 32, 20)) * 16 if k % 2 else 0
+        frames = 512 if k != 4 else 100
+        a.note_events(ev); b.note_events(ev)
+        want.append(a.sample(np.empty(frames, dtype=np.float32)).copy())
+        b.sample_begin(frames)
+        if k:
+            n = want[k - 1].size
+            got.append(b.sample_end(np.empty(n, dtype=np.float32)).copy())
+    got.append(b.sample_end(np.empty(want[-1].size, dtype=np.float32)).copy())
+    for k, (w, g) in enumerate(zip(want, got)):
+        assert_bits_equal(g, w, "buffer %d" % k)
+    with pytest.raises(s2.S2rError):
+        b.sample_end(buf)                                        # nothing in flight
+    b.sample_begin(16); b.sample_begin(16)
+    with pytest.raises(s2.S2rError):
+        b.sample_begin(16)                                       # a third one
+    b.sample_end(np.empty(16, dtype=np.float32)); b.sample_end(np.empty(16, dtype=np.float32))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): kernel-trace stats plus PMC passes for the render kernel.
 # Output: gpurun_out/prof_<tag>/{trace,pmc1,pmc2,pmc_fetch,pmc_write}/...csv  — summarise with
-# tools/summarize_prof.py and copy the summaries into profiles/.
+# tools/summarize_prof.py and copy the summaries into profiles/ (bench.py quotes profiles/r02/c3_summary.json).
 # usage: tools/profile_gpu.sh <tag> [bench.py args...]
 set -u
 TAG=${1:-run}; shift || true

@@ -13,10 +13,19 @@ import sys
 from collections import defaultdict
 
 
+SETUP = int(os.environ.get("S2R_PROF_SETUP", "66"))      # bench.py's untimed set-up buffers (workload c3: PERIOD + 2)
+
+
 def main():
     root = sys.argv[1]
     want = sys.argv[2] if len(sys.argv) > 2 else "s2r_render_kernel"
     out = {"source": root, "kernel_filter": want}
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        out["kernel_source_hash"] = bench.kernel_source_hash()     # bench.py quotes these counters only for this build
+    except Exception:
+        pass
     for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
         rows = list(csv.DictReader(open(f)))
         out["kernel_stats"] = [{"name": r["Name"][:120], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
@@ -31,21 +40,24 @@ def main():
             d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
             out["dispatch"]["avg_ns"] = sum(d) / len(d)
             out["dispatch"]["n"] = len(d)
-            # bench.py launches the render kernel in a fixed order: warmup, the K timed steps, 16
-            # launches timed with HIP events (-> roofline.kernel_ms), 16 more with every shortcut off
-            # (-> roofline_valu.kernel_ms), ...; the same slices of the trace, for comparison
-            w = int(os.environ.get("S2R_PROF_WARMUP", "4")); k = int(os.environ.get("S2R_PROF_STEPS", "16"))
-            m = min(k, 16)
+            # bench.py launches the render kernel in a fixed order: the untimed set-up (one period + 2 buffers for workload
+            # c3), warm-up, the K timed steps, min(K, 64) steps through the synchronous host API, 16 launches timed with HIP
+            # events (-> roofline.kernel_ms), 16 more with every shortcut off (-> roofline_valu.kernel_ms); the same slices
+            # of the trace, for comparison
+            w = SETUP + int(os.environ.get("S2R_PROF_WARMUP", "4")); k = int(os.environ.get("S2R_PROF_STEPS", "16"))
+            m = min(max(k, 4), 16); sy = min(k, 64)
             def avg(a, b):
                 seg = d[a:b]
                 return sum(seg) / len(seg) if seg else None
-            out["dispatch"]["phases_avg_ns"] = {"warmup": avg(0, w), "timed_steps": avg(w, w + k),
-                                                "kernel_ms_launches": avg(w + k, w + k + m),
-                                                "kernel_ms_all_modulating_launches": avg(w + k + m, w + k + 2 * m)}
+            out["dispatch"]["phases_avg_ns"] = {"setup_and_warmup": avg(0, w), "timed_steps": avg(w, w + k),
+                                                "host_api_sync_steps": avg(w + k, w + k + sy),
+                                                "kernel_ms_launches": avg(w + k + sy, w + k + sy + m),
+                                                "kernel_ms_all_in_lane_launches": avg(w + k + sy + m, w + k + sy + 2 * m)}
+            out["dispatch"]["avg_ns"] = avg(w, w + k)            # the timed steps
     # PMC passes: one row per dispatch and counter; the same launch order as the trace, so the same
     # slices.  `pmc_avg_per_dispatch` is the TIMED-STEPS phase (steady state); the warm-up launches,
     # where every group streams coefficients, are reported separately.
-    w = int(os.environ.get("S2R_PROF_WARMUP", "4")); k = int(os.environ.get("S2R_PROF_STEPS", "16"))
+    w = SETUP + int(os.environ.get("S2R_PROF_WARMUP", "4")); k = int(os.environ.get("S2R_PROF_STEPS", "16"))
     counters = defaultdict(list)
     for sub in ("pmc1", "pmc2", "pmc_fetch", "pmc_write"):
         for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
@@ -59,7 +71,7 @@ def main():
     def mean(v):
         return sum(v) / len(v) if v else None
     out["pmc_avg_per_dispatch"] = {n: mean(v[w:w + k]) for n, v in sorted(counters.items())}
-    out["pmc_avg_first_launches"] = {n: mean(v[:min(w, 8)]) for n, v in sorted(counters.items())}
+    out["pmc_avg_first_launches"] = {n: mean(v[:8]) for n, v in sorted(counters.items())}
     out["pmc_dispatches"] = {n: len(v) for n, v in sorted(counters.items())}
     out["pmc_phase"] = "dispatches %d..%d of the render kernel (bench.py's timed steps)" % (w, w + k - 1)
     json.dump(out, sys.stdout, indent=1)
