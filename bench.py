@@ -330,6 +330,24 @@ def main():
     kernel_ms_full = kernel_ms_loop(min(max(args.steps, 4), 16))
     synth.set_flat_shortcut(True)
 
+    # ---- every voice inside its mod-envelope decay (N = 1): the whole pool re-triggered, then 8 buffers (the default
+    #      patch's mod envelope decays for 9 600 frames = 9.4 buffers), coefficient tables ON (the product path) ----
+    all_mod = None
+    if world == 1:
+        retrig = np.zeros(total, dtype=s2.NOTE_EVENT_DTYPE)
+        retrig["kind"] = 1
+        retrig["note"] = 36 + (np.arange(total) % 61)
+        retrig["velocity"] = 1.0
+        fence()
+        sh.note_events(retrig)
+        sh.fill(FRAMES, SR)                       # (the buffer that applies 65 536 note-ons is not timed)
+        fence()
+        t2 = time.perf_counter()
+        for _ in range(8):
+            sh.fill(FRAMES, SR)
+        fence()
+        all_mod = total * FRAMES * 8 / (time.perf_counter() - t2)
+
     if rank == 0:
         value = total * FRAMES * args.steps / dt_max
         kernel_s = kernel_ms * 1e-3
@@ -391,6 +409,8 @@ def main():
             "value_host_api_sync": host_api_sync,
             "value_host_api_sync_note": "the same steps through s2r_fill, which returns every buffer in the caller's host memory before the next events are handed over (host event processing and GPU time add up instead of overlapping)",
             "value_kernel_only": vpg * FRAMES / kernel_s,
+            "value_all_voices_modulating": all_mod,
+            "value_all_voices_modulating_note": "every voice re-triggered, then 8 buffers inside the 9 600-frame mod decay; device-resident fills queued back to back, product path (tables on)",
             "mix_checksum": float(np.abs(mix_host).sum()),
         }
         if world > 1:

@@ -144,7 +144,8 @@ struct VoiceRegs {
 // The value produced is the reference's selected expression, operation for operation.
 struct EnvRun {
     float slope, base, y0, thr;
-    int stage;      // 0 attack, 1 decay, 2 sustain, 3 release, 4 end
+    float stage;    // 0 attack, 1 decay, 2 sustain, 3 release, 4 end (a float like its neighbours: a struct of one
+                    // type is what the optimiser keeps in registers; with an int here the pair lived in scratch)
 };
 
 // the cascade of simdtest.rs:288-292 for one frame offset t, from scratch: the first stage whose
@@ -162,7 +163,7 @@ __device__ __forceinline__ EnvRun env_stage_at(const S2rEnv &e, float ro, float 
     s.base  = s1 ? e.A : s3 ? ro : 0.0f;
     s.y0    = s1 ? 1.0f : (s2 || s3) ? e.S : 0.0f;
     s.thr   = s0 ? e.A : s1 ? e.sus_off : s2 ? ro : s3 ? end : __builtin_inff();
-    s.stage = s0 ? 0 : s1 ? 1 : s2 ? 2 : s3 ? 3 : 4;
+    s.stage = s0 ? 0.0f : s1 ? 1.0f : s2 ? 2.0f : s3 ? 3.0f : 4.0f;
     return s;
 }
 
@@ -609,12 +610,12 @@ __device__ __forceinline__ f4 load_f4u(const float *p) { return *reinterpret_cas
 // the mod envelope's active stage; a release that starts at the clamp attack + decay (simdtest.rs:283) is indexed by
 // the offset, a later one by the frames since the release.
 struct TabCur { int32_t idx; uint32_t mask; };
-__device__ __forceinline__ TabCur tab_cursor(const S2rTabRef &t, int stage, bool late_release, uint32_t release_u, bool live) {
+__device__ __forceinline__ TabCur tab_cursor(const S2rTabRef &t, float stage, bool late_release, uint32_t release_u, bool live) {
     TabCur c;
-    const bool moving = stage <= 1 || stage == 3;
+    const bool moving = stage <= 1.0f || stage == 3.0f;
     c.mask = (live && moving) ? 0xffffffffu : 0u;
     const int32_t rel = late_release ? t.ru - (int32_t)release_u : t.rc - (int32_t)t.rc_t0;
-    const int32_t idx = stage <= 1 ? t.ad : stage == 2 ? t.sus : stage == 3 ? rel : t.end;
+    const int32_t idx = stage <= 1.0f ? t.ad : stage == 2.0f ? t.sus : stage == 3.0f ? rel : t.end;
     c.idx = live ? idx : t.dead;
     return c;
 }
