@@ -49,6 +49,7 @@ __global__ void __launch_bounds__(256) s2r_table_kernel(const S2rTabBuild b) {
     } else {
         const FiltCoef fc = dsp_filter_coef(b.lpf_kind, b.lpf_damping, b.sr, f_lpf);
         c0 = fc.alpha; c1 = fc.beta; c2 = fc.gamma;
+        if (dead) c0 = 1.0f;                                     // (what a lane without a voice reads as the one-pole's x: chunk_bank)
     }
     b.base[i] = c0;
     b.base[(size_t)b.plane + i] = c1;

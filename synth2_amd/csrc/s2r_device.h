@@ -50,6 +50,13 @@ struct S2rBankEntry {
     int32_t lpf_kind;
     float lpf_shape;      // damping_factor (LP2/HP2) or quality_factor (BP2)
     S2rEnv amp, mod;
+    // this patch's coefficient tables (S2rTabRef with `base` = the bank's table buffer + tab_off floats); always four
+    // planes: c0, c1, c2 (x, 1 - x, - for the one-pole; alpha, beta, gamma otherwise), pow(2, mod * amt_osc)
+    uint32_t tab_valid;   // 0: envelopes too long to tabulate — the voices of this patch compute in-lane
+    uint32_t tab_off, tab_plane;
+    int32_t tab_ad, tab_rc;
+    uint32_t tab_rc_t0;
+    int32_t tab_ru, tab_sus, tab_end, tab_dead;
 };
 
 struct S2rTimedEvent;

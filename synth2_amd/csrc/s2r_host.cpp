@@ -143,6 +143,7 @@ struct s2r_synth {
     float *tab_dev = nullptr; size_t tab_cap = 0;        // floats
     S2rTabRef tab{};
     bool tab_dirty = true; uint32_t tab_rate = 0;
+    float *bank_tab_dev = nullptr; size_t bank_tab_cap = 0;      // the patch bank's coefficient tables (floats)
     unsigned long long *stamps_dev = nullptr;            // diagnostic builds (-DS2R_STAMPS): per-wave phase stamps of the last fill
     bool use_tab = true, use_arg_events = true;
     float pitch_table[256];
@@ -308,6 +309,18 @@ bool tables_wanted(const s2r_synth *s) {
            (s->bank[0].lpf_kind == S2R_FILT_ONEPOLE || s->block_voices <= 256u);
 }
 
+// region lengths of one patch's tables; false: an envelope too long to tabulate
+bool plan_tables(const S2rEnv &e, S2rTabBuild &b) {
+    if (!(e.sus_off >= 0.0f && e.sus_off < (float)S2R_TAB_MAX_ENTRIES && e.R >= 0.0f && e.R < (float)S2R_TAB_MAX_ENTRIES)) return false;
+    b.mod = e;
+    b.rc_t0 = (uint32_t)std::ceil((double)e.sus_off);
+    b.n_ad = b.rc_t0 + 1u + S2R_TAB_PAD;
+    b.n_rel = (uint32_t)std::ceil((double)e.R) + 2u + S2R_TAB_PAD;
+    b.n_entries = b.n_ad + 2u * b.n_rel + 48u;
+    b.plane = (b.n_entries + 3u) & ~3u;
+    return true;
+}
+
 // (Re)builds the patch's coefficient tables for this sample rate on `stream` when the patch or the rate changed.
 // Envelopes too long to tabulate (attack + decay or release beyond S2R_TAB_MAX_ENTRIES frames) leave tab.base null:
 // such a patch computes in-lane.
@@ -316,17 +329,10 @@ int ensure_tables(s2r_synth *s, const S2rRenderParams &p, uint32_t sample_rate, 
     if (!s->tab_dirty && s->tab_rate == sample_rate) return S2R_OK;
     s->tab = S2rTabRef{};
     s->tab_dirty = false; s->tab_rate = sample_rate;
-    const S2rEnv &e = p.mod;
-    if (!(e.sus_off >= 0.0f && e.sus_off < (float)S2R_TAB_MAX_ENTRIES && e.R >= 0.0f && e.R < (float)S2R_TAB_MAX_ENTRIES)) return S2R_OK;
     S2rTabBuild b{};
-    b.mod = e;
+    if (!plan_tables(p.mod, b)) return S2R_OK;
     b.lpf_freq = p.lpf_freq; b.amt_lpf = p.amt_lpf; b.amt_osc = p.amt_osc; b.sr = p.sr; b.rcp_sr = p.rcp_sr;
     b.fast_div_sr = p.fast_div_sr; b.lpf_kind = p.lpf_kind; b.lpf_damping = p.lpf_damping;
-    b.rc_t0 = (uint32_t)std::ceil((double)e.sus_off);
-    b.n_ad = b.rc_t0 + 1u + S2R_TAB_PAD;
-    b.n_rel = (uint32_t)std::ceil((double)e.R) + 2u + S2R_TAB_PAD;
-    b.n_entries = b.n_ad + 2u * b.n_rel + 48u;
-    b.plane = (b.n_entries + 3u) & ~3u;
     const bool onepole = p.lpf_kind == S2R_FILT_ONEPOLE;
     const uint32_t n_planes = (onepole ? 2u : 3u) + (p.amt_osc != 0.0f ? 1u : 0u);
     b.fm_plane = p.amt_osc != 0.0f ? (onepole ? 2u : 3u) : 0u;
@@ -401,15 +407,40 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
         // resolve every patch for this sample rate (Ms::as_samples, units.rs:44-53) and replace the
         // device copy; rare (bank edits, rate changes), so a synchronous hand-over is fine
         std::vector<S2rBankEntry> host(s->bank.size());
+        std::vector<S2rTabBuild> builds(s->bank.size());
+        size_t tab_floats = 0;
+        const float srf = (float)sample_rate;
         for (size_t k = 0; k < s->bank.size(); k++) {
             const s2r_patch &pt = s->bank[k];
             S2rBankEntry &e = host[k];
+            std::memset(&e, 0, sizeof e);
             e.osc_kind = pt.osc_kind; e.osc_gain = pt.osc_gain; e.noise_level = pt.noise; e.lpf_freq = pt.lpf_freq;
             e.amt_osc = pt.mod_env_to_osc_freq; e.amt_lpf = pt.mod_env_to_lpf_freq; e.lpf_kind = pt.lpf_kind;
             e.lpf_shape = pt.lpf_kind >= S2R_FILT_BP2 ? pt.lpf_q : pt.lpf_damping;
             e.amp = resolve_env(pt.amp_env, sample_rate);
             e.mod = resolve_env(pt.mod_env, sample_rate);
+            // this patch's coefficient tables, four planes in the bank's table buffer
+            S2rTabBuild &b = builds[k];
+            b = S2rTabBuild{};
+            if (s->use_tab && !s->no_flat_shortcut && plan_tables(e.mod, b)) {
+                b.lpf_freq = e.lpf_freq; b.amt_lpf = e.amt_lpf; b.amt_osc = e.amt_osc; b.sr = srf; b.rcp_sr = 1.0f / srf;
+                b.fast_div_sr = 0;                   // (the per-lane-patch kernel divides by the sample rate with a true division)
+                b.lpf_kind = e.lpf_kind; b.lpf_damping = e.lpf_shape; b.fm_plane = 3u;
+                e.tab_valid = 1u; e.tab_off = (uint32_t)tab_floats; e.tab_plane = b.plane;
+                e.tab_ad = 0; e.tab_rc = (int32_t)b.n_ad; e.tab_rc_t0 = b.rc_t0; e.tab_ru = (int32_t)(b.n_ad + b.n_rel);
+                e.tab_sus = (int32_t)(b.n_ad + 2u * b.n_rel); e.tab_end = e.tab_sus + 16; e.tab_dead = e.tab_sus + 32;
+                tab_floats += (size_t)b.plane * 4u;
+            }
         }
+        if (tab_floats > s->bank_tab_cap) {
+            S2R_HIP(s, hipStreamSynchronize(stream));
+            S2R_HIP(s, hipStreamSynchronize(s->stream));
+            if (s->bank_tab_dev) { S2R_HIP(s, hipFree(s->bank_tab_dev)); s->bank_tab_dev = nullptr; s->bank_tab_cap = 0; }
+            S2R_HIP(s, hipMalloc((void **)&s->bank_tab_dev, tab_floats * sizeof(float)));
+            s->bank_tab_cap = tab_floats;
+        }
+        for (size_t k = 0; k < s->bank.size(); k++)
+            if (host[k].tab_valid) { builds[k].base = s->bank_tab_dev + host[k].tab_off; S2R_HIP(s, s2r_launch_tables(builds[k], stream)); }
         S2R_HIP(s, hipMemcpyAsync(s->bank_dev, host.data(), host.size() * sizeof(S2rBankEntry), hipMemcpyHostToDevice, stream));
         S2R_HIP(s, hipStreamSynchronize(stream));
         s->bank_dirty = false; s->bank_rate = sample_rate;
@@ -422,6 +453,7 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
         if (rc != S2R_OK) return rc;
     }
     if (tables_wanted(s)) p.tab = s->tab;
+    else if (bank_kernel) { p.tab = S2rTabRef{}; p.tab.base = s->bank_tab_dev; }      // the per-lane-patch kernel adds each entry's tab_off
     p.stamps = s->stamps_dev;
     p.per_voice = per_voice_dev;
     p.tev = tev_dev;
@@ -506,6 +538,7 @@ void release_all(s2r_synth *s) {
     if (s->tev_copy) (void)hipFree(s->tev_copy);
     if (s->tab_dev) (void)hipFree(s->tab_dev);
     if (s->stamps_dev) (void)hipFree(s->stamps_dev);
+    if (s->bank_tab_dev) (void)hipFree(s->bank_tab_dev);
     if (s->t0) (void)hipEventDestroy(s->t0);
     if (s->t1) (void)hipEventDestroy(s->t1);
     if (s->stream) (void)hipStreamDestroy(s->stream);

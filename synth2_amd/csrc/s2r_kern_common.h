@@ -690,6 +690,44 @@ __device__ __forceinline__ void tile_store4(int q, f4 v) {
 #undef S2R_ST4
 }
 
+// Four sine-table lookups (lookup.rs:46-85 table_lookup_exclusive_x16 on SIN_TABLE): the four LDS reads are issued
+// together and waited for once (left to itself the compiler waits behind each read, and an `s_waitcnt lgkmcnt(0)` also
+// waits for the tile stores it does not count).  x * 1024 / period: through the run's double reciprocal, exactly
+// (s2r_math.h), or a true division when the period changes every frame (FMV).
+struct SineQuad { float tv[4]; uint32_t i1[4]; float2 pr[4]; };
+template <bool FMV>
+__device__ __forceinline__ SineQuad sine_quad_issue(f4 x, f4 period, double rcp_period, const float *sSin) {
+    SineQuad s;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s.tv[j] = FMV ? x[j] * 1024.0f / period[j] : s2r_div_by_rcp64(x[j] * 1024.0f, rcp_period);    // :63
+        s.i1[j] = s2r_f32_as_u32(s.tv[j]);                       // :64
+    }
+    // :67 i2 = (i1 + 1) % 1024 as the pair's byte offset ((i1 + 1) & 1023) * 8 == ((i1 << 3) + 8) & 0x1ff8: two instructions
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        s.pr[j] = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(sSin) + (((s.i1[j] << 3) + 8u) & 0x1ff8u));
+    return s;
+}
+__device__ __forceinline__ f4 sine_quad_finish(SineQuad &s) {
+    asm("" : "+v"(s.pr[0].x), "+v"(s.pr[0].y), "+v"(s.pr[1].x), "+v"(s.pr[1].y), "+v"(s.pr[2].x), "+v"(s.pr[2].y), "+v"(s.pr[3].x), "+v"(s.pr[3].y));
+    f4 out;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // s1 = i1 < 1024 ? SIN_TABLE[i1] : 0 (:68-70) without the compare: in the branch-free chunks 0 <= x < period
+        // (chunk_fast), so tv = RN(x * 1024 / period) <= 1024 and i1 <= 1024; for i1 == 1024 the pair read is entry
+        // i2 = 1, whose first half is SIN_TABLE[0] == +0.0 — the very value the compare would pick
+        const float s1 = s.pr[j].x, s2 = s.pr[j].y;
+        out[j] = __builtin_fmaf((s2 - s1) / 1.0f, s.tv[j] - (float)s.i1[j], s1);
+    }
+    return out;
+}
+template <bool FMV>
+__device__ __forceinline__ f4 sine_quad(f4 x, f4 period, double rcp_period, const float *sSin) {
+    SineQuad s = sine_quad_issue<FMV>(x, period, rcp_period, sSin);
+    return sine_quad_finish(s);
+}
+
 // v_pk_add_f32 on a pair (the compiler splits some of the chunk's packed adds into two scalar ones)
 typedef float fp2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f4 pk_add4(f4 a, f4 b) {
@@ -826,6 +864,7 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
     //      an ulp of period, so the product never rounds back up to it; checked exhaustively over ten binades of
     //      periods in tests/test_oracle_known_answers.py::test_phased_offset_stays_below_the_period). ----
     const uint32_t livemask = live ? 0xffffffffu : 0u;
+    f4 outs[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         // filters.rs:23.  A lane without a started voice must put +0.0 into the mix (synth.rs:178 skips
@@ -865,16 +904,7 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
             const u4 lt = (u4)((i4)(u4)(x - ka) >> 31);          // all ones where x < half
             osc = (f4)(((u4)first & lt) | ((u4)second & ~lt));
         } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                // lookup.rs:46-85.  x * 1024 / period: through the run's double reciprocal, exactly (s2r_math.h); a true
-                // division when the period changes every frame
-                const float tv = FMV ? x[j] * 1024.0f / period[j] : s2r_div_by_rcp64(x[j] * 1024.0f, rcp_period);
-                const uint32_t i1 = s2r_f32_as_u32(tv), i2 = (i1 + 1u) & 1023u;
-                const float2 pr = sin_pair(sSin, i2);
-                const float s1 = i1 < 1024u ? pr.x : 0.0f, s2 = pr.y;
-                osc[j] = __builtin_fmaf((s2 - s1) / 1.0f, tv - (float)i1, s1);
-            }
+            osc = sine_quad<FMV>(x, period, rcp_period, sSin);
         }
         const f4 sv = pk_add4(osc + splat(p.osc_gain), nz[q]);   // process.rs:342-345 (ADD), :358
         f4 y;
@@ -893,7 +923,12 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
         // (a dead lane's dsp_filters.rs state may run away on its made-up input: its output is masked to +0.0 here)
         if (FILT != 0) out = (f4)((u4)out & livemask);
         tile_store4(q, out);
-        if (pv_dst) { pv_dst[4 * q] = out.x; pv_dst[4 * q + 1] = out.y; pv_dst[4 * q + 2] = out.z; pv_dst[4 * q + 3] = out.w; }
+        outs[q] = out;
+    }
+    // the per-voice rows (tests, s2r_fill_voices): one branch behind the chunk's basic block, not one per quad
+    if (pv_dst) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f4u *>(pv_dst + 4 * q) = outs[q];
     }
 }
 
