@@ -6,6 +6,7 @@ import numpy as np
 import synth2_amd as s2
 
 V = int(os.environ.get("V", 65536))
+FR = int(os.environ.get("FR", 1024))      # frames per fill
 
 
 def run(bank, label):
@@ -23,12 +24,12 @@ def run(bank, label):
     ev["velocity"] = 1.0
     s.note_events(ev)
     s.set_timing(True)
-    buf = np.empty(1024, dtype=np.float32)
+    buf = np.empty(FR, dtype=np.float32)
     ts = []
     for k in range(24):
         s.sample(buf)
         ts.append(s.last_render_ms())
-    print("%-40s first %.3f ms  settled %.3f ms  (%.3g voice-samples/s)" % (label, ts[0], np.mean(ts[12:]), V * 1024 / (np.mean(ts[12:]) * 1e-3)))
+    print("%-40s first %.3f ms  settled %.3f ms  (%.3g voice-samples/s)" % (label, ts[0], np.mean(ts[12:]), V * FR / (np.mean(ts[12:]) * 1e-3)))
 
 
 d = s2.default_patch()
