@@ -22,6 +22,7 @@ __constant__ uint64_t c_exp2f_table[S2R_EXP2F_N] = S2R_EXP2F_TABLE_INIT;
 
 constexpr int kChunk = 16;         // the reference's x16 chunk (synth.rs:158, process.rs:25)
 constexpr uint32_t kSuperMax = 256; // frames between two cross-wave combines: 256 (small workgroups) or 64
+constexpr uint32_t kSuperWhole = 1024; // ... or the whole fill, where a workgroup has its compute unit to itself (below)
 constexpr int kP = 4;              // frames whose closed-form work one lane carries at once (ILP)
 
 // The closed-form part of kP = 4 consecutive frames is evaluated together on 4-wide vectors.
@@ -619,6 +620,24 @@ __device__ __forceinline__ TabCur tab_cursor(const S2rTabRef &t, float stage, bo
     c.idx = live ? idx : t.dead;
     return c;
 }
+
+// Super-chunk length of a render launch (host side).  Every super-chunk boundary costs each wave a barrier and a fresh
+// run decision — about three 16-frame chunks' worth (tools/stamps.py) — so where the grid has no more workgroups than
+// the device has compute units (one workgroup per CU whatever its LDS size: 65 536 voices in 256-voice workgroups on
+// an MI355X) the whole fill is ONE super-chunk: group sums for up to 1024 frames in LDS (64 KiB, one buffer), one
+// barrier, one combine.  Bigger grids keep 256-frame super-chunks in two buffers, small enough for two workgroups per CU.
+inline uint32_t s2r_pick_super_frames(uint32_t n_groups, uint32_t grid, uint32_t frames) {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n_cu = v;
+        else n_cu = 1;
+    }
+    if (n_groups <= 16 && grid <= (uint32_t)n_cu && frames <= kSuperWhole) return kSuperWhole;
+    return n_groups <= 16 ? kSuperMax : (n_groups <= 32 ? 64u : 32u);
+}
+// group-sum buffers the launch needs: two (a super-chunk's combine overlaps the next one's chunks) unless the fill is one
+__host__ __device__ inline uint32_t s2r_sw_buffers(uint32_t frames, uint32_t super_frames) { return frames > super_frames ? 2u : 1u; }
 
 // ---------------------------------------------------------------------------------------
 // The fill's note events when they ride in the kernel arguments (S2rRenderArgs): every wave looks at 64 records per

@@ -55,6 +55,13 @@ for rep in range(3):
     work = sum(cols[1 + 2 * i] for i in range(4))
     print("   waves with timed events: %d; events per such wave: median %d max %d" % (ev_w.size, int(np.median(t[ev_w, 11])) if ev_w.size else 0, int(t[:, 11].max())))
     order = np.argsort(-total)[:12]
+    x = st[:, 10]
+    runchunks = (x >> np.uint64(48)).astype(np.int64); t_dense = ((x >> np.uint64(24)) & np.uint64(0xffffff)).astype(np.int64); t_run = (x & np.uint64(0xffffff)).astype(np.int64)
+    print("   slowest waves, where the work went: " + "  ".join("w%d dense %d chunks %d cyc (%d/chunk), runs %d chunks %d cyc (%d/chunk), general %d |" % (
+        w, t[w, 12], t_dense[w], t_dense[w] // max(1, t[w, 12]), runchunks[w], t_run[w], t_run[w] // max(1, runchunks[w]), t[w, 13]) for w in order[:5]))
+    med = np.argsort(total)[len(total) // 2 - 2: len(total) // 2 + 2]
+    print("   median waves: " + "  ".join("w%d dense %d chunks %d cyc, runs %d chunks %d cyc (%d/chunk), general %d |" % (
+        w, t[w, 12], t_dense[w], runchunks[w], t_run[w], t_run[w] // max(1, runchunks[w]), t[w, 13]) for w in med))
     print("   slowest waves: " + "  ".join("w%d total %d work %d ev %d dense %d general %d runs %d |" % (w, total[w], work[w], t[w, 11], t[w, 12], t[w, 13], t[w, 14]) for w in order[:6]))
     if ev_w.size:
         nb = [w for w in ev_w if w + 1 < waves and t[w + 1, 11] == 0][:6]
