@@ -409,6 +409,23 @@ __device__ __forceinline__ FlatConsts make_flat_consts(const S2rRenderParams &p,
     return c;
 }
 
+// ... read from the patch's coefficient tables where there are some: their sustain and end regions hold exactly these
+// values (s2r_table_kernel runs the same routines on mod == 0 * 1 + S and mod == 0), at wave-uniform addresses
+template <int OSC, bool FM>
+__device__ __forceinline__ FlatConsts flat_consts_from_tables(const S2rRenderParams &p, float pitch) {
+    FlatConsts c;
+    c.xc_s = p.tab.base[p.tab.sus];
+    c.xc_0 = p.tab.base[p.tab.end];
+    if (FM) {
+        const float *fm = p.tab.base + (size_t)p.tab.fm_plane * p.tab.plane;
+        c.k_s = make_osck<OSC>(p.sr / (fm[p.tab.sus] * pitch));  // process.rs:146-147, units.rs:32-42
+        c.k_0 = make_osck<OSC>(p.sr / (fm[p.tab.end] * pitch));
+    } else {
+        c.k_s = c.k_0 = make_osck<OSC>(p.sr / (1.0f * pitch));    // (not looked at without FM)
+    }
+    return c;
+}
+
 template <int OSC, bool FM>
 __device__ __forceinline__ FlatCache refresh_flat(const FlatConsts &c, const EnvRun em, FlatCache fc) {
     if (em.slope == 0.0f) {
