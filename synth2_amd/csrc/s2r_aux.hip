@@ -134,38 +134,14 @@ __global__ void s2r_decimate4_history_kernel(float *x, uint32_t n_out) {
 // publishes the first timed event of every touched voice
 // ... and moves the records from mapped host memory into HBM in one coalesced sweep: the coefficient pass and
 // the render kernel follow per-voice chains through them, and a PCIe round trip per hop is what they cannot afford
-// A chain's first record that sits at frame 0 — the fill's folded untimed events, which the host merges into the chains
-// when the fill has timed events too — is applied here, to the voice's words in HBM, exactly as s2r_events_kernel would
-// (restart: *voice = Voice { .. }, synth.rs:63-69; release: release_frame_offset = current_frame_offset, :74-75), and
-// the chain starts behind it: the render kernel then loads a started voice instead of restarting 64 of them in its
-// first chunk (a cohort of note-ons is what a pool's busiest waves begin every buffer with).
-__global__ void s2r_tev_heads_kernel(const S2rVoiceArrays v, int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n) {
+// (It touches no voice state — a chain's first record that sits at frame 0, the fill's folded untimed events, is applied
+// by the render kernel's prologue — so the host may run it beside the previous fill's render kernel.)
+__global__ void s2r_tev_heads_kernel(int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const S2rTimedEvent e = tev[i];
     tev_copy[i] = e;
-    if (!(e.flags & S2R_TEV_FIRST)) return;
-    if (e.frame != 0u) { heads[e.voice] = (int32_t)i; return; }
-    const uint32_t vi = e.voice;
-    if (e.flags & S2R_EV_RESTART) {
-        v.pitch[vi] = e.pitch;
-        v.offset[vi] = 0u;
-        v.release[vi] = 0u;                                      // a release right after the on is at offset 0
-        v.flags[vi] = S2R_VF_STARTED | ((e.flags & S2R_EV_RELEASE) ? S2R_VF_RELEASED : 0u);
-        v.phase[vi] = 0.0f;
-        v.lpf_last[vi] = 0.0f;
-        v.fx1[vi] = 0.0f; v.fx2[vi] = 0.0f; v.fy1[vi] = 0.0f; v.fy2[vi] = 0.0f;
-        v.seed[vi] = e.seed;
-        v.program[vi] = e.program;
-        v.osc_z[vi] = s2r_u2f(S2R_OSC_Z_NONE);
-    } else if (e.flags & S2R_EV_RELEASE) {
-        const uint32_t fl = v.flags[vi];
-        if ((fl & S2R_VF_STARTED) && !(fl & S2R_VF_RELEASED)) {
-            v.release[vi] = v.offset[vi];
-            v.flags[vi] = fl | S2R_VF_RELEASED;
-        }
-    }
-    if (e.next >= 0) heads[vi] = e.next;
+    if (e.flags & S2R_TEV_FIRST) heads[e.voice] = (int32_t)i;
 }
 
 // note events folded per voice by the host (synth.rs:61-80)
@@ -242,9 +218,9 @@ hipError_t s2r_launch_events(const S2rVoiceArrays &v, const S2rVoiceEvent *dev_e
     return hipGetLastError();
 }
 
-hipError_t s2r_launch_tev_heads(const S2rVoiceArrays &v, int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n, hipStream_t stream) {
+hipError_t s2r_launch_tev_heads(int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(s2r_tev_heads_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, v, heads, tev, tev_copy, n);
+    hipLaunchKernelGGL(s2r_tev_heads_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, heads, tev, tev_copy, n);
     return hipGetLastError();
 }
 

@@ -258,7 +258,7 @@ int flush_events(s2r_synth *s, hipStream_t stream, EventSlot **timed_slot, const
     }
     if (nt) {
         std::memcpy(sl.thost, s->tpending.data(), nt * sizeof(S2rTimedEvent));
-        S2R_HIP(s, s2r_launch_tev_heads(s->v, s->voice_ev_head, sl.tdev, s->tev_copy, nt, stream));
+        S2R_HIP(s, s2r_launch_tev_heads(s->voice_ev_head, sl.tdev, s->tev_copy, nt, stream));
         *timed_slot = &sl; *tev_dev = s->tev_copy;         // the kernels read the HBM copy
         for (const S2rTimedEvent &e : s->tpending) s->tlast[e.voice] = -1;
         s->tpending.clear();
