@@ -66,10 +66,9 @@ __global__ void __launch_bounds__(256) s2r_table_kernel(const S2rTabBuild b) {
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t kMixRun = 16;
 
-__global__ void __launch_bounds__(256) s2r_mix_kernel(const S2rMixParams m) {
-    extern __shared__ float s_run[];                             // [total runs][16 frames]
+__device__ __forceinline__ void mix_body(const S2rMixParams &m, uint32_t block, float *s_run) {
     const uint32_t f_local = threadIdx.x & 15u, slot = threadIdx.x >> 4;
-    const uint32_t f = blockIdx.x * 16u + f_local;
+    const uint32_t f = block * 16u + f_local;
     const uint32_t runs_per_group = (m.blocks_per_group + kMixRun - 1) / kMixRun;
     const uint32_t total_runs = runs_per_group * m.n_groups;
     if (f < m.frames) {
@@ -104,6 +103,11 @@ __global__ void __launch_bounds__(256) s2r_mix_kernel(const S2rMixParams m) {
     }
 }
 
+__global__ void __launch_bounds__(256) s2r_mix_kernel(const S2rMixParams m) {
+    extern __shared__ float s_run[];                             // [total runs][16 frames]
+    mix_body(m, blockIdx.x, s_run);
+}
+
 // out[i] = ((+0.0 + rows[0][i]) + rows[1][i]) + ...   (rank-order combine of shard partials)
 __global__ void s2r_sum_rows_kernel(const float *rows, uint32_t n_rows, uint32_t frames, float *out) {
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -136,12 +140,25 @@ __global__ void s2r_decimate4_history_kernel(float *x, uint32_t n_out) {
 // the render kernel follow per-voice chains through them, and a PCIe round trip per hop is what they cannot afford
 // (It touches no voice state — a chain's first record that sits at frame 0, the fill's folded untimed events, is applied
 // by the render kernel's prologue — so the host may run it beside the previous fill's render kernel.)
-__global__ void s2r_tev_heads_kernel(int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void heads_body(int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n, uint32_t i) {
     if (i >= n) return;
     const S2rTimedEvent e = tev[i];
     tev_copy[i] = e;
     if (e.flags & S2R_TEV_FIRST) heads[e.voice] = (int32_t)i;
+}
+
+__global__ void s2r_tev_heads_kernel(int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n) {
+    heads_body(heads, tev, tev_copy, n, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// Between two render kernels of a caller with several fills in flight: the PREVIOUS fill's mix (its first `mix_blocks`
+// workgroups) and THIS fill's chain heads (the rest) in one launch — the two have nothing to do with each other, and a
+// launch boundary costs the stream more than either of them.
+__global__ void __launch_bounds__(256) s2r_mix_and_heads_kernel(const S2rMixParams m, uint32_t mix_blocks, int32_t *heads,
+                                                                const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n) {
+    extern __shared__ float s_run[];
+    if (blockIdx.x < mix_blocks) mix_body(m, blockIdx.x, s_run);
+    else heads_body(heads, tev, tev_copy, n, (blockIdx.x - mix_blocks) * blockDim.x + threadIdx.x);
 }
 
 // note events folded per voice by the host (synth.rs:61-80)
@@ -209,6 +226,18 @@ hipError_t s2r_launch_mix(const S2rMixParams &m, hipStream_t stream) {
     const size_t lds = (size_t)runs_per_group * m.n_groups * 16u * sizeof(float);
     if (lds > 64u * 1024u) return hipErrorInvalidValue;          // > 16 k workgroups in one shard
     hipLaunchKernelGGL(s2r_mix_kernel, dim3((m.frames + 15) / 16), dim3(256), lds, stream, m);
+    return hipGetLastError();
+}
+
+hipError_t s2r_launch_mix_and_heads(const S2rMixParams &m, int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n,
+                                    hipStream_t stream) {
+    if (m.frames == 0) return s2r_launch_tev_heads(heads, tev, tev_copy, n, stream);
+    if (n == 0) return s2r_launch_mix(m, stream);
+    const uint32_t runs_per_group = (m.blocks_per_group + kMixRun - 1) / kMixRun;
+    const size_t lds = (size_t)runs_per_group * m.n_groups * 16u * sizeof(float);
+    if (lds > 64u * 1024u) return hipErrorInvalidValue;
+    const uint32_t mix_blocks = (m.frames + 15) / 16;
+    hipLaunchKernelGGL(s2r_mix_and_heads_kernel, dim3(mix_blocks + (n + 255) / 256), dim3(256), lds, stream, m, mix_blocks, heads, tev, tev_copy, n);
     return hipGetLastError();
 }
 

@@ -197,6 +197,8 @@ hipError_t s2r_launch_tables(const S2rTabBuild &b, hipStream_t stream);
 hipError_t s2r_launch_render(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
 hipError_t s2r_launch_mix(const S2rMixParams &p, hipStream_t stream);
 hipError_t s2r_launch_events(const S2rVoiceArrays &v, const S2rVoiceEvent *dev_events, uint32_t n, hipStream_t stream);
+hipError_t s2r_launch_mix_and_heads(const S2rMixParams &m, int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n,
+                                    hipStream_t stream);
 hipError_t s2r_launch_tev_heads(int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n, hipStream_t stream);
 // build-defined 4x decimator: x = 62 samples of history + 4 * n_out new ones, h = 63 taps (device), and the
 // last 62 inputs copied to the front of x afterwards (second launch) for the next call

@@ -135,6 +135,9 @@ struct s2r_synth {
     hipEvent_t ring_done[2] = {nullptr, nullptr};
     size_t ring_frames[2] = {0, 0};
     uint32_t ring_head = 0, ring_count = 0;
+    // s2r_fill_begin leaves its fill's mix to the NEXT s2r_fill_begin, which launches it together with its own chain
+    // heads (s2r_mix_and_heads_kernel: one launch boundary less per buffer), or to s2r_fill_end, whichever comes first
+    struct DeferredMix { bool active = false; S2rMixParams m{}; int ring_slot = -1; } dmix;
     float *os_buf = nullptr, *os_taps = nullptr; // 4x oversampling: [62 history + max_frames] mix at 4x rate, 63 taps
     float *sin_dev = nullptr;
     float *per_voice_dev = nullptr; size_t per_voice_cap = 0;
@@ -205,6 +208,15 @@ void push_event(s2r_synth *s, uint32_t pool_index, uint32_t flags, float pitch, 
 // upload the folded events and apply them on `stream`; publish the timed ones.  Returns the slot
 // whose `done` event the caller must record AFTER the render kernel when timed events exist
 // (the kernel reads them from the slot's mapped memory), or nullptr.
+// the mix a fill left behind, on its own (no chain heads to go with)
+int launch_deferred_mix(s2r_synth *s, hipStream_t stream) {
+    if (!s->dmix.active) return S2R_OK;
+    s->dmix.active = false;
+    S2R_HIP(s, s2r_launch_mix(s->dmix.m, stream));
+    if (s->dmix.ring_slot >= 0) S2R_HIP(s, hipEventRecord(s->ring_done[s->dmix.ring_slot], stream));
+    return S2R_OK;
+}
+
 int flush_events(s2r_synth *s, hipStream_t stream, EventSlot **timed_slot, const S2rTimedEvent **tev_dev) {
     *timed_slot = nullptr; *tev_dev = nullptr;
     if (s->pending.empty() && s->tpending.empty()) return S2R_OK;
@@ -258,7 +270,13 @@ int flush_events(s2r_synth *s, hipStream_t stream, EventSlot **timed_slot, const
     }
     if (nt) {
         std::memcpy(sl.thost, s->tpending.data(), nt * sizeof(S2rTimedEvent));
-        S2R_HIP(s, s2r_launch_tev_heads(s->voice_ev_head, sl.tdev, s->tev_copy, nt, stream));
+        if (s->dmix.active && stream == s->stream) {           // the previous fill's mix rides with this fill's chain heads
+            s->dmix.active = false;
+            S2R_HIP(s, s2r_launch_mix_and_heads(s->dmix.m, s->voice_ev_head, sl.tdev, s->tev_copy, nt, stream));
+            if (s->dmix.ring_slot >= 0) S2R_HIP(s, hipEventRecord(s->ring_done[s->dmix.ring_slot], stream));
+        } else {
+            S2R_HIP(s, s2r_launch_tev_heads(s->voice_ev_head, sl.tdev, s->tev_copy, nt, stream));
+        }
         *timed_slot = &sl; *tev_dev = s->tev_copy;         // the kernels read the HBM copy
         for (const S2rTimedEvent &e : s->tpending) s->tlast[e.voice] = -1;
         s->tpending.clear();
@@ -386,8 +404,16 @@ S2rRenderParams make_params(s2r_synth *s, size_t frames, uint32_t sample_rate) {
 }
 
 // events -> render -> (mix) on `stream`; the partial or final mix lands in `dev_out`
+// `defer_ring_slot` >= 0 (s2r_fill_begin): the fill's mix is left to the next fill_begin / fill_end (DeferredMix)
 int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t stream, float *dev_out,
-                 bool root_add, bool stereo, float *per_voice_dev) {
+                 bool root_add, bool stereo, float *per_voice_dev, int defer_ring_slot = -1) {
+    if (s->dmix.active && stream != s->stream) {
+        // a fill on a caller's stream behind one in flight on ours: that one's mix reads the partial rows this fill
+        // is about to overwrite
+        int rc = launch_deferred_mix(s, s->stream);
+        if (rc != S2R_OK) return rc;
+        S2R_HIP(s, hipStreamSynchronize(s->stream));
+    }
     // The common case — a handful of untimed events without seed overrides — needs no launch for them: they ride in
     // the render kernel's arguments and every wave applies the ones that hit its voices before it loads its state.
     bool arg_events = s->use_arg_events && s->tpending.empty() && s->pending.size() <= S2R_ARG_MAX_EVENTS;
@@ -397,6 +423,11 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
     const S2rTimedEvent *tev_dev = nullptr;
     if (!arg_events) {
         int rc = flush_events(s, stream, &timed_slot, &tev_dev);
+        if (rc != S2R_OK) return rc;
+    }
+    {   // (no chain heads in this fill to take the previous fill's mix along: it goes alone, before the render kernel
+        // overwrites the partial rows)
+        int rc = launch_deferred_mix(s, stream);
         if (rc != S2R_OK) return rc;
     }
     // (the kernel that renders patch banks also renders single patches with a DPW oscillator: it reads its patch from the
@@ -489,7 +520,8 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
         m.root_add = root_add ? 1 : 0;
         m.stereo = stereo ? 1 : 0;
         m.out = dev_out;
-        S2R_HIP(s, s2r_launch_mix(m, stream));
+        if (defer_ring_slot >= 0 && stream == s->stream) { s->dmix.active = true; s->dmix.m = m; s->dmix.ring_slot = defer_ring_slot; }
+        else S2R_HIP(s, s2r_launch_mix(m, stream));
     }
     s->pool->advance(frames - s->fill_time);
     s->fill_time = 0;
@@ -850,10 +882,11 @@ int s2r_fill_begin(s2r_synth *s, size_t frames, uint32_t sample_rate_hz) {
     const uint32_t slot = (s->ring_head + s->ring_count) & 1u;
     if (frames) {
         // the last kernel of the fill writes the mix straight into this slot's mapped host buffer
-        rc = enqueue_fill(s, frames, sample_rate_hz, s->stream, s->ring_dev[slot], true, false, nullptr);
+        rc = enqueue_fill(s, frames, sample_rate_hz, s->stream, s->ring_dev[slot], true, false, nullptr, (int)slot);
         if (rc != S2R_OK) return rc;
     }
-    S2R_HIP(s, hipEventRecord(s->ring_done[slot], s->stream));
+    // (a deferred mix records the slot's event when it is launched: by the next fill_begin or by fill_end)
+    if (!(s->dmix.active && s->dmix.ring_slot == (int)slot)) S2R_HIP(s, hipEventRecord(s->ring_done[slot], s->stream));
     s->ring_frames[slot] = frames;
     s->ring_count++;
     return S2R_OK;
@@ -864,6 +897,11 @@ int s2r_fill_end(s2r_synth *s, float *mono_out) {
     if (s->ring_count == 0) return set_err(s, S2R_ERR_INVALID, "no fill in flight");
     const uint32_t slot = s->ring_head;
     if (s->ring_frames[slot] && !mono_out) return set_err(s, S2R_ERR_INVALID, "null output buffer");
+    if (s->dmix.active && s->dmix.ring_slot == (int)slot) {      // nobody began another fill in the meantime
+        S2R_HIP(s, hipSetDevice(s->device));
+        int rc = launch_deferred_mix(s, s->stream);
+        if (rc != S2R_OK) return rc;
+    }
     S2R_HIP(s, hipEventSynchronize(s->ring_done[slot]));
     if (s->ring_frames[slot]) std::memcpy(mono_out, s->ring_host[slot], s->ring_frames[slot] * sizeof(float));
     s->ring_head ^= 1u;
