@@ -765,6 +765,45 @@ def _bank():
     return b
 
 
+def test_fill_begin_mixed_with_the_other_fill_calls():
+    """a fill begun and not yet ended leaves its mix to whoever comes next (s2r_host.cpp DeferredMix): another fill_begin
+    (with or without timed events), a synchronous s2r_fill, s2r_render_voices, or its own fill_end — the buffers come
+    out as if every fill had been a plain s2r_fill"""
+    a = s2.Synth(300, max_frames=256)
+    b = s2.Synth(300, max_frames=256)
+    rng = np.random.RandomState(9)
+
+    def events(timed):
+        ev = np.zeros(12, dtype=s2.NOTE_EVENT_DTYPE)
+        ev["kind"] = rng.randint(0, 2, 12); ev["note"] = rng.randint(40, 90, 12); ev["velocity"] = 1.0
+        ev["frame"] = np.sort(rng.randint(0, 16, 12)) * 16 if timed else 0
+        return ev
+    init = np.zeros(200, dtype=s2.NOTE_EVENT_DTYPE); init["kind"] = 1; init["note"] = 40 + np.arange(200) % 50; init["velocity"] = 1.0
+    a.note_events(init); b.note_events(init)
+    want, got = [], []
+    plan = ["begin", "begin_timed", "end", "sync", "end", "begin", "voices", "end", "begin", "begin", "end", "end"]
+    for step in plan:
+        if step == "end":
+            got.append(b.sample_end(np.empty(256, dtype=np.float32)).copy())
+            continue
+        if step == "voices":
+            pa, pb = a.render_voices(256), b.render_voices(256)
+            assert_bits_equal(pb, pa, "render_voices behind a fill in flight")
+            continue
+        ev = events(step == "begin_timed")
+        a.note_events(ev); b.note_events(ev)
+        w = a.sample(np.empty(256, dtype=np.float32)).copy()
+        if step == "sync":
+            g = b.sample(np.empty(256, dtype=np.float32)).copy()
+            assert_bits_equal(g, w, "s2r_fill behind a fill in flight")
+        else:
+            want.append(w)
+            b.sample_begin(256)
+    assert len(want) == len(got)
+    for k, (w, g) in enumerate(zip(want, got)):
+        assert_bits_equal(g, w, "begun fill %d" % k)
+
+
 @pytest.mark.parametrize("frames", [1024, 1040, 2048])
 def test_super_chunk_layouts(frames):
     """the whole fill as one super-chunk (frames <= 1024 on a grid no larger than the device: group sums in one LDS
