@@ -7,7 +7,7 @@ import numpy as np
 import synth2_amd as s2
 from bench import make_c3_events, FRAMES, SR, PERIOD
 
-V = 65536
+V = int(os.environ.get("V", 65536))
 cyc = make_c3_events(V, PERIOD)
 for frames in (FRAMES, 16):
     s = s2.Synth(V, max_frames=FRAMES)
