@@ -19,7 +19,7 @@ made PERIODIC so that the envelope-stage mix is stationary and the result does n
 lives one C3 life (on -> LCG note-off -> release -> silent) every 64 buffers, the lives start 1/64 of the pool per
 buffer, in index order (the allocation policy — oldest voice, lowest index — then restarts exactly the voices whose
 turn it is).  Note-ons land on buffer starts, note-offs on their 16-frame boundary INSIDE the buffer (timed events, the
-granularity s2_bin's loop has, main.rs:138-143).  Before the warm-up the population is aged by one whole period
+granularity s2_bin's loop has, main.rs:138-143).  Before the warm-up the population is aged by six whole periods
 (untimed set-up).  Workload `churn` is round 1's: everything on at frame 0, then 128 note-offs + 128 note-ons per
 buffer per 64 k voices.
 
@@ -47,6 +47,7 @@ if ROOT not in sys.path:
 
 SR = 48000
 FRAMES = 1024
+C3_SETUP = 6 * 64 + 2      # untimed set-up buffers of workload c3 (tools/summarize_prof.py maps launches to phases with it)
 PERIOD = 64                     # buffers between two lives of a voice (workload c3)
 # algorithmic HBM bytes per started voice per fill: read pitch, offset, release, flags, phase,
 # lpf_last, seed (7 x 4 B) and write offset, phase, lpf_last (3 x 4 B)        
@@ -228,7 +229,9 @@ def main():
         period = PERIOD if total >= PERIOD else 1
         cyc = make_c3_events(total, period)
         events_of = lambda k: cyc[k % period]
-        n_setup = period + 2                      # one whole period: every voice has lived once, the stage mix is stationary
+        # six periods: after the first every voice has lived once and the stage mix is stationary; the rest is ~25 ms of
+        # back-to-back launches so that the timed steps (the driver times 20 of them: 1.3 ms) see settled clocks and caches
+        n_setup = (C3_SETUP - 2) // PERIOD * period + 2
     else:
         init = np.zeros(total, dtype=s2.NOTE_EVENT_DTYPE)
         init["kind"] = 1
@@ -386,7 +389,7 @@ def main():
             "config": {"workload": ("C3 (SURVEY 8d), periodic: %d voices per GPU, default patch (example.synth2 empty body: saw + amp/mod ADSR + "
                                     "one-pole LPF), 48 kHz, 1024-frame buffers; every voice lives one C3 life (note-on, note-off after "
                                     "16*(512 + lcg(v) mod 2048) frames, release) per %d buffers, lives staggered 1/%d of the pool per buffer; "
-                                    "%.0f events per buffer, note-offs as timed events on their 16-frame boundary; population aged one period "
+                                    "%.0f events per buffer, note-offs as timed events on their 16-frame boundary; population aged six periods "
                                     "before the warm-up" % (vpg, PERIOD, PERIOD, n_events_per_step)) if args.workload == "c3" else
                                    ("churn: %d voices per GPU, default patch, 48 kHz, 1024-frame buffers, all on at frame 0, then %d note-off + %d "
                                     "note-on per buffer per 64k voices" % (vpg, args.churn, args.churn)),

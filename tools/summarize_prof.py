@@ -13,7 +13,9 @@ import sys
 from collections import defaultdict
 
 
-SETUP = int(os.environ.get("S2R_PROF_SETUP", "66"))      # bench.py's untimed set-up buffers (workload c3: PERIOD + 2)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench      # noqa: E402
+SETUP = int(os.environ.get("S2R_PROF_SETUP", str(bench.C3_SETUP)))      # bench.py's untimed set-up buffers (workload c3)
 
 
 def main():
