@@ -255,7 +255,22 @@ def main():
 
     in_flight = [0]
 
+    host_t = [0.0, 0.0, 0.0]                      # seconds inside s2r_note_events / s2r_fill_begin / s2r_fill_end (N = 1)
+
     def step(k):
+        if world == 1:
+            ta = time.perf_counter()
+            sh.note_events(events_of(k))
+            tb = time.perf_counter()
+            synth.sample_begin(FRAMES, SR)
+            tc = time.perf_counter()
+            in_flight[0] += 1
+            if in_flight[0] == 2:
+                synth.sample_end(out_host)
+                in_flight[0] -= 1
+            td = time.perf_counter()
+            host_t[0] += tb - ta; host_t[1] += tc - tb; host_t[2] += td - tc
+            return
         sh.note_events(events_of(k))
         if world == 1:
             # the host-buffer API with two buffers in flight, as s2_bin keeps them (audio_player.rs:56-60): buffer k is
@@ -286,11 +301,24 @@ def main():
     k0 += args.warmup
     fence()
     # ---- timed region: exactly K steps ----
+    host_t[:] = [0.0, 0.0, 0.0]
+    # The fence's blocking synchronize puts this thread to sleep, and it wakes on a core in a low power state: measured
+    # (per-step trace of the three calls), the next ~16 steps — most of the 20 the driver times — then run the host
+    # side 1.5-2x slower (s2r_note_events 19 -> 30 us, s2r_fill_begin 12 -> 30 us) and the step becomes host-bound.
+    # 5 ms of busy waiting between the fence and the timer bring the core back; the timed region is still exactly K
+    # steps with a fence on either side.
+    t_spin = time.perf_counter() + 0.005
+    while time.perf_counter() < t_spin:
+        pass
     t0 = time.perf_counter()
     for k in range(k0, k0 + args.steps):
         step(k)
+    t_loop = time.perf_counter() - t0
     fence()
     dt = time.perf_counter() - t0
+    host_split = {"note_events_us": 1e6 * host_t[0] / args.steps, "fill_begin_us": 1e6 * host_t[1] / args.steps,
+                  "fill_end_us": 1e6 * host_t[2] / args.steps, "final_fence_us": 1e6 * (dt - t_loop),
+                  "note": "host time per timed step inside the three calls (fill_end includes the wait for the GPU), and the fence behind the last step"}
     k0 += args.steps
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -324,7 +352,7 @@ def main():
         synth.set_timing(False)
         fence()
         k0 += n
-        return float(np.mean(kms)) if kms else float("nan")
+        return float(np.median(kms)) if kms else float("nan")      # (median: one launch behind a host hiccup reads milliseconds)
 
     kernel_ms = kernel_ms_loop(min(max(args.steps, 4), 16))
     # the same workload with the flat-envelope coefficient reuse and the coefficient tables switched off: every frame
@@ -409,7 +437,8 @@ def main():
                               "flops_per_voice_sample": FLOPS_PER_VOICE_SAMPLE, "kernel_ms": kernel_ms_full,
                               "issue_slots": valu_issue,
                               "note": "launch time with the flat-envelope reuse and the coefficient tables OFF, i.e. all 250 flop-eq per voice-sample executed in-lane"},
-            "value_host_api_sync": host_api_sync,
+            "host_time_per_step": host_split if world == 1 else None,
+               "value_host_api_sync": host_api_sync,
             "value_host_api_sync_note": "the same steps through s2r_fill, which returns every buffer in the caller's host memory before the next events are handed over (host event processing and GPU time add up instead of overlapping)",
             "value_kernel_only": vpg * FRAMES / kernel_s,
             "value_all_voices_modulating": all_mod,
