@@ -208,6 +208,15 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    # The CPU baseline runs FIRST (rank 0 of N = 1): it is reported beside the GPU number, and a box that has been idle
+    # hands the first process a package in its lowest power state — measured, the host side of the timed steps
+    # (s2r_note_events) then runs 2x slower and the step is host-bound.  Twenty seconds of all cores busy settle that.
+    cpu_legs = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = max(1, min(cores, 64))
+        cpu_legs = cpu_baseline_legs(cores, args.cpu_seconds)
+
     strong = args.voices_total > 0
     if strong:
         if args.voices_total % (64 * world):
@@ -448,10 +457,8 @@ def main():
         if world > 1:
             out["multi_gpu_note"] = ("the RCCL collective of this path has not been verified on hardware by its authors (no multi-GPU box "
                                      "was available to them): tests cover it with gloo only")
-        if world == 1 and not args.no_cpu_baseline:
-            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            cores = max(1, min(cores, 64))
-            legs = cpu_baseline_legs(cores, args.cpu_seconds)
+        if cpu_legs is not None:
+            legs = cpu_legs
             out["cpu_baseline"] = dict(legs[-1])                  # all cores at C3's pool size
             out["cpu_baseline"]["sample"] += "; C restatement of s2_lib (oracle/), not rustc output"
             out["cpu_baseline_legs"] = legs
