@@ -455,8 +455,8 @@ def main():
             "mix_checksum": float(np.abs(mix_host).sum()),
         }
         if world > 1:
-            out["multi_gpu_note"] = ("the RCCL collective of this path has not been verified on hardware by its authors (no multi-GPU box "
-                                     "was available to them): tests cover it with gloo only")
+            out["multi_gpu_note"] = ("this path has not been run on two or more GPUs by its authors (no such box was available to them): "
+                                     "tests cover it with N ranks under gloo and with one rank through RCCL")
         if cpu_legs is not None:
             legs = cpu_legs
             out["cpu_baseline"] = dict(legs[-1])                  # all cores at C3's pool size

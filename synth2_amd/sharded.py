@@ -20,8 +20,9 @@ The renderer and the row-combine are injectable so the exchange logic can be exe
 with gloo (tests/test_sharded_gloo.py feeds it partial rows made by the CPU oracle); the
 defaults are the HIP path and nothing else — there is no CPU fallback here.
 
-The RCCL collective itself has only ever run under gloo in this repository's tests (no multi-GPU box was available to
-the build): the first ``backend="nccl"`` execution is the driver's N-GPU bench.
+Of the RCCL path what a one-GPU box can run has run: ONE rank through ``backend="nccl"`` (``force_exchange``:
+tests/test_gpu_parity.py::test_sharded_exchange_through_rccl_with_one_rank — all-gather with and without overlap, and the
+reduce, bit-identical to the plain path) and N ranks under gloo; the first N-GPU execution is the driver's bench.
 """
 import torch
 import torch.distributed as dist
@@ -31,7 +32,7 @@ from . import synth as _synth
 
 class ShardedSynth:
     def __init__(self, voices_per_rank, max_frames=1024, rank=0, world=1, device=None, renderer=None,
-                 combine=None, block_voices=0, overlap=True, interleave=64, reduce_to_root=False):
+                 combine=None, block_voices=0, overlap=True, interleave=64, reduce_to_root=False, force_exchange=False):
         self.rank, self.world = rank, world
         self.voices_per_rank = voices_per_rank
         self.total_voices = voices_per_rank * world
@@ -48,8 +49,12 @@ class ShardedSynth:
                                     block_voices=block_voices, **kw)
         self.renderer = renderer
         self.combine = combine if combine is not None else self._combine_hip
-        self.overlap = overlap and world > 1
-        self.reduce_to_root = reduce_to_root and world > 1
+        # force_exchange: a single rank still goes through the collective (a rehearsal of the N-rank path's calls on a
+        # one-GPU box: tests/test_gpu_parity.py::test_sharded_exchange_through_rccl_with_one_rank)
+        self.force_exchange = force_exchange and world == 1
+        exchange = world > 1 or self.force_exchange
+        self.overlap = overlap and exchange
+        self.reduce_to_root = reduce_to_root and exchange
         # every buffer is exchanged as whole max_frames rows (4 KiB at 1024 frames: the exchange is latency-bound), so a
         # shorter fill needs neither a temporary nor a wait; what lies behind `frames` in a row is never read
         self.partial = [torch.zeros(max_frames, dtype=torch.float32, device=self.device) for _ in range(2)]
@@ -105,14 +110,14 @@ class ShardedSynth:
         slot = self._k & 1
         self._k += 1
         part = self.partial[slot]
-        if self.world == 1 and hasattr(self.renderer, "fill_device_root") and self.combine == self._combine_hip:
+        if self.world == 1 and not self.force_exchange and hasattr(self.renderer, "fill_device_root") and self.combine == self._combine_hip:
             # one shard: its mix kernel roots the sum itself ((+0.0) + total), no combine pass
             self.renderer.fill_device_root(self.mix.data_ptr(), frames, sample_rate, self._stream_ptr())
             if self._host_target is not None:
                 self._host_target.copy_(self.mix, non_blocking=True)
             return
         self.renderer.fill_device(part.data_ptr(), frames, sample_rate, self._stream_ptr())
-        if self.world == 1:
+        if self.world == 1 and not self.force_exchange:
             self.gathered[slot][0].copy_(part)
             self.combine(self.gathered[slot], 1, frames, self.mix)
             return

@@ -765,6 +765,21 @@ def _bank():
     return b
 
 
+def test_sharded_exchange_through_rccl_with_one_rank():
+    """the N-rank exchange (all-gather + rank-ordered combine, and the reduce variant) executed through RCCL by one rank
+    on this box's GPU — the collective's calls, shapes, work handles and stream ordering, short of a second GPU"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_rccl_one_rank_worker.py")],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "RCCL_ONE_RANK_OK" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+
+
 def test_fill_begin_mixed_with_the_other_fill_calls():
     """a fill begun and not yet ended leaves its mix to whoever comes next (s2r_host.cpp DeferredMix): another fill_begin
     (with or without timed events), a synchronous s2r_fill, s2r_render_voices, or its own fill_end — the buffers come
