@@ -373,6 +373,7 @@ def main():
     # ---- every voice inside its mod-envelope decay (N = 1): the whole pool re-triggered, then 8 buffers (the default
     #      patch's mod envelope decays for 9 600 frames = 9.4 buffers), coefficient tables ON (the product path) ----
     all_mod = None
+    kernel_ms_full_plain = None
     if world == 1:
         retrig = np.zeros(total, dtype=s2.NOTE_EVENT_DTYPE)
         retrig["kind"] = 1
@@ -387,6 +388,21 @@ def main():
             sh.fill(FRAMES, SR)
         fence()
         all_mod = total * FRAMES * 8 / (time.perf_counter() - t2)
+        # ... and the same population with every shortcut off (no tables, no flat-envelope reuse): the arithmetic of
+        # SURVEY 8(d) executed in-lane by every voice on every frame, no note events in the way — the cleanest reading of
+        # the VALU roofline (the C3 launches above carry their events' wave imbalance on top)
+        synth.set_flat_shortcut(False)
+        sh.note_events(retrig)
+        sh.fill(FRAMES, SR)
+        synth.set_timing(True)
+        kms = []
+        for _ in range(8):
+            sh.fill(FRAMES, SR)
+            kms.append(synth.last_render_ms())
+        synth.set_timing(False)
+        synth.set_flat_shortcut(True)
+        fence()
+        kernel_ms_full_plain = float(np.median(kms))
 
     if rank == 0:
         value = total * FRAMES * args.steps / dt_max
@@ -444,8 +460,10 @@ def main():
             "roofline_valu": {"bound": "valu-fp32", "achieved": valu_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": valu_tf / VALU_PEAK_TFLOPS,
                               "flops_per_voice_sample": FLOPS_PER_VOICE_SAMPLE, "kernel_ms": kernel_ms_full,
+                              "frac_no_events": (FLOPS_PER_VOICE_SAMPLE * vpg * FRAMES / (kernel_ms_full_plain * 1e-3) / 1e12 / VALU_PEAK_TFLOPS) if kernel_ms_full_plain else None,
+                              "kernel_ms_no_events": kernel_ms_full_plain,
                               "issue_slots": valu_issue,
-                              "note": "launch time with the flat-envelope reuse and the coefficient tables OFF, i.e. all 250 flop-eq per voice-sample executed in-lane"},
+                              "note": "launch time with the flat-envelope reuse and the coefficient tables OFF, i.e. all 250 flop-eq per voice-sample executed in-lane: `frac` on the C3 launches (their event-dense waves set the kernel's length), `frac_no_events` on the whole pool re-triggered and held (what round 1's figure, 0.53, was measured on)"},
             "host_time_per_step": host_split if world == 1 else None,
                "value_host_api_sync": host_api_sync,
             "value_host_api_sync_note": "the same steps through s2r_fill, which returns every buffer in the caller's host memory before the next events are handed over (host event processing and GPU time add up instead of overlapping)",
