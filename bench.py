@@ -457,13 +457,17 @@ def main():
                          "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": "s2r_render_kernel", "kernel_ms": kernel_ms,
                          "note": "algorithmic bytes = %d B per voice per fill; the path is VALU-issue-bound, see roofline_valu" % BYTES_PER_VOICE_FILL},
-            "roofline_valu": {"bound": "valu-fp32", "achieved": valu_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": valu_tf / VALU_PEAK_TFLOPS,
-                              "flops_per_voice_sample": FLOPS_PER_VOICE_SAMPLE, "kernel_ms": kernel_ms_full,
-                              "frac_no_events": (FLOPS_PER_VOICE_SAMPLE * vpg * FRAMES / (kernel_ms_full_plain * 1e-3) / 1e12 / VALU_PEAK_TFLOPS) if kernel_ms_full_plain else None,
-                              "kernel_ms_no_events": kernel_ms_full_plain,
-                              "issue_slots": valu_issue,
-                              "note": "launch time with the flat-envelope reuse and the coefficient tables OFF, i.e. all 250 flop-eq per voice-sample executed in-lane: `frac` on the C3 launches (their event-dense waves set the kernel's length), `frac_no_events` on the whole pool re-triggered and held (what round 1's figure, 0.53, was measured on)"},
+            "roofline_valu": (lambda tf_c3, tf_plain: {
+                "bound": "valu-fp32", "achieved": tf_plain if tf_plain else tf_c3, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": (tf_plain if tf_plain else tf_c3) / VALU_PEAK_TFLOPS,
+                "flops_per_voice_sample": FLOPS_PER_VOICE_SAMPLE,
+                "kernel_ms": kernel_ms_full_plain if kernel_ms_full_plain else kernel_ms_full,
+                "frac_c3_launches": tf_c3 / VALU_PEAK_TFLOPS, "kernel_ms_c3_launches": kernel_ms_full,
+                "issue_slots": valu_issue,
+                "note": "launch time with the flat-envelope reuse and the coefficient tables OFF, i.e. all 250 flop-eq per voice-sample executed in-lane. "
+                        "`frac`: the whole pool re-triggered and held, every voice inside its mod decay, no note events (the population round 1's 0.53 was measured on); "
+                        "`frac_c3_launches`: the C3 launches of the timed region in the same mode, whose event-dense waves set the launch's length (and have no tables to run the dense-event loop on in this mode)"})(
+                valu_tf, (FLOPS_PER_VOICE_SAMPLE * vpg * FRAMES / (kernel_ms_full_plain * 1e-3) / 1e12) if kernel_ms_full_plain else None),
             "host_time_per_step": host_split if world == 1 else None,
                "value_host_api_sync": host_api_sync,
             "value_host_api_sync_note": "the same steps through s2r_fill, which returns every buffer in the caller's host memory before the next events are handed over (host event processing and GPU time add up instead of overlapping)",
