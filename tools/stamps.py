@@ -44,15 +44,17 @@ for rep in range(3):
     t = st.astype(np.int64)
     t0 = t[:, 0].min()
     total = t[:, 15] - t[:, 0]
-    names = ["prologue"] + ["sc%d work" % i if j == 0 else "sc%d combine" % i for i in range(4) for j in range(2)] + ["epilogue"]
-    cols = [t[:, 1] - t[:, 0]] + [t[:, 2 + i] - t[:, 1 + i] for i in range(8)] + [t[:, 15] - t[:, 9]]
+    # (a fill of up to 1024 frames on a grid no larger than the device is ONE super-chunk: slots 2, 3 and then 15)
+    n_sc = int(np.count_nonzero(t[0, 2:10])) // 2
+    names = ["prologue"] + ["sc%d work" % i if j == 0 else "sc%d combine" % i for i in range(n_sc) for j in range(2)] + ["epilogue"]
+    cols = [t[:, 1] - t[:, 0]] + [t[:, 2 + i] - t[:, 1 + i] for i in range(2 * n_sc)] + [t[:, 15] - t[:, 1 + 2 * n_sc]]
     t[:, 15] = np.where(t[:, 15] == 0, t[:, 0], t[:, 15])
     slow = int(np.argmax(t[:, 15]))
     print("fill %d (%s): kernel span %.1f us at 100 MHz-free ticks=cycles: first entry -> last exit %d cycles; wave total median %d, max %d (wave %d)" % (
         k, kind, 0.0, int(t[:, 15].max() - t0), int(np.median(total)), int(total.max()), int(np.argmax(total))))
     print("   entry skew (last wave's entry - first's): %d cycles" % int(t[:, 0].max() - t0))
     ev_w = np.nonzero(t[:, 11] > 0)[0]
-    work = sum(cols[1 + 2 * i] for i in range(4))
+    work = sum(cols[1 + 2 * i] for i in range(n_sc))
     print("   waves with timed events: %d; events per such wave: median %d max %d" % (ev_w.size, int(np.median(t[ev_w, 11])) if ev_w.size else 0, int(t[:, 11].max())))
     order = np.argsort(-total)[:12]
     x = st[:, 10]
@@ -65,9 +67,9 @@ for rep in range(3):
     med = np.argsort(total)[len(total) // 2 - 2: len(total) // 2 + 2]
     print("   median waves: " + "  ".join("w%d dense %d chunks %d cyc, runs %d chunks %d cyc (%d/chunk), general %d |" % (
         w, t[w, 12], t_dense[w], runchunks[w], t_run[w], t_run[w] // max(1, runchunks[w]), 0) for w in med))
-    print("   slowest waves: " + "  ".join("w%d total %d work %d ev %d dense %d general %d runs %d |" % (w, total[w], work[w], t[w, 11], t[w, 12], t[w, 13], t[w, 14]) for w in order[:6]))
+    print("   slowest waves: " + "  ".join("w%d total %d work %d ev %d dense %d runs %d |" % (w, total[w], work[w], t[w, 11], t[w, 12], t[w, 14]) for w in order[:6]))
     if ev_w.size:
         nb = [w for w in ev_w if w + 1 < waves and t[w + 1, 11] == 0][:6]
-        print("   event wave vs its neighbour without events: " + "  ".join("w%d(ev %d dense %d gen %d runs %d) work %d vs %d (gen %d runs %d) |" % (w, t[w, 11], t[w, 12], t[w, 13], t[w, 14], work[w], work[w + 1], t[w + 1, 13], t[w + 1, 14]) for w in nb))
+        print("   event wave vs its neighbour without events: " + "  ".join("w%d(ev %d dense %d runs %d) work %d vs %d (runs %d) |" % (w, t[w, 11], t[w, 12], t[w, 14], work[w], work[w + 1], t[w + 1, 14]) for w in nb))
     for n, c in zip(names, cols):
         print("   %-12s median %7d   p99 %7d   max %7d   | last-exiting wave %d: %7d" % (n, int(np.median(c)), int(np.percentile(c, 99)), int(c.max()), slow, int(c[slow])))
