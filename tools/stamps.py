@@ -65,6 +65,7 @@ for rep in range(3):
     t_top = (y >> np.uint64(32)).astype(np.int64); t_sel = (y & np.uint64(0xffffffff)).astype(np.int64)
     print("   slowest waves, outside the loops: " + "  ".join("w%d events at the loop top %d cyc, choosing runs %d cyc (%d runs) |" % (w, t_top[w], t_sel[w], t[w, 14]) for w in order[:5]))
     med = np.argsort(total)[len(total) // 2 - 2: len(total) // 2 + 2]
+    print("   median waves, outside the loops: " + "  ".join("w%d loop top %d cyc, choosing runs %d cyc (%d runs) |" % (w, t_top[w], t_sel[w], t[w, 14]) for w in med))
     print("   median waves: " + "  ".join("w%d dense %d chunks %d cyc, runs %d chunks %d cyc (%d/chunk), general %d |" % (
         w, t[w, 12], t_dense[w], runchunks[w], t_run[w], t_run[w] // max(1, runchunks[w]), 0) for w in med))
     print("   slowest waves: " + "  ".join("w%d total %d work %d ev %d dense %d runs %d |" % (w, total[w], work[w], t[w, 11], t[w, 12], t[w, 14]) for w in order[:6]))
