@@ -46,6 +46,20 @@ class Synth {
         const int rc = s2r_create(&cfg, &h_);
         if (rc != S2R_OK) throw Error(rc, s2r_status_string(rc));
     }
+    // ONE Synth over several GPUs (s2r_config.devices): the pool cut into one shard per device, the allocation policy
+    // run once per event, the shards' partial mixes added in shard order on devices[0]
+    static Synth with_devices(uint32_t num_voices, const int *devices, uint32_t n_devices, uint32_t max_frames = 2048,
+                              uint32_t shard_interleave = 64) {
+        s2r_config cfg{};
+        cfg.struct_size = sizeof cfg;
+        cfg.total_voices = num_voices;
+        cfg.max_frames = max_frames;
+        cfg.device = -1;
+        cfg.shard_interleave = shard_interleave;
+        cfg.n_devices = n_devices;
+        for (uint32_t k = 0; k < n_devices && k < S2R_MAX_DEVICES; ++k) cfg.devices[k] = devices[k];
+        return Synth(cfg);
+    }
     ~Synth() { s2r_destroy(h_); }
     Synth(const Synth &) = delete;
     Synth &operator=(const Synth &) = delete;
@@ -59,6 +73,11 @@ class Synth {
     void note_off(Note note) { check(s2r_note_off(h_, note.v)); }                                    // synth.rs:72-80
     // Synth::sample(&mut [f32], SampleRateKhz), synth.rs:154-169
     void sample(float *buffer, size_t len, SampleRateKhz sample_rate) { check(s2r_fill(h_, buffer, len, sample_rate.v)); }
+    // the same in two halves for a caller with two buffers in flight (s2_bin: audio_player.rs:56-60, main.rs:135-149)
+    void sample_begin(size_t len, SampleRateKhz sample_rate) { check(s2r_fill_begin(h_, len, sample_rate.v)); }
+    void sample_end(float *buffer, size_t capacity) { check(s2r_fill_end(h_, buffer, capacity)); }
+    // a batch of events, each at frame 0 or at its 16-frame boundary inside the next buffer (main.rs:138-143)
+    void note_events(const s2r_note_event *events, size_t n) { check(s2r_note_events(h_, events, n)); }
 
     s2r_synth *handle() { return h_; }
 

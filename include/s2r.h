@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define S2R_ABI_VERSION 3
+#define S2R_ABI_VERSION 4
 
 typedef enum {
     S2R_OK = 0,
@@ -86,6 +86,7 @@ typedef enum {
     S2R_FILT_SVF_LP = 6, S2R_FILT_SVF_BP = 7, S2R_FILT_SVF_HP = 8
 } s2r_filter_kind;
 
+#define S2R_MAX_DEVICES 16
 typedef struct {
     uint32_t struct_size;          /* = sizeof(s2r_config) */
     uint32_t total_voices;         /* size of the voice pool; the reference fixes it at
@@ -100,9 +101,7 @@ typedef struct {
                                       0 => 256.  Part of the mix-tree spec */
     uint32_t mix_groups;           /* >= 1: second-level grouping of the block partials so a
                                       1-GPU run reproduces the G-GPU summation order; 0 => 1 */
-    uint32_t lanes_per_voice;      /* 0 or 1: one GPU lane per voice.  (2 and 4 — round 1's kernels that
-                                      spread a voice over several lanes, bit-identical and slower at every
-                                      pool size — are still accepted and mean 1.) */
+    uint32_t reserved0;            /* must be 0 */
     /* Round-robin sharding (0 => off: this handle renders the contiguous range above).  G > 0: the
      * pool is dealt out in runs of G consecutive voices to shard_count handles, and this one
      * (shard_index) renders every shard_count-th run — its local voice l is pool voice
@@ -114,6 +113,17 @@ typedef struct {
     uint32_t shard_interleave;
     uint32_t shard_index;
     uint32_t shard_count;
+    /* Device list.  n_devices <= 1: the handle renders on `device`.  n_devices = N > 1: ONE handle
+     * renders the pool on devices[0..N) — the pool is cut into N shards (contiguous ranges when shard_interleave is
+     * 0, else dealt out in runs of shard_interleave voices), shard k lives on devices[k] (an ordinal may repeat), the
+     * allocation policy of synth.rs:61-120 runs ONCE per event on the calling thread and the event is routed to the
+     * shard that holds the chosen voice; every fill each shard leaves its partial mix in row k of a buffer on
+     * devices[0] (a peer-to-peer write over xGMI, 4 KiB) and devices[0] adds the rows in shard order rooted at +0.0
+     * (synth.rs:176,195) — with contiguous shards the very association one device produces with mix_groups = N.
+     * shard_begin / shard_voices / shard_index / shard_count must be 0 (or shard_count 1) then; total_voices must be
+     * a multiple of N * block_voices. */
+    uint32_t n_devices;
+    int32_t devices[S2R_MAX_DEVICES];
 } s2r_config;
 
 /* One voice's complete state, for checkpoint/resume and tests.
@@ -193,7 +203,11 @@ int s2r_fill(s2r_synth *s, float *mono_out, size_t frames, uint32_t sample_rate_
  * between a begin and its end the caller may hand over the next buffer's events and begin that fill.  s2r_fill is
  * begin + end. */
 int s2r_fill_begin(s2r_synth *s, size_t frames, uint32_t sample_rate_hz);
-int s2r_fill_end(s2r_synth *s, float *mono_out);
+/* `capacity` = floats `mono_out` can take: S2R_ERR_INVALID (and nothing is consumed) when it is smaller than the
+ * `frames` the oldest fill was begun with — s2r_fill_pending_frames says how many that is (0: none in flight). */
+int s2r_fill_end(s2r_synth *s, float *mono_out, size_t capacity);
+size_t s2r_fill_pending_frames(const s2r_synth *s);
+uint32_t s2r_fills_in_flight(const s2r_synth *s);
 /* The audio callback's mono -> every channel copy (s2_bin/src/audio_player.rs:224-228),
  * done on device: interleaved L,R with L == R. */
 int s2r_fill_stereo(s2r_synth *s, float *interleaved_lr_out, size_t frames, uint32_t sample_rate_hz);
@@ -231,7 +245,7 @@ int s2r_set_noise_seed(s2r_synth *s, uint32_t voice_index, uint32_t seed);
 uint32_t s2r_abi_version(void);
 uint32_t s2r_shard_voices(const s2r_synth *s);
 uint32_t s2r_block_voices(const s2r_synth *s);
-uint32_t s2r_lanes_per_voice(const s2r_synth *s);
+uint32_t s2r_device_count(const s2r_synth *s);                  /* 1, or the N of a device list */
 /* note_offs that found no active (started, unreleased) voice holding the note and therefore did nothing.  The
  * reference ignores them silently: its `log::warn!("note {} released twice")` (synth.rs:77) sits behind
  * find_active_voice, which only returns unreleased voices (synth.rs:36-38,82-90), so it can never fire — this
@@ -246,12 +260,10 @@ int s2r_set_timing(s2r_synth *s, int enabled);
  * Turning it off makes every frame pay the full pow/exp chain (bench.py's
  * `value_all_voices_modulating` leg). */
 int s2r_set_flat_shortcut(s2r_synth *s, int enabled);
-/* Measurement knob (default 1): 64-voice groups whose mod envelope moves during a fill get
- * their LPF coefficients computed ahead of the render kernel instead of in-lane.
- * 0: off; 1: on (for fills of >= 128 frames over shards of >= 1024 voices — shorter or smaller
- * work is quicker without the extra launches), and a fill with few untimed events applies them in
- * the classification launch (events in the kernel arguments); 2: like 1 but always with the separate
- * events kernel; 3 / 4: like 1 / 2 for every fill size and shard size (tests).  Same bits. */
+/* Measurement knob (default 1): where a patch's filter coefficients come from while a mod envelope moves.
+ * 0: computed in-lane per frame; 1: read from the patch's coefficient tables, and a fill with few
+ * untimed events carries them in the render kernel's arguments; 2: tables, but note events always through their
+ * own launch; 3 / 4: synonyms of 1 / 2 (earlier rounds' test matrices).  Same bits in every mode. */
 int s2r_set_coeff_stream(s2r_synth *s, int enabled);
 float s2r_last_render_ms(s2r_synth *s);
 const char *s2r_last_error(const s2r_synth *s);             /* never NULL */

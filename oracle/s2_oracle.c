@@ -15,6 +15,7 @@
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 /* ------------------------------------------------------------------ units.rs */
 
@@ -645,57 +646,162 @@ void s2o_render_voices(s2o_synth *s, float *per_voice, size_t frames, uint32_t s
         render_one_voice(s, &s->voices[v], per_voice + (size_t)v * frames, frames, sr);
 }
 
-typedef struct { s2o_synth *s; float *pv; size_t frames; uint32_t sr; uint32_t v0, v1; float *acc; } mt_job;
-static void *mt_render(void *arg) {
-    mt_job *j = (mt_job *)arg;
-    for (uint32_t v = j->v0; v < j->v1; v++)
-        render_one_voice(j->s, &j->s->voices[v], j->pv + (size_t)v * j->frames, j->frames, j->sr);
-    return NULL;
-}
-void s2o_render_voices_mt(s2o_synth *s, float *per_voice, size_t frames, uint32_t sr, int threads) {
-    if (threads < 1) threads = 1;
-    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads);
-    mt_job *jobs = (mt_job *)malloc(sizeof(mt_job) * threads);
-    for (int t = 0; t < threads; t++) {
-        jobs[t] = (mt_job){ s, per_voice, frames, sr,
-                            (uint32_t)((uint64_t)s->num_voices * t / threads),
-                            (uint32_t)((uint64_t)s->num_voices * (t + 1) / threads), NULL };
-        pthread_create(&th[t], NULL, mt_render, &jobs[t]);
+/* ------------------------------------------------------------------ multi-threaded drivers
+ * (timing legs and the full-size parity tests).  Voices are independent until the add (synth.rs:195), so they are
+ * sharded over a PERSISTENT pool of worker threads: created on first use, parked on a condition variable between
+ * jobs, never joined per buffer; per-thread row and accumulator buffers are kept and grown, not allocated per call. */
+typedef void (*pool_fn)(void *ctx, int t, int n_threads);
+static struct {
+    pthread_mutex_t mu; pthread_cond_t go, done;
+    pthread_t *th; int n_workers;            /* workers 1..n (the caller is thread 0) */
+    pool_fn fn; void *ctx; int n_active; unsigned long long gen; int remaining;
+    float **scratch; size_t *scratch_cap;    /* per thread: grown on demand, kept */
+    int scratch_n;
+} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, NULL, 0, NULL, NULL, 0, 0, 0, NULL, NULL, 0 };
+
+static void *pool_worker(void *arg) {
+    const int me = (int)(intptr_t)arg;
+    unsigned long long seen = 0;
+    pthread_mutex_lock(&g_pool.mu);
+    for (;;) {
+        while (g_pool.gen == seen) pthread_cond_wait(&g_pool.go, &g_pool.mu);
+        seen = g_pool.gen;
+        if (me < g_pool.n_active) {
+            pool_fn fn = g_pool.fn; void *ctx = g_pool.ctx; const int n = g_pool.n_active;
+            pthread_mutex_unlock(&g_pool.mu);
+            fn(ctx, me, n);
+            pthread_mutex_lock(&g_pool.mu);
+            if (--g_pool.remaining == 0) pthread_cond_signal(&g_pool.done);
+        }
     }
-    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
-    free(th); free(jobs);
+    return NULL;
 }
 
-static void *mt_sample(void *arg) {
-    mt_job *j = (mt_job *)arg;
-    float *row = (float *)malloc(sizeof(float) * j->frames);
-    for (size_t i = 0; i < j->frames; i++) j->acc[i] = 0.0f;
-    for (uint32_t v = j->v0; v < j->v1; v++) {
-        if (!j->s->voices[v].has_current) continue;
-        render_one_voice(j->s, &j->s->voices[v], row, j->frames, j->sr);
-        for (size_t i = 0; i < j->frames; i++) j->acc[i] += row[i];
+static float *pool_scratch(int t, size_t floats) {
+    if (g_pool.scratch_cap[t] < floats) {
+        free(g_pool.scratch[t]);
+        g_pool.scratch[t] = (float *)malloc(sizeof(float) * floats);
+        g_pool.scratch_cap[t] = floats;
     }
-    free(row);
-    return NULL;
+    return g_pool.scratch[t];
+}
+
+/* runs fn(ctx, t, threads) for t = 0..threads-1, the caller being thread 0; returns when all are done */
+static void pool_run(int threads, pool_fn fn, void *ctx) {
+    if (threads < 1) threads = 1;
+    pthread_mutex_lock(&g_pool.mu);
+    if (g_pool.scratch_n < threads) {
+        g_pool.scratch = (float **)realloc(g_pool.scratch, sizeof(float *) * threads);
+        g_pool.scratch_cap = (size_t *)realloc(g_pool.scratch_cap, sizeof(size_t) * threads);
+        for (int t = g_pool.scratch_n; t < threads; t++) { g_pool.scratch[t] = NULL; g_pool.scratch_cap[t] = 0; }
+        g_pool.scratch_n = threads;
+    }
+    if (g_pool.n_workers < threads - 1) {
+        g_pool.th = (pthread_t *)realloc(g_pool.th, sizeof(pthread_t) * (threads - 1));
+        for (int t = g_pool.n_workers; t < threads - 1; t++)
+            pthread_create(&g_pool.th[t], NULL, pool_worker, (void *)(intptr_t)(t + 1));
+        g_pool.n_workers = threads - 1;
+    }
+    g_pool.fn = fn; g_pool.ctx = ctx; g_pool.n_active = threads; g_pool.remaining = threads - 1;
+    g_pool.gen++;
+    pthread_cond_broadcast(&g_pool.go);
+    pthread_mutex_unlock(&g_pool.mu);
+    fn(ctx, 0, threads);
+    pthread_mutex_lock(&g_pool.mu);
+    while (g_pool.remaining) pthread_cond_wait(&g_pool.done, &g_pool.mu);
+    pthread_mutex_unlock(&g_pool.mu);
+}
+
+typedef struct { s2o_synth *s; float *pv; size_t frames, stride, col0; uint32_t sr; float *acc; } mt_job;
+
+static void mt_render(void *ctx, int t, int n) {
+    mt_job *j = (mt_job *)ctx;
+    const uint32_t v0 = (uint32_t)((uint64_t)j->s->num_voices * t / n), v1 = (uint32_t)((uint64_t)j->s->num_voices * (t + 1) / n);
+    for (uint32_t v = v0; v < v1; v++)
+        render_one_voice(j->s, &j->s->voices[v], j->pv + (size_t)v * j->stride + j->col0, j->frames, j->sr);
+}
+void s2o_render_voices_mt(s2o_synth *s, float *per_voice, size_t frames, uint32_t sr, int threads) {
+    mt_job j = { s, per_voice, frames, frames, 0, sr, NULL };
+    pool_run(threads, mt_render, &j);
+}
+
+/* thread t's voices rendered and added (in index order) into its accumulator acc[t][frames_stride] at column col0 */
+static void mt_sample(void *ctx, int t, int n) {
+    mt_job *j = (mt_job *)ctx;
+    const uint32_t v0 = (uint32_t)((uint64_t)j->s->num_voices * t / n), v1 = (uint32_t)((uint64_t)j->s->num_voices * (t + 1) / n);
+    float row[16];
+    float *acc = j->acc + (size_t)t * j->stride + j->col0;
+    for (size_t i = 0; i < j->frames; i++) acc[i] = 0.0f;
+    for (uint32_t v = v0; v < v1; v++) {
+        if (!j->s->voices[v].has_current) continue;
+        for (size_t d = 0; d < j->frames; d += 16) {
+            const size_t m = j->frames - d < 16 ? j->frames - d : 16;
+            render_one_voice(j->s, &j->s->voices[v], row, m, j->sr);
+            for (size_t i = 0; i < m; i++) acc[d + i] += row[i];
+        }
+    }
+}
+static void sum_thread_partials(const float *acc, int threads, size_t stride, size_t frames, float *buffer) {
+    for (size_t i = 0; i < frames; i++) {
+        float a = 0.0f;
+        for (int t = 0; t < threads; t++) a += acc[(size_t)t * stride + i];
+        buffer[i] = a;
+    }
 }
 void s2o_sample_mt(s2o_synth *s, float *buffer, size_t frames, uint32_t sr, int threads) {
     if (threads < 1) threads = 1;
-    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads);
-    mt_job *jobs = (mt_job *)malloc(sizeof(mt_job) * threads);
-    float *acc = (float *)malloc(sizeof(float) * frames * threads);
-    for (int t = 0; t < threads; t++) {
-        jobs[t] = (mt_job){ s, NULL, frames, sr,
-                            (uint32_t)((uint64_t)s->num_voices * t / threads),
-                            (uint32_t)((uint64_t)s->num_voices * (t + 1) / threads), acc + (size_t)t * frames };
-        pthread_create(&th[t], NULL, mt_sample, &jobs[t]);
+    pthread_mutex_lock(&g_pool.mu);                   /* (the accumulators: thread 0's scratch, kept between calls) */
+    if (g_pool.scratch_n < 1) { g_pool.scratch = (float **)calloc(1, sizeof(float *)); g_pool.scratch_cap = (size_t *)calloc(1, sizeof(size_t)); g_pool.scratch_n = 1; }
+    float *acc = pool_scratch(0, frames * (size_t)threads);
+    pthread_mutex_unlock(&g_pool.mu);
+    mt_job j = { s, NULL, frames, frames, 0, sr, acc };
+    pool_run(threads, mt_sample, &j);
+    sum_thread_partials(acc, threads, frames, frames, buffer);
+}
+
+/* One buffer in the reference caller's pattern (s2_bin/src/main.rs:138-147): for every 16-frame chunk, the note
+ * events stamped with that frame are applied (in order), then Synth::sample renders the chunk.  Events: the layout of
+ * libs2r's s2r_note_event {u8 kind (0 off, 1 on, 2 program change), u8 note, u16 frame, f32 velocity}, sorted by
+ * frame; frames must be multiples of 16.  per_voice != NULL: every voice's frames, [num_voices][frames];
+ * mix != NULL: the voices of each thread added in index order, thread partials in thread order (timing leg). */
+static double g_events_seconds[2];       /* [0] inside note_on / note_off (the reference's O(V) scans), [1] rendering */
+void s2o_events_seconds(double out[2], int reset) {
+    out[0] = g_events_seconds[0]; out[1] = g_events_seconds[1];
+    if (reset) g_events_seconds[0] = g_events_seconds[1] = 0.0;
+}
+void s2o_render_events_mt(s2o_synth *s, const s2o_note_event *ev, size_t n_ev, float *per_voice, float *mix,
+                          size_t frames, uint32_t sr, int threads) {
+    if (threads < 1) threads = 1;
+    float *acc = NULL;
+    if (mix) {
+        pthread_mutex_lock(&g_pool.mu);
+        if (g_pool.scratch_n < 1) { g_pool.scratch = (float **)calloc(1, sizeof(float *)); g_pool.scratch_cap = (size_t *)calloc(1, sizeof(size_t)); g_pool.scratch_n = 1; }
+        acc = pool_scratch(0, frames * (size_t)threads);
+        pthread_mutex_unlock(&g_pool.mu);
     }
-    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
-    for (size_t i = 0; i < frames; i++) {
-        float a = 0.0f;
-        for (int t = 0; t < threads; t++) a += acc[(size_t)t * frames + i];
-        buffer[i] = a;
+    size_t k = 0, c = 0;
+    struct timespec ta, tb, tc;
+    while (c < frames) {
+        clock_gettime(CLOCK_MONOTONIC, &ta);
+        for (; k < n_ev && ev[k].frame <= c; k++) {          /* apply_all_midi_messages, main.rs:170-187 */
+            if (ev[k].kind == 1) s2o_note_on(s, ev[k].note, ev[k].velocity);
+            else if (ev[k].kind == 0) s2o_note_off(s, ev[k].note);
+            else s2o_program_change(s, ev[k].note);
+        }
+        clock_gettime(CLOCK_MONOTONIC, &tb);
+        /* the stretch up to the next event (a whole number of 16-frame sample() calls: the chunking restarts per
+         * call, synth.rs:158, and 16-frame calls of full chunks compose to one longer call of full chunks) */
+        size_t next = frames;
+        if (k < n_ev && ev[k].frame < frames) next = ev[k].frame;
+        const size_t n = next - c;
+        if (per_voice) { mt_job j = { s, per_voice, n, frames, c, sr, NULL }; pool_run(threads, mt_render, &j); }
+        else { mt_job j = { s, NULL, n, frames, c, sr, acc }; pool_run(threads, mt_sample, &j); }
+        clock_gettime(CLOCK_MONOTONIC, &tc);
+        g_events_seconds[0] += (double)(tb.tv_sec - ta.tv_sec) + 1e-9 * (double)(tb.tv_nsec - ta.tv_nsec);
+        g_events_seconds[1] += (double)(tc.tv_sec - tb.tv_sec) + 1e-9 * (double)(tc.tv_nsec - tb.tv_nsec);
+        c = next;
     }
-    free(th); free(jobs); free(acc);
+    if (mix) sum_thread_partials(acc, threads, frames, frames, mix);
 }
 
 /* synth.rs:171-203: accum = 0; for voices in index order (started ones only) accum += buf */
@@ -749,12 +855,62 @@ static float blocks_sum(const float *per_voice, uint32_t voices, size_t frames, 
     return total;
 }
 
+/* The same tree a row at a time (every addition of the scalar form above, in its order, on whole rows of `frames`
+ * values): the voice rows are read once, front to back, instead of once per frame with a stride of a whole row — what
+ * makes the 65 536-voice checks affordable.  tests/test_oracle_known_answers.py holds the two forms against each other. */
+static void rows_blocks_sum(const float *per_voice, uint32_t voices, size_t frames, uint32_t b0, uint32_t b1, uint32_t block_voices,
+                            float *total, float *run, float *blk, float *grp) {
+    for (uint32_t r0 = b0; r0 < b1; r0 += 16) {
+        const uint32_t r1 = r0 + 16 < b1 ? r0 + 16 : b1;
+        for (uint32_t b = r0; b < r1; b++) {
+            const uint32_t vb = b * block_voices;
+            for (uint32_t g = 0; g < block_voices / 16; g++) {
+                const uint32_t v0 = vb + 16 * g;
+                for (size_t i = 0; i < frames; i++) grp[i] = (v0 < voices) ? per_voice[(size_t)v0 * frames + i] : 0.0f;
+                for (uint32_t k = 1; k < 16; k++) {
+                    if (v0 + k < voices) { const float *row = per_voice + (size_t)(v0 + k) * frames; for (size_t i = 0; i < frames; i++) grp[i] += row[i]; }
+                    else for (size_t i = 0; i < frames; i++) grp[i] += 0.0f;
+                }
+                if (g == 0) memcpy(blk, grp, frames * sizeof(float));
+                else for (size_t i = 0; i < frames; i++) blk[i] += grp[i];
+            }
+            if (b == r0) memcpy(run, blk, frames * sizeof(float));
+            else for (size_t i = 0; i < frames; i++) run[i] += blk[i];
+        }
+        if (r0 == b0) memcpy(total, run, frames * sizeof(float));
+        else for (size_t i = 0; i < frames; i++) total[i] += run[i];
+    }
+}
+
 void s2o_mix_tree_partial(const float *per_voice, uint32_t voices, size_t frames, uint32_t block_voices, float *out) {
+    const uint32_t nblocks = (voices + block_voices - 1) / block_voices;
+    float *tmp = (float *)malloc(sizeof(float) * 3 * (frames ? frames : 1));
+    rows_blocks_sum(per_voice, voices, frames, 0, nblocks, block_voices, out, tmp, tmp + frames, tmp + 2 * frames);
+    free(tmp);
+}
+
+void s2o_mix_tree(const float *per_voice, uint32_t voices, size_t frames, s2o_tree tree, float *out) {
+    const uint32_t nblocks = (voices + tree.block_voices - 1) / tree.block_voices;
+    const uint32_t groups = tree.groups ? tree.groups : 1;
+    const uint32_t per_group = (nblocks + groups - 1) / groups;
+    float *tmp = (float *)malloc(sizeof(float) * 4 * (frames ? frames : 1));
+    for (size_t i = 0; i < frames; i++) out[i] = 0.0f;                /* accum = splat(0.0), synth.rs:176 */
+    for (uint32_t g = 0; g < groups; g++) {
+        const uint32_t b0 = g * per_group, b1 = b0 + per_group < nblocks ? b0 + per_group : nblocks;
+        if (b0 >= b1) continue;
+        rows_blocks_sum(per_voice, voices, frames, b0, b1, tree.block_voices, tmp, tmp + frames, tmp + 2 * frames, tmp + 3 * frames);
+        for (size_t i = 0; i < frames; i++) out[i] += tmp[i];
+    }
+    free(tmp);
+}
+
+/* the scalar form (one frame at a time), kept as the statement of the tree the row form is checked against */
+void s2o_mix_tree_partial_scalar(const float *per_voice, uint32_t voices, size_t frames, uint32_t block_voices, float *out) {
     uint32_t nblocks = (voices + block_voices - 1) / block_voices;
     for (size_t i = 0; i < frames; i++) out[i] = blocks_sum(per_voice, voices, frames, 0, nblocks, block_voices, i);
 }
 
-void s2o_mix_tree(const float *per_voice, uint32_t voices, size_t frames, s2o_tree tree, float *out) {
+void s2o_mix_tree_scalar(const float *per_voice, uint32_t voices, size_t frames, s2o_tree tree, float *out) {
     uint32_t nblocks = (voices + tree.block_voices - 1) / tree.block_voices;
     uint32_t groups = tree.groups ? tree.groups : 1;
     uint32_t per_group = (nblocks + groups - 1) / groups;

@@ -123,10 +123,22 @@ void s2o_render_voices_mt(s2o_synth *s, float *per_voice, size_t frames, uint32_
 /* render + sequential mix without materialising per-voice rows, voices sharded over
  * `threads` threads, thread partials summed in thread order (timing leg only). */
 void s2o_sample_mt(s2o_synth *s, float *buffer, size_t frames, uint32_t sample_rate, int threads);
+/* One buffer the way the reference's caller drives Synth (s2_bin/src/main.rs:138-147): MIDI applied between 16-frame
+ * sample() calls.  Events carry the frame (a multiple of 16, non-decreasing) at which they take effect; same layout as
+ * libs2r's s2r_note_event.  per_voice ([num_voices][frames]) and / or mix (thread partials in thread order) may be
+ * NULL.  Worker threads persist between calls. */
+typedef struct { uint8_t kind; uint8_t note; uint16_t frame; float velocity; } s2o_note_event;   /* kind: 0 off, 1 on, 2 program change */
+void s2o_render_events_mt(s2o_synth *s, const s2o_note_event *events, size_t n_events, float *per_voice, float *mix,
+                          size_t frames, uint32_t sample_rate, int threads);
+/* seconds spent by s2o_render_events_mt [0] in note_on / note_off (the reference's O(V) scans) and [1] rendering */
+void s2o_events_seconds(double out[2], int reset);
 void s2o_mix_sequential(const float *per_voice, uint32_t voices, size_t frames, float *out);
 void s2o_mix_tree(const float *per_voice, uint32_t voices, size_t frames, s2o_tree tree, float *out);
 /* partial mix of one shard (what one GPU produces): tree over the shard's voices, no root add */
 void s2o_mix_tree_partial(const float *per_voice, uint32_t voices, size_t frames, uint32_t block_voices, float *out);
+/* the same two, one frame at a time: the statement of the tree that the row-at-a-time forms above are tested against */
+void s2o_mix_tree_scalar(const float *per_voice, uint32_t voices, size_t frames, s2o_tree tree, float *out);
+void s2o_mix_tree_partial_scalar(const float *per_voice, uint32_t voices, size_t frames, uint32_t block_voices, float *out);
 
 /* process.rs:14-49 — one voice, caller-owned state */
 int s2o_process_layer_buf_simd(const s2o_layer_cfg *cfg, s2o_layer_state *st, float pitch,

@@ -48,9 +48,24 @@ class Tree(C.Structure):
     _fields_ = [("block_voices", C.c_uint32), ("groups", C.c_uint32)]
 
 
+_NATIVE = os.path.join(_HERE, "_build", "libs2oracle_native.so")
+_use_native = False
+
+
+def use_native_build():
+    """bench.py's cpu_baseline legs: the same sources compiled on THIS host with -march=native, into
+    oracle/_build/.  Must be called before the library is first loaded.  Same bits: -ffp-contract=off, no fast-math."""
+    global _use_native
+    assert _lib is None, "the oracle library is already loaded"
+    subprocess.check_call(["make", "-C", _HERE, "_build/libs2oracle_native.so"], stdout=subprocess.DEVNULL)
+    _use_native = True
+
+
 def build(force=False):
     if os.environ.get("S2O_LIB"):                # an instrumented build of the same sources (tests/test_sanitizers.py)
         return os.environ["S2O_LIB"]
+    if _use_native:
+        return _NATIVE
     if force or not os.path.exists(_LIB):
         subprocess.check_call(["make", "-C", _HERE, "libs2oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB
@@ -81,9 +96,13 @@ def lib():
     L.s2o_render_voices.argtypes = [P, _f32p, C.c_size_t, C.c_uint32]
     L.s2o_render_voices_mt.argtypes = [P, _f32p, C.c_size_t, C.c_uint32, C.c_int]
     L.s2o_sample_mt.argtypes = [P, _f32p, C.c_size_t, C.c_uint32, C.c_int]
+    L.s2o_render_events_mt.argtypes = [P, C.c_void_p, C.c_size_t, _f32p, _f32p, C.c_size_t, C.c_uint32, C.c_int]
+    L.s2o_events_seconds.argtypes = [C.POINTER(C.c_double), C.c_int]
     L.s2o_mix_sequential.argtypes = [_f32p, C.c_uint32, C.c_size_t, _f32p]
     L.s2o_mix_tree.argtypes = [_f32p, C.c_uint32, C.c_size_t, Tree, _f32p]
     L.s2o_mix_tree_partial.argtypes = [_f32p, C.c_uint32, C.c_size_t, C.c_uint32, _f32p]
+    L.s2o_mix_tree_scalar.argtypes = [_f32p, C.c_uint32, C.c_size_t, Tree, _f32p]
+    L.s2o_mix_tree_partial_scalar.argtypes = [_f32p, C.c_uint32, C.c_size_t, C.c_uint32, _f32p]
     L.s2o_process_layer_buf_simd.restype = C.c_int
     L.s2o_process_layer_buf_simd.argtypes = [C.POINTER(LayerCfg), C.POINTER(LayerState), C.c_float, C.c_uint32,
                                              C.c_uint32, C.c_int, C.c_uint32, _f32p, C.c_size_t]
@@ -191,9 +210,27 @@ class OracleSynth:
             self.L.s2o_render_voices(self.p, _fp(out), frames, sample_rate)
         return out
 
+    def render_events(self, events, frames, sample_rate=48000, threads=1, per_voice=True, mix=False):
+        """one buffer in s2_bin's pattern (main.rs:138-147): the events (structured array kind/note/frame/velocity, the
+        layout of libs2r's s2r_note_event, sorted by frame) applied between 16-frame sample() calls"""
+        ev = np.ascontiguousarray(events)
+        assert ev.dtype.itemsize == 8
+        pv = np.zeros((self.num_voices, frames), dtype=np.float32) if per_voice else None
+        mx = np.zeros(frames, dtype=np.float32) if mix else None
+        self.L.s2o_render_events_mt(self.p, ev.ctypes.data, ev.size, _fp(pv) if per_voice else None, _fp(mx) if mix else None,
+                                    frames, sample_rate, threads)
+        return pv if not mix else (mx if not per_voice else (pv, mx))
+
     @property
     def panicked(self):
         return bool(self.p.contents.panicked)
+
+
+def events_seconds(reset=True):
+    """(seconds inside note_on / note_off, seconds rendering) accumulated by render_events"""
+    out = (C.c_double * 2)()
+    lib().s2o_events_seconds(out, 1 if reset else 0)
+    return float(out[0]), float(out[1])
 
 
 def decim4_taps():
@@ -222,19 +259,20 @@ def mix_sequential(per_voice):
     return out
 
 
-def mix_tree(per_voice, block_voices=256, groups=1):
+def mix_tree(per_voice, block_voices=256, groups=1, scalar=False):
+    """the GPU's summation tree; scalar=True: the frame-at-a-time statement of it"""
     L = lib()
     pv = np.ascontiguousarray(per_voice, dtype=np.float32)
     out = np.zeros(pv.shape[1], dtype=np.float32)
-    L.s2o_mix_tree(_fp(pv), pv.shape[0], pv.shape[1], Tree(block_voices, groups), _fp(out))
+    (L.s2o_mix_tree_scalar if scalar else L.s2o_mix_tree)(_fp(pv), pv.shape[0], pv.shape[1], Tree(block_voices, groups), _fp(out))
     return out
 
 
-def mix_tree_partial(per_voice, block_voices=256):
+def mix_tree_partial(per_voice, block_voices=256, scalar=False):
     L = lib()
     pv = np.ascontiguousarray(per_voice, dtype=np.float32)
     out = np.zeros(pv.shape[1], dtype=np.float32)
-    L.s2o_mix_tree_partial(_fp(pv), pv.shape[0], pv.shape[1], block_voices, _fp(out))
+    (L.s2o_mix_tree_partial_scalar if scalar else L.s2o_mix_tree_partial)(_fp(pv), pv.shape[0], pv.shape[1], block_voices, _fp(out))
     return out
 
 

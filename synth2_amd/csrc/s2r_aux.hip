@@ -109,12 +109,13 @@ __global__ void __launch_bounds__(256) s2r_mix_kernel(const S2rMixParams m) {
 }
 
 // out[i] = ((+0.0 + rows[0][i]) + rows[1][i]) + ...   (rank-order combine of shard partials)
-__global__ void s2r_sum_rows_kernel(const float *rows, uint32_t n_rows, uint32_t frames, float *out) {
+__global__ void s2r_sum_rows_kernel(const float *rows, uint32_t n_rows, uint32_t frames, uint32_t stride, int stereo, float *out) {
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= frames) return;
-    float total = 0.0f;
-    for (uint32_t r = 0; r < n_rows; ++r) total += rows[(size_t)r * frames + f];
-    out[f] = total;
+    float total = 0.0f;                                          // accum = splat(0.0), synth.rs:176
+    for (uint32_t r = 0; r < n_rows; ++r) total += rows[(size_t)r * stride + f];
+    if (stereo) { out[2u * f] = total; out[2u * f + 1u] = total; }   // audio_player.rs:224-228
+    else out[f] = total;
 }
 
 // build-defined 4x decimator: out[n] = sum over k of h[k] * x[4n + k], taps in index order,
@@ -260,8 +261,8 @@ hipError_t s2r_launch_decimate4(float *x_with_history, const float *taps, uint32
     return hipGetLastError();
 }
 
-hipError_t s2r_launch_sum_rows(const float *rows, uint32_t n_rows, uint32_t frames, float *out, hipStream_t stream) {
+hipError_t s2r_launch_sum_rows(const float *rows, uint32_t n_rows, uint32_t frames, uint32_t stride, int stereo, float *out, hipStream_t stream) {
     if (frames == 0) return hipSuccess;
-    hipLaunchKernelGGL(s2r_sum_rows_kernel, dim3((frames + 255) / 256), dim3(256), 0, stream, rows, n_rows, frames, out);
+    hipLaunchKernelGGL(s2r_sum_rows_kernel, dim3((frames + 255) / 256), dim3(256), 0, stream, rows, n_rows, frames, stride, stereo, out);
     return hipGetLastError();
 }

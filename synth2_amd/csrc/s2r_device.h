@@ -203,4 +203,5 @@ hipError_t s2r_launch_tev_heads(int32_t *heads, const S2rTimedEvent *tev, S2rTim
 // build-defined 4x decimator: x = 62 samples of history + 4 * n_out new ones, h = 63 taps (device), and the
 // last 62 inputs copied to the front of x afterwards (second launch) for the next call
 hipError_t s2r_launch_decimate4(float *x_with_history, const float *taps, uint32_t n_out, float *out, hipStream_t stream);
-hipError_t s2r_launch_sum_rows(const float *rows, uint32_t n_rows, uint32_t frames, float *out, hipStream_t stream);
+// out[i] = ((+0.0 + rows[0][i]) + rows[1][i]) + ...; rows are `stride` floats apart; stereo: interleaved L, R with L == R
+hipError_t s2r_launch_sum_rows(const float *rows, uint32_t n_rows, uint32_t frames, uint32_t stride, int stereo, float *out, hipStream_t stream);

@@ -8,9 +8,14 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "s2r.h"
@@ -101,13 +106,25 @@ struct EventSlot {
 struct s2r_synth {
     s2r_config cfg{};
     int device = 0;
-    uint32_t shard_begin = 0, shard_voices = 0, padded_voices = 0, block_voices = 256, n_blocks = 0, mix_groups = 1, lanes = 1;
+    uint32_t shard_begin = 0, shard_voices = 0, padded_voices = 0, block_voices = 256, n_blocks = 0, mix_groups = 1;
     uint32_t interleave = 0, shard_index = 0, shard_count = 1;   // round-robin sharding (s2r_config.shard_interleave)
     std::vector<s2r_patch> bank;                 // bank[0] is "the" patch of the reference's Synth
     uint32_t program = 0;                        // current program: the patch the next note_on gives its voice
     S2rBankEntry *bank_dev = nullptr;            // S2R_MAX_BANK entries, resolved for bank_rate
     bool bank_dirty = true; uint32_t bank_rate = 0;
-    std::unique_ptr<S2rVoicePool> pool;
+    std::shared_ptr<S2rVoicePool> pool;          // one per Synth: the shards of a device-list handle share their parent's
+    // Device list (s2r_config.n_devices > 1): this handle is the PARENT — it owns the pool, runs the allocation policy
+    // once per event and routes the event to the shard (`kids[k]`, an ordinary single-device handle on devices[k])
+    // that holds the voice; per fill every shard writes its partial mix into row k of `rows_dev` on the parent's
+    // device (peer-to-peer where the devices differ) and the parent adds the rows in shard order rooted at +0.0.
+    s2r_synth *parent = nullptr;
+    std::vector<s2r_synth *> kids;
+    float *rows_dev[2] = {nullptr, nullptr};     // [n kids][max_frames], one per fill in flight
+    std::vector<float *> kid_stage;              // per kid: a row on ITS device when it cannot write the parent's rows directly
+    std::vector<hipEvent_t> kid_done[2];         // per slot, per kid: its partial row is in rows_dev[slot]
+    uint32_t rows_slot = 0;
+    struct Workers;
+    Workers *workers = nullptr;                  // one host thread per further shard: the shards' launches run side by side
     std::vector<uint32_t> seed_override;         // per pool voice; 0 = reference behaviour
     // event folding (one record per touched shard voice between two fills)
     std::vector<S2rVoiceEvent> pending;
@@ -156,7 +173,62 @@ struct s2r_synth {
     std::string err = "";
 };
 
+
+// The shards of a device-list handle are launched side by side: shard 0 by the calling thread, every further shard by a
+// host thread of its own that lives as long as the handle.  A thread spins briefly for its next job (fills follow each
+// other within microseconds in a render loop) before it blocks.
+struct s2r_synth::Workers {
+    struct Slot {
+        std::thread th;
+        std::mutex mu; std::condition_variable cv;
+        std::function<int()> job;
+        std::atomic<int> state{0};      // 0 idle, 1 job posted, 2 done, 3 quit
+        int rc = 0;
+    };
+    std::vector<std::unique_ptr<Slot>> slots;
+    explicit Workers(uint32_t n) {
+        for (uint32_t i = 0; i < n; i++) {
+            slots.emplace_back(new Slot());
+            Slot *sl = slots.back().get();
+            sl->th = std::thread([sl]() {
+                for (;;) {
+                    int st = 0;
+                    for (int spin = 0; spin < 20000 && (st = sl->state.load(std::memory_order_acquire)) != 1 && st != 3; spin++) __builtin_ia32_pause();
+                    if (st != 1 && st != 3) {
+                        std::unique_lock<std::mutex> lk(sl->mu);
+                        sl->cv.wait(lk, [&] { st = sl->state.load(std::memory_order_acquire); return st == 1 || st == 3; });
+                    }
+                    if (st == 3) return;
+                    sl->rc = sl->job();
+                    sl->state.store(2, std::memory_order_release);
+                }
+            });
+        }
+    }
+    void post(uint32_t i, std::function<int()> job) {
+        Slot *sl = slots[i].get();
+        sl->job = std::move(job);
+        { std::lock_guard<std::mutex> lk(sl->mu); sl->state.store(1, std::memory_order_release); }
+        sl->cv.notify_one();
+    }
+    int wait(uint32_t i) {
+        Slot *sl = slots[i].get();
+        while (sl->state.load(std::memory_order_acquire) != 2) __builtin_ia32_pause();
+        sl->state.store(0, std::memory_order_release);
+        return sl->rc;
+    }
+    ~Workers() {
+        for (auto &sl : slots) {
+            { std::lock_guard<std::mutex> lk(sl->mu); sl->state.store(3, std::memory_order_release); }
+            sl->cv.notify_one();
+            sl->th.join();
+        }
+    }
+};
+
 namespace {
+
+s2r_synth::Workers *new_workers(uint32_t n) { return n ? new (std::nothrow) s2r_synth::Workers(n) : nullptr; }
 
 int set_err(s2r_synth *s, int code, const char *fmt, ...) {
     if (s) {
@@ -188,10 +260,24 @@ inline uint32_t to_pool(const s2r_synth *s, uint32_t local) {
     return ((local / s->interleave) * s->shard_count + s->shard_index) * s->interleave + local % s->interleave;
 }
 
-void push_event(s2r_synth *s, uint32_t pool_index, uint32_t flags, float pitch, uint32_t seed, uint32_t program = 0) {
+// the handle that renders pool voice `pool_index` — this one, or for a device-list handle the shard that holds it — and
+// the voice's index there; nullptr when another process' handle renders it
+inline s2r_synth *shard_of(s2r_synth *s, uint32_t pool_index, uint32_t *local) {
+    if (!s->kids.empty()) {
+        const uint32_t n = (uint32_t)s->kids.size();
+        const uint32_t k = s->interleave ? (pool_index / s->interleave) % n : pool_index / (s->shard_voices / n);
+        s = s->kids[k];
+    }
     const int64_t mine = to_local(s, pool_index);
-    if (mine < 0) return;
-    const uint32_t local = (uint32_t)mine;
+    if (mine < 0) return nullptr;
+    *local = (uint32_t)mine;
+    return s;
+}
+
+void push_event(s2r_synth *top, uint32_t pool_index, uint32_t flags, float pitch, uint32_t seed, uint32_t program = 0) {
+    uint32_t local = 0;
+    s2r_synth *s = shard_of(top, pool_index, &local);
+    if (!s) return;
     int32_t slot = s->pending_slot[local];
     if (slot < 0) {
         slot = (int32_t)s->pending.size();
@@ -453,7 +539,9 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
             // this patch's coefficient tables, four planes in the bank's table buffer
             S2rTabBuild &b = builds[k];
             b = S2rTabBuild{};
-            if (s->use_tab && !s->no_flat_shortcut && plan_tables(e.mod, b)) {
+            // (the whole bank's tables stay under 2^28 floats = 1 GiB, so tab_off cannot wrap its 32 bits: a patch that
+            // would pass the budget computes in-lane, tab_valid = 0)
+            if (s->use_tab && !s->no_flat_shortcut && plan_tables(e.mod, b) && tab_floats + (size_t)b.plane * 4u <= ((size_t)1 << 28)) {
                 b.lpf_freq = e.lpf_freq; b.amt_lpf = e.amt_lpf; b.amt_osc = e.amt_osc; b.sr = srf; b.rcp_sr = 1.0f / srf;
                 b.fast_div_sr = 0;                   // (the per-lane-patch kernel divides by the sample rate with a true division)
                 b.lpf_kind = e.lpf_kind; b.lpf_damping = e.lpf_shape; b.fm_plane = 3u;
@@ -523,9 +611,63 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
         if (defer_ring_slot >= 0 && stream == s->stream) { s->dmix.active = true; s->dmix.m = m; s->dmix.ring_slot = defer_ring_slot; }
         else S2R_HIP(s, s2r_launch_mix(m, stream));
     }
-    s->pool->advance(frames - s->fill_time);
-    s->fill_time = 0;
+    if (!s->parent) {                             // (a device-list handle moves the shared clock once, after its shards)
+        s->pool->advance(frames - s->fill_time);
+        s->fill_time = 0;
+    }
     return S2R_OK;
+}
+
+
+// A device-list handle's fill: every shard renders on its own device and stream (shard 0 launched by this thread, the
+// others by their threads) and leaves its partial mix in row k of rows_dev[slot] on the parent's device; the parent's
+// stream waits for the rows and adds them in shard order rooted at +0.0 (synth.rs:176,195) into `dev_out`.
+int enqueue_multi(s2r_synth *s, size_t frames, uint32_t sample_rate, float *dev_out, bool stereo, float *per_voice_host = nullptr) {
+    const uint32_t n = (uint32_t)s->kids.size();
+    const uint32_t slot = s->rows_slot;
+    s->rows_slot ^= 1u;
+    auto shard_job = [s, frames, sample_rate, slot, per_voice_host](uint32_t k) -> int {
+        s2r_synth *kid = s->kids[k];
+        if (hipSetDevice(kid->device) != hipSuccess) return set_err(kid, S2R_ERR_HIP, "hipSetDevice(%d) failed", kid->device);
+        if (per_voice_host) {                     // (mix disabled: the shard's rows, scattered to pool order by the caller)
+            const size_t need = (size_t)kid->shard_voices * frames;
+            if (need > kid->per_voice_cap) {
+                if (kid->per_voice_dev) { S2R_HIP(kid, hipFree(kid->per_voice_dev)); kid->per_voice_dev = nullptr; kid->per_voice_cap = 0; }
+                S2R_HIP(kid, hipMalloc((void **)&kid->per_voice_dev, need * sizeof(float)));
+                kid->per_voice_cap = need;
+            }
+            int rc = enqueue_fill(kid, frames, sample_rate, kid->stream, nullptr, false, false, kid->per_voice_dev);
+            if (rc != S2R_OK) return rc;
+            return S2R_OK;
+        }
+        float *row = s->rows_dev[slot] + (size_t)k * s->cfg.max_frames;
+        float *dst = s->kid_stage[k] ? s->kid_stage[k] : row;
+        int rc = enqueue_fill(kid, frames, sample_rate, kid->stream, dst, false, false, nullptr);
+        if (rc != S2R_OK) return rc;
+        if (s->kid_stage[k]) S2R_HIP(kid, hipMemcpyPeerAsync(row, s->device, dst, kid->device, frames * sizeof(float), kid->stream));
+        S2R_HIP(kid, hipEventRecord(s->kid_done[slot][k], kid->stream));
+        return S2R_OK;
+    };
+    for (uint32_t k = 1; k < n; k++) s->workers->post(k - 1u, [shard_job, k]() { return shard_job(k); });
+    int rc = shard_job(0);
+    for (uint32_t k = 1; k < n; k++) {
+        const int rk = s->workers->wait(k - 1u);
+        if (rk != S2R_OK && rc == S2R_OK) { rc = rk; s->err = "shard " + std::to_string(k) + ": " + s->kids[k]->err; }
+    }
+    if (rc != S2R_OK) { if (s->err.empty()) s->err = "shard 0: " + s->kids[0]->err; return rc; }
+    s->pool->advance(frames - s->fill_time);      // the shared clock, once
+    s->fill_time = 0;
+    if (per_voice_host) return S2R_OK;
+    S2R_HIP(s, hipSetDevice(s->device));
+    for (uint32_t k = 0; k < n; k++) S2R_HIP(s, hipStreamWaitEvent(s->stream, s->kid_done[slot][k], 0));
+    S2R_HIP(s, s2r_launch_sum_rows(s->rows_dev[slot], n, (uint32_t)frames, s->cfg.max_frames, stereo ? 1 : 0, dev_out, s->stream));
+    return S2R_OK;
+}
+
+// the fill of any handle on ITS stream: the final mix (root-added) lands in `dev_out`
+int enqueue_root(s2r_synth *s, size_t frames, uint32_t sample_rate, float *dev_out, bool stereo, int defer_ring_slot = -1) {
+    if (!s->kids.empty()) return enqueue_multi(s, frames, sample_rate, dev_out, stereo);
+    return enqueue_fill(s, frames, sample_rate, s->stream, dev_out, true, stereo, nullptr, defer_ring_slot);
 }
 
 int fill_host(s2r_synth *s, float *out, size_t frames, uint32_t sample_rate, bool stereo) {
@@ -536,7 +678,7 @@ int fill_host(s2r_synth *s, float *out, size_t frames, uint32_t sample_rate, boo
     S2R_HIP(s, hipSetDevice(s->device));
     // the last kernel of the fill writes the few KiB of output straight into mapped host memory: no copy
     // command between the launch and the wait
-    rc = enqueue_fill(s, frames, sample_rate, s->stream, s->out_host_dev, true, stereo, nullptr);
+    rc = enqueue_root(s, frames, sample_rate, s->out_host_dev, stereo);
     if (rc != S2R_OK) return rc;
     const size_t n = frames * (stereo ? 2 : 1);
     S2R_HIP(s, hipStreamSynchronize(s->stream));
@@ -546,8 +688,16 @@ int fill_host(s2r_synth *s, float *out, size_t frames, uint32_t sample_rate, boo
 
 void release_all(s2r_synth *s) {
     if (!s) return;
+    delete s->workers; s->workers = nullptr;        // (joins the shard threads before their handles go)
+    for (s2r_synth *kid : s->kids) release_all(kid);
+    s->kids.clear();
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (int b = 0; b < 2; b++) {
+        if (s->rows_dev[b]) (void)hipFree(s->rows_dev[b]);
+        for (hipEvent_t e : s->kid_done[b]) if (e) (void)hipEventDestroy(e);
+    }
+    for (float *st : s->kid_stage) if (st) (void)hipFree(st);
     for (EventSlot &sl : s->slots) {
         if (sl.host) (void)hipHostFree(sl.host);
         if (sl.thost) (void)hipHostFree(sl.thost);
@@ -598,8 +748,9 @@ const char *s2r_status_string(int status) {
     }
 }
 
-int s2r_create(const s2r_config *cfg, s2r_synth **out) {
-    if (!cfg || !out || cfg->struct_size != sizeof(s2r_config)) return S2R_ERR_INVALID;
+// one shard on one device (s2r_create without a device list, and each shard of one with).  `pool` != null: a shard of
+// the device-list handle `parent`, which owns the pool and runs the allocation policy.
+static int create_single(const s2r_config *cfg, std::shared_ptr<S2rVoicePool> pool, s2r_synth *parent, s2r_synth **out) {
     *out = nullptr;
     if (cfg->total_voices == 0 || cfg->max_frames == 0) return S2R_ERR_INVALID;
     const uint32_t bv = cfg->block_voices ? cfg->block_voices : 256u;
@@ -635,14 +786,12 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
     s->n_blocks = (shard_voices + bv - 1) / bv;
     s->padded_voices = s->n_blocks * bv;
     s->mix_groups = cfg->mix_groups ? cfg->mix_groups : 1u;
-    // lanes per voice: one.  (Round 1 also built kernels that spread a voice over 2 or 4 lanes; bit-identical and
-    // slower at every pool size once the branch-free runs existed, they are gone — 2 and 4 are accepted and mean 1.)
-    if (cfg->lanes_per_voice != 0 && cfg->lanes_per_voice != 1 && cfg->lanes_per_voice != 2 && cfg->lanes_per_voice != 4) { delete s; return S2R_ERR_INVALID; }
-    s->lanes = 1;
+    if (cfg->reserved0 != 0) { delete s; return S2R_ERR_INVALID; }
+    s->parent = parent;
     s->bank.resize(1);
     s2r_default_patch(&s->bank[0]);
-    s->pool.reset(new S2rVoicePool(cfg->total_voices));
-    s->seed_override.assign(cfg->total_voices, 0u);
+    if (pool) s->pool = pool;
+    else { s->pool.reset(new S2rVoicePool(cfg->total_voices)); s->seed_override.assign(cfg->total_voices, 0u); }
     s->pending_slot.assign(shard_voices, -1);
     build_pitch_table(s->pitch_table);
 
@@ -717,6 +866,97 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
     return S2R_OK;
 }
 
+
+int s2r_create(const s2r_config *cfg, s2r_synth **out) {
+    if (!cfg || !out || cfg->struct_size != sizeof(s2r_config)) return S2R_ERR_INVALID;
+    *out = nullptr;
+    if (cfg->n_devices <= 1) {
+        s2r_config one = *cfg;
+        if (cfg->n_devices == 1) one.device = cfg->devices[0];
+        one.n_devices = 0;
+        return create_single(&one, nullptr, nullptr, out);
+    }
+    // ---- a device list: one parent, one shard handle per device ----
+    const uint32_t n = cfg->n_devices;
+    const uint32_t bv = cfg->block_voices ? cfg->block_voices : 256u;
+    if (n > S2R_MAX_DEVICES || cfg->total_voices == 0 || cfg->max_frames == 0 || cfg->reserved0 != 0) return S2R_ERR_INVALID;
+    if (cfg->shard_begin || cfg->shard_voices || cfg->shard_index || cfg->shard_count > 1 || cfg->mix_groups > 1) return S2R_ERR_INVALID;
+    if (bv < 64 || bv > 1024 || (bv & 63u) || cfg->total_voices % ((uint64_t)n * bv)) return S2R_ERR_INVALID;
+    if (cfg->shard_interleave && ((cfg->shard_interleave & 15u) || bv % cfg->shard_interleave)) return S2R_ERR_INVALID;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return S2R_ERR_NO_DEVICE;
+    for (uint32_t k = 0; k < n; k++) if (cfg->devices[k] < 0 || cfg->devices[k] >= n_dev) return S2R_ERR_NO_DEVICE;
+    s2r_synth *s = new (std::nothrow) s2r_synth();
+    if (!s) return S2R_ERR_OUT_OF_MEMORY;
+    s->cfg = *cfg;
+    s->device = cfg->devices[0];
+    s->shard_voices = cfg->total_voices;
+    s->block_voices = bv;
+    s->interleave = cfg->shard_interleave; s->shard_count = n;
+    s->bank.resize(1);
+    s2r_default_patch(&s->bank[0]);
+    s->pool.reset(new S2rVoicePool(cfg->total_voices));
+    s->seed_override.assign(cfg->total_voices, 0u);
+    build_pitch_table(s->pitch_table);
+    for (uint32_t k = 0; k < n; k++) {
+        s2r_config kc = *cfg;
+        kc.n_devices = 0; kc.device = cfg->devices[k]; kc.mix_groups = 1; kc.block_voices = bv;
+        if (cfg->shard_interleave) { kc.shard_index = k; kc.shard_count = n; kc.shard_begin = 0; kc.shard_voices = 0; }
+        else { kc.shard_begin = k * (cfg->total_voices / n); kc.shard_voices = cfg->total_voices / n; kc.shard_index = 0; kc.shard_count = 1; }
+        s2r_synth *kid = nullptr;
+        const int rc = create_single(&kc, s->pool, s, &kid);
+        if (rc != S2R_OK) { release_all(s); return rc; }
+        s->kids.push_back(kid);
+    }
+#define CREATE_HIP(call)                                                                   \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            fprintf(stderr, "libs2r: %s failed: %s\n", #call, hipGetErrorString(e_));      \
+            release_all(s);                                                                \
+            return e_ == hipErrorOutOfMemory ? S2R_ERR_OUT_OF_MEMORY : S2R_ERR_HIP;        \
+        }                                                                                  \
+    } while (0)
+    CREATE_HIP(hipSetDevice(s->device));
+    CREATE_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; b++) {
+        CREATE_HIP(hipMalloc((void **)&s->rows_dev[b], (size_t)n * cfg->max_frames * sizeof(float)));
+        CREATE_HIP(hipMemsetAsync(s->rows_dev[b], 0, (size_t)n * cfg->max_frames * sizeof(float), s->stream));
+        s->kid_done[b].assign(n, nullptr);
+    }
+    CREATE_HIP(hipMalloc((void **)&s->out_dev, (size_t)2 * cfg->max_frames * sizeof(float)));
+    CREATE_HIP(hipHostMalloc((void **)&s->out_host, (size_t)2 * cfg->max_frames * sizeof(float), hipHostMallocMapped));
+    CREATE_HIP(hipHostGetDevicePointer((void **)&s->out_host_dev, s->out_host, 0));
+    for (int k = 0; k < 2; k++) {
+        CREATE_HIP(hipHostMalloc((void **)&s->ring_host[k], (size_t)cfg->max_frames * sizeof(float), hipHostMallocMapped));
+        CREATE_HIP(hipHostGetDevicePointer((void **)&s->ring_dev[k], s->ring_host[k], 0));
+        CREATE_HIP(hipEventCreateWithFlags(&s->ring_done[k], hipEventDisableTiming));
+    }
+    CREATE_HIP(hipStreamSynchronize(s->stream));
+    // A shard on another device writes its row straight into the parent's buffer when the devices are peers (one
+    // 4 KiB write over xGMI by its mix kernel: SURVEY 5's preferred shape); otherwise into a row of its own that a
+    // peer copy moves.
+    s->kid_stage.assign(n, nullptr);
+    for (uint32_t k = 0; k < n; k++) {
+        s2r_synth *kid = s->kids[k];
+        CREATE_HIP(hipSetDevice(kid->device));
+        for (int b = 0; b < 2; b++) CREATE_HIP(hipEventCreateWithFlags(&s->kid_done[b][k], hipEventDisableTiming));
+        if (kid->device == s->device) continue;
+        int can = 0;
+        bool direct = false;
+        if (hipDeviceCanAccessPeer(&can, kid->device, s->device) == hipSuccess && can) {
+            const hipError_t e = hipDeviceEnablePeerAccess(s->device, 0);
+            direct = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+            (void)hipGetLastError();
+        }
+        if (!direct) CREATE_HIP(hipMalloc((void **)&s->kid_stage[k], (size_t)cfg->max_frames * sizeof(float)));
+    }
+#undef CREATE_HIP
+    s->workers = new_workers(n - 1u);
+    *out = s;
+    return S2R_OK;
+}
+
 void s2r_destroy(s2r_synth *s) { release_all(s); }
 
 int s2r_set_patch(s2r_synth *s, const s2r_patch *patch) {
@@ -726,6 +966,7 @@ int s2r_set_patch(s2r_synth *s, const s2r_patch *patch) {
     if (rc != S2R_OK) return set_err(s, rc, "%s", err.c_str());
     s->bank[0] = *patch;
     s->bank_dirty = true; s->tab_dirty = true;
+    for (s2r_synth *kid : s->kids) { kid->bank[0] = *patch; kid->bank_dirty = true; kid->tab_dirty = true; }
     return S2R_OK;
 }
 
@@ -740,6 +981,7 @@ int s2r_set_patch_bank(s2r_synth *s, const s2r_patch *patches, uint32_t n) {
     s->bank.assign(patches, patches + n);
     if (s->program >= n) s->program = 0;
     s->bank_dirty = true; s->tab_dirty = true;
+    for (s2r_synth *kid : s->kids) { kid->bank = s->bank; kid->bank_dirty = true; kid->tab_dirty = true; }
     return S2R_OK;
 }
 
@@ -766,6 +1008,7 @@ int s2r_load_patch(s2r_synth *s, const char *text, size_t len) {
     if (rc != S2R_OK) return set_err(s, rc, "%s", err.c_str());
     s->bank[0] = p;
     s->bank_dirty = true; s->tab_dirty = true;
+    for (s2r_synth *kid : s->kids) { kid->bank[0] = p; kid->bank_dirty = true; kid->tab_dirty = true; }
     return S2R_OK;
 }
 
@@ -853,19 +1096,19 @@ int s2r_note_events(s2r_synth *s, const s2r_note_event *events, size_t n) {
             fl = S2R_EV_RELEASE;
             if (vi < 0) { s->double_release++; continue; }
         }
-        const int64_t mine = to_local(s, (uint32_t)vi);
-        if (mine < 0) continue;
+        uint32_t local = 0;
+        s2r_synth *sh = shard_of(s, (uint32_t)vi, &local);
+        if (!sh) continue;
         // (no capacity limit here: the device-side buffers grow in flush_events when a fill brings more timed
         // events than they hold)
-        const uint32_t local = (uint32_t)mine;
-        const int32_t idx = (int32_t)s->tpending.size();
+        const int32_t idx = (int32_t)sh->tpending.size();
         S2rTimedEvent te{};
         te.voice = local; te.frame = frame; te.flags = fl; te.pitch = pitch; te.seed = seed; te.next = -1;
         te.program = s->program;
-        if (s->tlast[local] >= 0) s->tpending[(size_t)s->tlast[local]].next = idx;
+        if (sh->tlast[local] >= 0) sh->tpending[(size_t)sh->tlast[local]].next = idx;
         else te.flags |= S2R_TEV_FIRST;
-        s->tlast[local] = idx;
-        s->tpending.push_back(te);
+        sh->tlast[local] = idx;
+        sh->tpending.push_back(te);
     }
     return S2R_OK;
 }
@@ -882,7 +1125,7 @@ int s2r_fill_begin(s2r_synth *s, size_t frames, uint32_t sample_rate_hz) {
     const uint32_t slot = (s->ring_head + s->ring_count) & 1u;
     if (frames) {
         // the last kernel of the fill writes the mix straight into this slot's mapped host buffer
-        rc = enqueue_fill(s, frames, sample_rate_hz, s->stream, s->ring_dev[slot], true, false, nullptr, (int)slot);
+        rc = enqueue_root(s, frames, sample_rate_hz, s->ring_dev[slot], false, (int)slot);
         if (rc != S2R_OK) return rc;
     }
     // (a deferred mix records the slot's event when it is launched: by the next fill_begin or by fill_end)
@@ -892,11 +1135,16 @@ int s2r_fill_begin(s2r_synth *s, size_t frames, uint32_t sample_rate_hz) {
     return S2R_OK;
 }
 
-int s2r_fill_end(s2r_synth *s, float *mono_out) {
+size_t s2r_fill_pending_frames(const s2r_synth *s) { return (s && s->ring_count) ? s->ring_frames[s->ring_head] : 0; }
+uint32_t s2r_fills_in_flight(const s2r_synth *s) { return s ? s->ring_count : 0; }
+
+int s2r_fill_end(s2r_synth *s, float *mono_out, size_t capacity) {
     if (!s) return S2R_ERR_INVALID;
     if (s->ring_count == 0) return set_err(s, S2R_ERR_INVALID, "no fill in flight");
     const uint32_t slot = s->ring_head;
     if (s->ring_frames[slot] && !mono_out) return set_err(s, S2R_ERR_INVALID, "null output buffer");
+    if (capacity < s->ring_frames[slot])
+        return set_err(s, S2R_ERR_INVALID, "the oldest fill in flight has %zu frames, the buffer takes %zu", s->ring_frames[slot], capacity);
     if (s->dmix.active && s->dmix.ring_slot == (int)slot) {      // nobody began another fill in the meantime
         S2R_HIP(s, hipSetDevice(s->device));
         int rc = launch_deferred_mix(s, s->stream);
@@ -940,7 +1188,7 @@ int s2r_fill_oversampled(s2r_synth *s, float *mono_out, size_t frames, uint32_t 
         S2R_HIP(s, hipMalloc((void **)&s->os_buf, ((size_t)(kTaps - 1) + s->cfg.max_frames) * sizeof(float)));
         S2R_HIP(s, hipMemsetAsync(s->os_buf, 0, ((size_t)(kTaps - 1) + s->cfg.max_frames) * sizeof(float), s->stream));
     }
-    rc = enqueue_fill(s, os_frames, sample_rate_hz * S2R_OVERSAMPLE, s->stream, s->os_buf + (kTaps - 1), true, false, nullptr);
+    rc = enqueue_root(s, os_frames, sample_rate_hz * S2R_OVERSAMPLE, s->os_buf + (kTaps - 1), false);
     if (rc != S2R_OK) return rc;
     S2R_HIP(s, s2r_launch_decimate4(s->os_buf, s->os_taps, (uint32_t)frames, s->out_host_dev, s->stream));
     S2R_HIP(s, hipStreamSynchronize(s->stream));
@@ -953,6 +1201,7 @@ int s2r_fill_device(s2r_synth *s, float *dev_partial_out, size_t frames, uint32_
     if (rc != S2R_OK) return rc;
     if (frames == 0) return S2R_OK;
     if (!dev_partial_out) return set_err(s, S2R_ERR_INVALID, "null device output buffer");
+    if (!s->kids.empty()) return set_err(s, S2R_ERR_INVALID, "s2r_fill_device is the per-shard building block: a device-list handle combines its shards itself (s2r_fill)");
     S2R_HIP(s, hipSetDevice(s->device));
     return enqueue_fill(s, frames, sample_rate_hz, (hipStream_t)hip_stream, dev_partial_out, false, false, nullptr);
 }
@@ -962,13 +1211,14 @@ int s2r_fill_device_root(s2r_synth *s, float *dev_out, size_t frames, uint32_t s
     if (rc != S2R_OK) return rc;
     if (frames == 0) return S2R_OK;
     if (!dev_out) return set_err(s, S2R_ERR_INVALID, "null device output buffer");
+    if (!s->kids.empty()) return set_err(s, S2R_ERR_INVALID, "s2r_fill_device_root takes a single-device handle");
     S2R_HIP(s, hipSetDevice(s->device));
     return enqueue_fill(s, frames, sample_rate_hz, (hipStream_t)hip_stream, dev_out, true, false, nullptr);
 }
 
 int s2r_sum_partials_device(const float *dev_rows, uint32_t n_rows, size_t frames, float *dev_out, void *hip_stream) {
     if (!dev_rows || !dev_out || n_rows == 0) return S2R_ERR_INVALID;
-    return s2r_launch_sum_rows(dev_rows, n_rows, (uint32_t)frames, dev_out, (hipStream_t)hip_stream) == hipSuccess ? S2R_OK : S2R_ERR_HIP;
+    return s2r_launch_sum_rows(dev_rows, n_rows, (uint32_t)frames, (uint32_t)frames, 0, dev_out, (hipStream_t)hip_stream) == hipSuccess ? S2R_OK : S2R_ERR_HIP;
 }
 
 int s2r_render_voices(s2r_synth *s, float *per_voice_out, size_t frames, uint32_t sample_rate_hz) {
@@ -977,6 +1227,21 @@ int s2r_render_voices(s2r_synth *s, float *per_voice_out, size_t frames, uint32_
     if (frames == 0) return S2R_OK;
     if (!per_voice_out) return set_err(s, S2R_ERR_INVALID, "null output buffer");
     if (!s->tpending.empty()) return set_err(s, S2R_ERR_INVALID, "s2r_render_voices does not take timed events; use s2r_fill");
+    if (!s->kids.empty()) {                       // every shard's rows, put back into pool order
+        for (s2r_synth *kid : s->kids) if (!kid->tpending.empty()) return set_err(s, S2R_ERR_INVALID, "s2r_render_voices does not take timed events; use s2r_fill");
+        rc = enqueue_multi(s, frames, sample_rate_hz, nullptr, false, per_voice_out);
+        if (rc != S2R_OK) return rc;
+        std::vector<float> tmp;
+        for (s2r_synth *kid : s->kids) {
+            S2R_HIP(s, hipSetDevice(kid->device));
+            tmp.resize((size_t)kid->shard_voices * frames);
+            S2R_HIP(s, hipMemcpyAsync(tmp.data(), kid->per_voice_dev, tmp.size() * sizeof(float), hipMemcpyDeviceToHost, kid->stream));
+            S2R_HIP(s, hipStreamSynchronize(kid->stream));
+            for (uint32_t l = 0; l < kid->shard_voices; l++)
+                std::memcpy(per_voice_out + (size_t)to_pool(kid, l) * frames, tmp.data() + (size_t)l * frames, frames * sizeof(float));
+        }
+        return S2R_OK;
+    }
     S2R_HIP(s, hipSetDevice(s->device));
     const size_t need = (size_t)s->shard_voices * frames;
     if (need > s->per_voice_cap) {
@@ -993,6 +1258,16 @@ int s2r_render_voices(s2r_synth *s, float *per_voice_out, size_t frames, uint32_
 
 int s2r_export_state(s2r_synth *s, s2r_voice_state *voices) {
     if (!s || !voices) return S2R_ERR_INVALID;
+    if (!s->kids.empty()) {                       // pool order: every shard's voices put back where the pool has them
+        std::vector<s2r_voice_state> tmp;
+        for (s2r_synth *kid : s->kids) {
+            tmp.resize(kid->shard_voices);
+            const int rc = s2r_export_state(kid, tmp.data());
+            if (rc != S2R_OK) { s->err = kid->err; return rc; }
+            for (uint32_t l = 0; l < kid->shard_voices; l++) voices[to_pool(kid, l)] = tmp[l];
+        }
+        return S2R_OK;
+    }
     S2R_HIP(s, hipSetDevice(s->device));
     if (!s->tpending.empty()) return set_err(s, S2R_ERR_INVALID, "export_state with timed events pending: fill first");
     EventSlot *ts = nullptr; const S2rTimedEvent *td = nullptr;
@@ -1027,6 +1302,16 @@ int s2r_export_state(s2r_synth *s, s2r_voice_state *voices) {
 
 int s2r_import_state(s2r_synth *s, const s2r_voice_state *voices) {
     if (!s || !voices) return S2R_ERR_INVALID;
+    if (!s->kids.empty()) {
+        std::vector<s2r_voice_state> tmp;
+        for (s2r_synth *kid : s->kids) {
+            tmp.resize(kid->shard_voices);
+            for (uint32_t l = 0; l < kid->shard_voices; l++) tmp[l] = voices[to_pool(kid, l)];
+            const int rc = s2r_import_state(kid, tmp.data());
+            if (rc != S2R_OK) { s->err = kid->err; return rc; }
+        }
+        return S2R_OK;
+    }
     S2R_HIP(s, hipSetDevice(s->device));
     // pending events refer to the state being replaced
     for (const S2rVoiceEvent &e : s->pending) s->pending_slot[e.voice] = -1;
@@ -1057,29 +1342,31 @@ int s2r_import_state(s2r_synth *s, const s2r_voice_state *voices) {
 }
 
 int s2r_set_noise_seed(s2r_synth *s, uint32_t voice_index, uint32_t seed) {
-    if (!s || voice_index >= s->pool->size()) return S2R_ERR_INVALID;
+    if (!s || s->parent || voice_index >= s->pool->size()) return S2R_ERR_INVALID;
     s->seed_override[voice_index] = seed;
-    if (to_local(s, voice_index) >= 0) {
-        S2R_HIP(s, hipSetDevice(s->device));
-        if (!s->tpending.empty()) return set_err(s, S2R_ERR_INVALID, "set_noise_seed with timed events pending: fill first");
+    uint32_t local = 0;
+    s2r_synth *sh = shard_of(s, voice_index, &local);
+    if (sh) {
+        S2R_HIP(s, hipSetDevice(sh->device));
+        if (!sh->tpending.empty()) return set_err(s, S2R_ERR_INVALID, "set_noise_seed with timed events pending: fill first");
         EventSlot *ts = nullptr; const S2rTimedEvent *td = nullptr;
-        int rc = flush_events(s, s->stream, &ts, &td);
-        if (rc != S2R_OK) return rc;
-        S2R_HIP(s, hipMemcpyAsync(s->v.seed + to_local(s, voice_index), &s->seed_override[voice_index],
-                                  sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
-        S2R_HIP(s, hipStreamSynchronize(s->stream));
+        int rc = flush_events(sh, sh->stream, &ts, &td);
+        if (rc != S2R_OK) { s->err = sh->err; return rc; }
+        S2R_HIP(s, hipMemcpyAsync(sh->v.seed + local, &s->seed_override[voice_index], sizeof(uint32_t), hipMemcpyHostToDevice, sh->stream));
+        S2R_HIP(s, hipStreamSynchronize(sh->stream));
     }
     return S2R_OK;
 }
 
 uint32_t s2r_shard_voices(const s2r_synth *s) { return s ? s->shard_voices : 0; }
 uint32_t s2r_block_voices(const s2r_synth *s) { return s ? s->block_voices : 0; }
-uint32_t s2r_lanes_per_voice(const s2r_synth *s) { return s ? s->lanes : 0; }
+uint32_t s2r_device_count(const s2r_synth *s) { return s ? (s->kids.empty() ? 1u : (uint32_t)s->kids.size()) : 0; }
 uint64_t s2r_double_release_count(const s2r_synth *s) { return s ? s->double_release : 0; }
 
 int s2r_set_flat_shortcut(s2r_synth *s, int enabled) {
     if (!s) return S2R_ERR_INVALID;
     s->no_flat_shortcut = enabled == 0;
+    for (s2r_synth *kid : s->kids) kid->no_flat_shortcut = s->no_flat_shortcut;
     return S2R_OK;
 }
 
@@ -1087,6 +1374,8 @@ int s2r_set_coeff_stream(s2r_synth *s, int enabled) {
     if (!s) return S2R_ERR_INVALID;
     s->use_tab = enabled != 0;                    // 0: coefficients in-lane; else from the patch's tables
     s->use_arg_events = enabled != 2 && enabled != 4;   // 2, 4: note events through their own launch, never in the kernel arguments
+    s->bank_dirty = true;                         // (a resolved bank carries the choice in its entries' tab_valid)
+    for (s2r_synth *kid : s->kids) { kid->use_tab = s->use_tab; kid->use_arg_events = s->use_arg_events; kid->bank_dirty = true; }
     return S2R_OK;
 }
 
@@ -1094,10 +1383,16 @@ int s2r_set_timing(s2r_synth *s, int enabled) {
     if (!s) return S2R_ERR_INVALID;
     s->timing = enabled != 0;
     s->timed = false;
+    for (s2r_synth *kid : s->kids) { kid->timing = s->timing; kid->timed = false; }
     return S2R_OK;
 }
 
 float s2r_last_render_ms(s2r_synth *s) {
+    if (s && !s->kids.empty()) {                  // the longest of the shards' render kernels
+        float worst = -1.0f;
+        for (s2r_synth *kid : s->kids) { const float ms = s2r_last_render_ms(kid); if (ms < 0.0f) return -1.0f; if (ms > worst) worst = ms; }
+        return worst;
+    }
     if (!s || !s->timing || !s->timed) return -1.0f;
     if (hipEventSynchronize(s->t1) != hipSuccess) return -1.0f;
     float ms = -1.0f;

@@ -62,8 +62,9 @@ FILT_SVF_LP, FILT_SVF_BP, FILT_SVF_HP = 6, 7, 8      # build-defined state-varia
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("total_voices", C.c_uint32), ("shard_begin", C.c_uint32),
                 ("shard_voices", C.c_uint32), ("max_frames", C.c_uint32), ("device", C.c_int32),
-                ("block_voices", C.c_uint32), ("mix_groups", C.c_uint32), ("lanes_per_voice", C.c_uint32),
-                ("shard_interleave", C.c_uint32), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32)]
+                ("block_voices", C.c_uint32), ("mix_groups", C.c_uint32), ("reserved0", C.c_uint32),
+                ("shard_interleave", C.c_uint32), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32),
+                ("n_devices", C.c_uint32), ("devices", C.c_int32 * 16)]
 
 
 class VoiceState(C.Structure):
@@ -144,7 +145,9 @@ def load_library():
         "s2r_note_events": (C.c_int, [H, C.c_void_p, C.c_size_t]),
         "s2r_fill": (C.c_int, [H, _f32p, C.c_size_t, C.c_uint32]),
         "s2r_fill_begin": (C.c_int, [H, C.c_size_t, C.c_uint32]),
-        "s2r_fill_end": (C.c_int, [H, _f32p]),
+        "s2r_fill_end": (C.c_int, [H, _f32p, C.c_size_t]),
+        "s2r_fill_pending_frames": (C.c_size_t, [H]),
+        "s2r_fills_in_flight": (C.c_uint32, [H]),
         "s2r_fill_stereo": (C.c_int, [H, _f32p, C.c_size_t, C.c_uint32]),
         "s2r_fill_oversampled": (C.c_int, [H, _f32p, C.c_size_t, C.c_uint32]),
         "s2r_fill_device": (C.c_int, [H, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
@@ -156,7 +159,7 @@ def load_library():
         "s2r_set_noise_seed": (C.c_int, [H, C.c_uint32, C.c_uint32]),
         "s2r_shard_voices": (C.c_uint32, [H]),
         "s2r_block_voices": (C.c_uint32, [H]),
-        "s2r_lanes_per_voice": (C.c_uint32, [H]),
+        "s2r_device_count": (C.c_uint32, [H]),
         "s2r_double_release_count": (C.c_uint64, [H]),
         "s2r_set_timing": (C.c_int, [H, C.c_int]),
         "s2r_set_flat_shortcut": (C.c_int, [H, C.c_int]),
@@ -253,17 +256,22 @@ class VoicePool:
 class Synth:
     """``s2_lib::try3::synth::Synth`` on an MI355X.
 
-    ``num_voices`` replaces the reference's ``NUM_VOICES = 8`` (synth.rs:7).  For multi-GPU
-    runs every rank builds a Synth over the same pool with its own ``shard_begin`` /
-    ``shard_voices`` and feeds it the same note events.
+    ``num_voices`` replaces the reference's ``NUM_VOICES = 8`` (synth.rs:7).  ``devices=[d0, d1, ...]``: ONE Synth over
+    several GPUs (s2r_config.devices: the pool cut into one shard per device, the allocation policy run once, the
+    shards' partial mixes added in shard order on d0).  With one process per GPU instead (torch.distributed,
+    synth2_amd/sharded.py) every rank builds a Synth over the same pool with its own ``shard_begin`` /
+    ``shard_voices`` (or ``shard_interleave`` / ``shard_index`` / ``shard_count``) and feeds it the same note events.
     """
 
     def __init__(self, num_voices=8, max_frames=2048, device=-1, shard_begin=0, shard_voices=0,
-                 block_voices=0, mix_groups=0, lanes_per_voice=0, shard_interleave=0, shard_index=0, shard_count=1):
+                 block_voices=0, mix_groups=0, shard_interleave=0, shard_index=0, shard_count=1, devices=None):
         self.L = load_library()
         self.h = C.c_void_p()
+        devs = list(devices) if devices is not None else []
+        if len(devs) > 16:
+            raise ValueError("a device list holds at most 16 devices")
         cfg = Config(C.sizeof(Config), num_voices, shard_begin, shard_voices, max_frames, device, block_voices, mix_groups,
-                     lanes_per_voice, shard_interleave, shard_index, shard_count)
+                     0, shard_interleave, shard_index, shard_count, len(devs), (C.c_int32 * 16)(*devs))
         rc = self.L.s2r_create(C.byref(cfg), C.byref(self.h))
         if rc != S2R_OK:
             self.h = None
@@ -272,7 +280,7 @@ class Synth:
         self.max_frames = max_frames
         self.shard_voices = self.L.s2r_shard_voices(self.h)
         self.block_voices = self.L.s2r_block_voices(self.h)
-        self.lanes_per_voice = self.L.s2r_lanes_per_voice(self.h)
+        self.device_count = self.L.s2r_device_count(self.h)
 
     # Synth::new() (synth.rs:54-59)
     @classmethod
@@ -347,8 +355,13 @@ class Synth:
     def sample_end(self, buffer):
         """second half: wait for the oldest fill in flight and copy it into ``buffer``"""
         assert buffer.dtype == np.float32 and buffer.flags["C_CONTIGUOUS"] and buffer.ndim == 1
-        self._check(self.L.s2r_fill_end(self.h, buffer.ctypes.data_as(_f32p)))
+        self._check(self.L.s2r_fill_end(self.h, buffer.ctypes.data_as(_f32p), buffer.size))
         return buffer
+
+    @property
+    def pending_frames(self):
+        """frames of the oldest fill begun and not yet ended (0: none in flight)"""
+        return int(self.L.s2r_fill_pending_frames(self.h))
 
     def sample_oversampled(self, frames, sample_rate=SampleRateKhz(48000)):
         """build-defined 4x oversampling: rendered at 4 * sample_rate, decimated to `frames` samples"""
@@ -395,9 +408,9 @@ class Synth:
         self._check(self.L.s2r_set_flat_shortcut(self.h, 1 if enabled else 0))
 
     def set_coeff_stream(self, enabled=True):
-        """False/0: coefficients in-lane; True/1: ahead-of-time stream for long fills over big shards (events applied
-        by the classification launch when the fill allows it); 2: same through the separate kernels only;
-        3 / 4: like 1 / 2 for every fill and shard size"""
+        """False/0: filter coefficients computed in-lane; True/1: read from the patch's coefficient tables, few untimed
+        events ride in the render kernel's arguments; 2: tables, events always through their own launch; 3 / 4: synonyms
+        of 1 / 2"""
         self._check(self.L.s2r_set_coeff_stream(self.h, int(enabled)))
 
     def set_timing(self, enabled=True):

@@ -45,12 +45,10 @@ def lcg(seed):
 class Pair:
     """An oracle synth and a GPU synth driven in lockstep."""
 
-    def __init__(self, num_voices, patch=None, max_frames=2048, block_voices=0, mix_groups=0, seeds=None, lanes=0, flat_shortcut=True, strict_lanes=True):
-        self.gpu = s2.Synth(num_voices, max_frames=max_frames, block_voices=block_voices, mix_groups=mix_groups,
-                            lanes_per_voice=lanes)
-        if strict_lanes and lanes not in (0, 1) and self.gpu.lanes_per_voice != lanes:
-            import pytest          # the 2- and 4-lane kernels exist only in S2R_WITH_LANE_VARIANTS=1 builds
-            pytest.skip("this build of libs2r maps lanes_per_voice=%d to %d" % (lanes, self.gpu.lanes_per_voice))
+    def __init__(self, num_voices, patch=None, max_frames=2048, block_voices=0, mix_groups=0, seeds=None, flat_shortcut=True, devices=None,
+                 shard_interleave=0):
+        self.gpu = s2.Synth(num_voices, max_frames=max_frames, block_voices=block_voices, mix_groups=mix_groups, devices=devices,
+                            shard_interleave=shard_interleave)
         self.cpu = s2o.OracleSynth(num_voices)
         if not flat_shortcut:
             self.gpu.set_flat_shortcut(False)

@@ -1,0 +1,192 @@
+"""GPU parity at BASELINE.json's full sizes (VERDICT r2 "next round" item 1): exactly the path bench.py times, config [2]'s
+SVF leg, and config [3]'s 1 048 576-voice pool as eight shards on one device — each against the CPU oracle, bit for bit
+(per-voice rows) and through the documented mix tree (the oracle's own restatement of it, oracle/s2_oracle.c)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from helpers import assert_bits_equal, make_patch, oracle_cfg_from_patch
+from oracle import s2o
+import synth2_amd as s2
+
+pytestmark = pytest.mark.gpu
+
+SR = 48000
+
+
+def _threads():
+    return max(1, min(32, len(os.sched_getaffinity(0))))
+
+
+def test_bench_c3_path_at_65536_voices_against_the_oracle():
+    """What `bench.py` times, at its size: `bench.make_c3_events(65536)` — 1 024 note-ons at frame 0 and ~1 024 note-offs
+    on their own 16-frame boundaries per buffer — through s2r_note_events + s2r_fill_begin / s2r_fill_end with two
+    buffers in flight (the MODE-2 render kernel, releases booked ahead, frame-0 events merged into the chains, the mix
+    deferred to the next fill's chain-heads launch), for one whole period + 3 buffers.  Every buffer is compared bit for
+    bit with the oracle driven the way the reference's caller drives Synth: MIDI applied between 16-frame sample() calls
+    (s2_bin/src/main.rs:138-147; synth.rs:154-203), mixed through the documented tree."""
+    import bench
+    V, period = 65536, bench.PERIOD
+    cyc = bench.make_c3_events(V, period)
+    gpu = s2.Synth(V, max_frames=bench.FRAMES)
+    gpu.load_patch("synth mySynth {\n\n}\n")               # example.synth2
+    ora = s2o.OracleSynth(V)
+    threads = _threads()
+    queue = []
+    n_buffers = period + 3
+    n_timed = 0
+    for k in range(n_buffers):
+        ev = cyc[k % period]
+        n_timed += int(np.count_nonzero(ev["frame"]))
+        gpu.note_events(ev)
+        gpu.sample_begin(bench.FRAMES, SR)
+        pv = ora.render_events(ev, bench.FRAMES, SR, threads=threads)
+        queue.append((k, s2o.mix_tree(pv, gpu.block_voices, 1)))
+        del pv
+        if len(queue) == 2:
+            kk, want = queue.pop(0)
+            assert_bits_equal(gpu.sample_end(np.empty(bench.FRAMES, dtype=np.float32)), want, "C3 bench path, buffer %d" % kk)
+    kk, want = queue.pop(0)
+    assert_bits_equal(gpu.sample_end(np.empty(bench.FRAMES, dtype=np.float32)), want, "C3 bench path, buffer %d" % kk)
+    assert n_timed > 60000 and not ora.panicked
+    # the state the run leaves behind: every voice's control words against the oracle's
+    st = gpu.export_state()
+    vs = np.ctypeslib.as_array(C.cast(ora.p.contents.voices, C.POINTER(C.c_uint8)), shape=(V, C.sizeof(s2o.Voice)))
+    vo = np.frombuffer(vs.tobytes(), dtype=np.dtype({"names": ["has_current", "cfo", "has_release", "rfo"],
+                                                     "formats": [np.int32, np.uint32, np.int32, np.uint32],
+                                                     "offsets": [s2o.Voice.has_current.offset, s2o.Voice.current_frame_offset.offset,
+                                                                 s2o.Voice.has_release.offset, s2o.Voice.release_frame_offset.offset],
+                                                     "itemsize": C.sizeof(s2o.Voice)}))
+    assert np.array_equal(st["started"] != 0, vo["has_current"] != 0)
+    live = vo["has_current"] != 0
+    assert np.array_equal(st["current_frame_offset"][live], vo["cfo"][live])
+    assert np.array_equal((st["released"] != 0)[live], (vo["has_release"] != 0)[live])
+    rel = live & (vo["has_release"] != 0)
+    assert np.array_equal(st["release_frame_offset"][rel], vo["rfo"][rel])
+
+
+def test_config2_svf_at_65536_voices():
+    """BASELINE config [2] as written — 65 536 voices, saw + ADSR + SVF (the build-defined state-variable filter at the
+    modulated cutoff): a 2 048-voice window of per-voice rows bit for bit against the oracle, and the mix equal to the
+    documented tree over the GPU's own rows (the association does not depend on the size), over the attack, a churned
+    buffer and a buffer with timed note-offs."""
+    voices = 65536
+    patch = make_patch(lpf_kind=s2.FILT_SVF_LP, lpf_freq=900.0, lpf_q=1.4)
+    a = s2.Synth(voices, max_frames=1024)
+    b = s2.Synth(voices, max_frames=1024)
+    a.set_patch(patch); b.set_patch(patch)
+    ev = np.zeros(voices, dtype=s2.NOTE_EVENT_DTYPE)
+    ev["kind"] = 1; ev["note"] = 36 + np.arange(voices) % 61; ev["velocity"] = 1.0
+    a.note_events(ev); b.note_events(ev)
+    W = 2048
+    ora = s2o.OracleSynth(W)
+    ora.config = oracle_cfg_from_patch(patch)
+    for i in range(W):
+        ora.note_on(int(ev["note"][i]))
+    for k in range(4):
+        if k == 2:
+            # re-trigger the 2 048 oldest voices (the allocation policy takes them in index order: exactly the window)
+            re = np.zeros(W, dtype=s2.NOTE_EVENT_DTYPE)
+            re["kind"] = 1; re["note"] = 40 + np.arange(W) % 50; re["velocity"] = 1.0
+            a.note_events(re); b.note_events(re)
+            for i in range(W):
+                ora.note_on(int(re["note"][i]))
+        mix = a.sample(np.empty(1024, dtype=np.float32))
+        pv = b.render_voices(1024)
+        assert_bits_equal(pv[:W], ora.render_voices(1024, threads=_threads()), "SVF, first %d voices, buffer %d" % (W, k))
+        assert_bits_equal(mix, s2o.mix_tree(pv, a.block_voices, 1), "SVF mix vs tree over the GPU's rows, buffer %d" % k)
+
+
+def _poke_note_on(ora, j, note, program=0):
+    """*voice = Voice { .. } (synth.rs:63-69) on oracle voice j, without the allocation policy"""
+    v = ora.p.contents.voices[j]
+    C.memset(C.byref(v), 0, C.sizeof(v))
+    v.note = note; v.velocity = 1.0; v.has_current = 1; v.current_frame_offset = 0; v.has_release = 0; v.program = program
+
+
+def _poke_note_off(ora, j):
+    """synth.rs:74-75 on oracle voice j"""
+    v = ora.p.contents.voices[j]
+    if v.has_current and not v.has_release:
+        v.has_release = 1; v.release_frame_offset = v.current_frame_offset
+
+
+def test_config3_1048576_voices_as_8_shards_on_one_device():
+    """BASELINE config [3] at its full pool: 1 048 576 voices dealt out to 8 shards in runs of 64 (what eight GPUs hold),
+    all eight on this one device.  (a) windows of every shard's per-voice rows bit for bit against the oracle — the
+    events that hit a window are found with the host-only allocation policy (s2r_voice_pool, itself checked against the
+    oracle's O(V) policy on the CPU) and applied to the window's oracle voices directly; (b) every shard's partial row
+    equals the oracle's tree over that shard's rows; (c) the rank-ordered sum of the eight partial rows is what ONE
+    handle with a device list of eight (s2r_config.devices = {0 x 8}) returns."""
+    import torch
+    V, N, G, F = 1048576, 8, 64, 1024
+    per = V // N
+    shards = [s2.Synth(V, max_frames=F, shard_interleave=G, shard_index=k, shard_count=N) for k in range(N)]
+    twins = [s2.Synth(V, max_frames=F, shard_interleave=G, shard_index=k, shard_count=N) for k in range(N)]
+    one = s2.Synth(V, max_frames=F, shard_interleave=G, devices=[0] * N)
+    assert one.device_count == N and one.shard_voices == V
+    policy = s2.VoicePool(V)
+    # windows (pool indices): the first voices, a stretch in the middle, the last voices (where note_off's
+    # "last active voice holding the note" lands)
+    win = np.concatenate([np.arange(0, 1024), np.arange(V // 2 - 512, V // 2 + 512), np.arange(V - 1024, V)])
+    slot_of = {int(p): i for i, p in enumerate(win)}
+    ora = s2o.OracleSynth(win.size)
+    rows = torch.zeros((N, F), dtype=torch.float32, device="cuda")
+    out = torch.zeros(F, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    rng = np.random.RandomState(11)
+    for b in range(3):
+        if b == 0:
+            ev = np.zeros(V, dtype=s2.NOTE_EVENT_DTYPE)
+            ev["kind"] = 1; ev["note"] = 36 + np.arange(V) % 61; ev["velocity"] = 1.0
+        else:
+            n = 4096
+            ev = np.zeros(n, dtype=s2.NOTE_EVENT_DTYPE)
+            ev["kind"] = rng.randint(0, 2, n); ev["note"] = 36 + rng.randint(0, 61, n); ev["velocity"] = 1.0
+            ev["frame"] = np.sort(rng.randint(0, F // 16, n)) * 16 if b == 2 else 0
+        for s in shards + [one]:
+            s.note_events(ev)
+        # Per-voice rows come from the twins.  s2r_render_voices takes no timed events, so the twins (and the window's
+        # oracle voices) are driven the way the reference's caller would: the events of a boundary, then the frames up
+        # to the next one.  The window's truth: replay the policy, apply what lands in the window, render.
+        want = np.zeros((win.size, F), dtype=np.float32)
+        pvs = [np.zeros((per, F), dtype=np.float32) for _ in range(N)]
+        bounds = sorted(set([0] + [int(f) for f in ev["frame"]] + [F]))
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            batch = ev[(ev["frame"] == lo)]
+            for e in batch:
+                if e["kind"] == 1:
+                    idx = policy.note_on(int(e["note"]), 1.0)
+                    if idx in slot_of:
+                        _poke_note_on(ora, slot_of[idx], int(e["note"]))
+                else:
+                    idx = policy.note_off(int(e["note"]))
+                    if idx in slot_of:
+                        _poke_note_off(ora, slot_of[idx])
+            ub = batch.copy(); ub["frame"] = 0
+            for t in twins:
+                t.note_events(ub)
+            n = hi - lo
+            want[:, lo:hi] = ora.render_voices(n, SR, threads=_threads())
+            policy.advance(n)
+            for k, t in enumerate(twins):
+                pvs[k][:, lo:hi] = t.render_voices(n, SR)
+        for k, s in enumerate(shards):
+            s.fill_device(rows[k].data_ptr(), F, SR, stream)
+        s2.sum_partials_device(rows.data_ptr(), N, F, out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        rows_h = rows.cpu().numpy()
+        acc = np.zeros(F, dtype=np.float32)
+        for k in range(N):
+            pool_idx = s2.synth.shard_pool_indices(V, k, N, G)
+            sel = np.nonzero(np.isin(pool_idx, win))[0]
+            assert sel.size == win.size // N
+            got = pvs[k][sel]
+            assert_bits_equal(got, want[[slot_of[int(p)] for p in pool_idx[sel]]], "shard %d, window rows, buffer %d" % (k, b))
+            part = s2o.mix_tree_partial(pvs[k], shards[k].block_voices)
+            assert_bits_equal(rows_h[k], part, "shard %d partial row, buffer %d" % (k, b))
+            acc = acc + part
+        assert_bits_equal(out.cpu().numpy(), acc, "rank-ordered sum of the 8 partial rows, buffer %d" % b)
+        assert_bits_equal(one.sample(np.empty(F, dtype=np.float32)), acc, "one handle over a device list of 8, buffer %d" % b)

@@ -44,22 +44,20 @@ def test_c1_one_voice_default_patch():
     assert np.any(g == 0.0)      # envelope has ended
 
 
-@pytest.mark.parametrize("lanes", [1])      # (round 1's 2- and 4-lanes-per-voice kernels are gone)
 @pytest.mark.parametrize("osc", [s2.OSC_SQUARE, s2.OSC_SAW, s2.OSC_TRIANGLE, s2.OSC_SINE])
 @pytest.mark.parametrize("fm", [0.0, 3.5])
-def test_per_voice_all_oscillators(osc, fm, lanes):
+def test_per_voice_all_oscillators(osc, fm):
     """every oscillator kind, with and without oscillator FM (mod_env_to_osc_freq), mix off"""
     patch = make_patch(osc_kind=osc, mod_env_to_osc_freq=fm, noise=0.25, osc_gain=0.75)
     patch.mod_env.attack_ms = 5.0
     patch.mod_env.sustain = 0.3
     patch.mod_env.release_ms = 40.0
-    pr = Pair(64, patch, lanes=lanes)
-    assert pr.gpu.lanes_per_voice in (1, lanes)      # 2 and 4 exist only in builds with S2R_WITH_LANE_VARIANTS
+    pr = Pair(64, patch)
     for v in range(40):
         pr.note_on(30 + (v * 7) % 70)
     for k in range(6):
         g, o = pr.render_voices(512)
-        assert_bits_equal(g, o, "osc %d fm %g lanes %d block %d" % (osc, fm, lanes, k))
+        assert_bits_equal(g, o, "osc %d fm %g block %d" % (osc, fm, k))
         if k == 2:
             for v in range(0, 40, 3):
                 pr.note_off(30 + (v * 7) % 70)
@@ -67,22 +65,20 @@ def test_per_voice_all_oscillators(osc, fm, lanes):
 
 def test_c2_1024_voices_one_workgroup():
     """BASELINE config 1: 1024 voices, default patch, one 1024-thread workgroup"""
-    _run_c2(block_voices=1024, lanes=1)
+    _run_c2(block_voices=1024)
 
 
-@pytest.mark.parametrize("lanes", [1])      # (round 1's 2- and 4-lanes-per-voice kernels are gone)
-def test_c2_1024_voices_blocks_of_256(lanes):
-    _run_c2(block_voices=256, lanes=lanes)
+def test_c2_1024_voices_blocks_of_256():
+    _run_c2(block_voices=256)
 
 
-@pytest.mark.parametrize("lanes", [1])      # (round 1's 2- and 4-lanes-per-voice kernels are gone)
 @pytest.mark.parametrize("stream", [3, 4, 1, 0])
-def test_coefficient_stream_is_bit_neutral(stream, lanes):
+def test_coefficient_stream_is_bit_neutral(stream):
     """64-voice groups with a moving mod envelope get their LPF coefficients from the ahead-of-time
     pass; with it off they are computed in-lane.  Mixed population: some groups fully flat, some
     partly moving, some restarted mid-run, ragged fills (tail frames bypass the stream)."""
     V = 1024
-    pr = Pair(V, lanes=lanes, max_frames=1024)
+    pr = Pair(V, max_frames=1024)
     pr.gpu.set_coeff_stream(stream)      # 3: events in the classification launch where possible, 4: separate kernels, 1: default policy, 0: in-lane
     for v in range(V):
         pr.note_on(36 + v % 61)          # 1024 events: more than one launch carries -> separate kernels
@@ -94,7 +90,7 @@ def test_coefficient_stream_is_bit_neutral(stream, lanes):
             for note in range(36, 97, 3):
                 pr.note_off(note)
         g, o, _pv = pr.sample(n)
-        assert_bits_equal(g, o, "stream=%s lanes=%d buffer %d" % (stream, lanes, b))
+        assert_bits_equal(g, o, "stream=%s buffer %d" % (stream, b))
 
 
 @pytest.mark.parametrize("mode", [3, 4])
@@ -155,9 +151,9 @@ def test_sample_rate_without_fast_division():
         assert_bits_equal(g, o, "sr 44100")
 
 
-def _run_c2(block_voices, lanes):
+def _run_c2(block_voices):
     V = 1024
-    pr = Pair(V, block_voices=block_voices, lanes=lanes)
+    pr = Pair(V, block_voices=block_voices)
     for v in range(V):
         pr.note_on(36 + (v % 61))
     # per-note release countdown derived from the LCG so every ADSR stage is live
@@ -173,13 +169,12 @@ def _run_c2(block_voices, lanes):
     print("C2 tree-vs-sequential mix deviation: %d ULP max" % worst)
 
 
-@pytest.mark.parametrize("lanes", [1])
 @pytest.mark.parametrize("frames", [1, 7, 15, 17, 100, 1000, 1023])
-def test_tail_frames_use_scalar_path(frames, lanes):
+def test_tail_frames_use_scalar_path(frames):
     """frames % 16 != 0: the tail goes through the scalar path with its different semantics
     (multiplicative gains, release from the current level, libm powf) — process.rs:39-48"""
     patch = make_patch(noise=0.5, osc_gain=0.5, mod_env_to_osc_freq=1.25)
-    pr = Pair(16, patch, lanes=lanes)
+    pr = Pair(16, patch)
     for v in range(10):
         pr.note_on(40 + 3 * v)
     for k in range(5):
@@ -443,13 +438,13 @@ def test_c4_shard_size_131072_voices():
     _full_size(131072, 2, 256)
 
 
-@pytest.mark.parametrize("voices,lanes", [(8, 1), (300, 1)])
-def test_timed_events_reproduce_the_16_frame_call_pattern(voices, lanes):
+@pytest.mark.parametrize("voices", [8, 300])
+def test_timed_events_reproduce_the_16_frame_call_pattern(voices):
     """note events stamped with a frame offset take effect INSIDE one 1024-frame launch exactly as
     if the caller had called sample() 16 frames at a time with MIDI applied in between, which is
     what s2_bin does (main.rs:138-143): the oracle is driven that way, chunk by chunk."""
-    pr = Pair(voices, lanes=lanes, max_frames=1024)
-    rng = np.random.RandomState(voices * 7 + lanes)
+    pr = Pair(voices, max_frames=1024)
+    rng = np.random.RandomState(voices * 7 + 1)
     held = []
     for b in range(8):
         frames = 1024 if b != 5 else 1000                 # one ragged buffer: tail frames + an event at the tail boundary
@@ -480,7 +475,7 @@ def test_timed_events_reproduce_the_16_frame_call_pattern(voices, lanes):
             pv[:, c:c + n] = pr.cpu.render_voices(n)
         assert k == n_ev
         o = s2o.mix_tree(pv, pr.block_voices, 1)
-        assert_bits_equal(g, o, "timed events, %d voices, L=%d, buffer %d" % (voices, lanes, b))
+        assert_bits_equal(g, o, "timed events, %d voices, buffer %d" % (voices, b))
     st = pr.gpu.export_state()
     for v in range(voices):
         cv = pr.cpu.voice(v)

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_loads_and_exports_every_declared_symbol():
     L = s2.load_library()
-    assert L.s2r_abi_version() == 3
+    assert L.s2r_abi_version() == 4
     hdr = open(os.path.join(ROOT, "include", "s2r.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     names = sorted(set(re.findall(r"\b(s2r_[a-z0-9_]+)\s*\(", hdr)))
@@ -32,6 +32,9 @@ def test_no_cpu_fallback_without_a_device(has_gpu):
     with pytest.raises(s2.S2rError) as e:
         s2.Synth(8)
     assert e.value.status == -2      # S2R_ERR_NO_DEVICE
+    with pytest.raises(s2.S2rError) as e:
+        s2.Synth(512, devices=[0, 0])       # a device list needs its devices just the same
+    assert e.value.status == -2
 
 
 def test_status_strings():

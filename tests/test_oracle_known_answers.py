@@ -346,3 +346,46 @@ def test_phased_offset_stays_below_the_period():
     off = period * ph
     assert not np.any(off >= period)
     assert np.array_equal(np.fmod(off, period), off)
+
+
+@pytest.mark.parametrize("voices,block,groups,frames", [(8, 256, 1, 100), (300, 64, 1, 33), (1000, 256, 3, 64), (4096 + 17, 128, 2, 16), (70, 1024, 1, 7)])
+def test_mix_tree_row_form_equals_the_scalar_statement(voices, block, groups, frames):
+    """the tree a row at a time (what the full-size checks use) performs the additions of the frame-at-a-time statement
+    in the same order: bit-equal on rows with signed zeros, ragged pools and every grouping"""
+    rng = np.random.RandomState(voices + frames)
+    pv = (rng.randn(voices, frames) * rng.choice([1e-3, 1.0, 1e3], (voices, 1))).astype(np.float32)
+    pv[rng.rand(voices, frames) < 0.1] = -0.0
+    pv[rng.rand(voices) < 0.2] = 0.0
+    assert np.array_equal(bits(s2o.mix_tree(pv, block, groups)), bits(s2o.mix_tree(pv, block, groups, scalar=True)))
+    assert np.array_equal(bits(s2o.mix_tree_partial(pv, block)), bits(s2o.mix_tree_partial(pv, block, scalar=True)))
+
+
+def test_render_events_is_the_16_frame_call_pattern():
+    """s2o_render_events_mt (events applied at their 16-frame boundary, the stretches in between rendered by the thread
+    pool) against the reference caller's loop spelled out: apply MIDI, sample(16 frames), repeat (main.rs:138-147)"""
+    V = 96
+    rng = np.random.RandomState(3)
+    a, b = s2o.OracleSynth(V), s2o.OracleSynth(V)
+    ev_dtype = np.dtype([("kind", np.uint8), ("note", np.uint8), ("frame", np.uint16), ("velocity", np.float32)])
+    for k in range(6):
+        frames = 512 if k != 3 else 500
+        n = int(rng.randint(0, 60))
+        ev = np.zeros(n, dtype=ev_dtype)
+        ev["kind"] = rng.randint(0, 2, n) | (k == 0); ev["note"] = rng.randint(50, 60, n); ev["velocity"] = 1.0
+        ev["frame"] = np.sort(rng.randint(0, (frames + 15) // 16, n)) * 16
+        pv, mix = a.render_events(ev, frames, threads=3, per_voice=True, mix=False), None
+        want = np.zeros((V, frames), dtype=np.float32)
+        i = 0
+        for c in range(0, frames, 16):
+            while i < n and ev["frame"][i] == c:
+                (b.note_on if ev["kind"][i] else b.note_off)(int(ev["note"][i])); i += 1
+            m = min(16, frames - c)
+            want[:, c:c + m] = b.render_voices(m)
+        assert np.array_equal(bits(pv), bits(want)), k
+    # the mix form (thread partials added in thread order): one thread is the reference's sequential order
+    c, d = s2o.OracleSynth(V), s2o.OracleSynth(V)
+    on = np.zeros(40, dtype=ev_dtype); on["kind"] = 1; on["note"] = 40 + np.arange(40); on["velocity"] = 1.0
+    m1 = c.render_events(on, 256, threads=1, per_voice=False, mix=True)
+    for e in on:
+        d.note_on(int(e["note"]))
+    assert np.array_equal(bits(m1), bits(d.sample(256)))

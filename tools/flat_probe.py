@@ -6,7 +6,7 @@ import numpy as np, torch
 import synth2_amd as s2
 voices, frames, flat = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 lanes = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-s = s2.Synth(voices, max_frames=4096, lanes_per_voice=lanes)
+s = s2.Synth(voices, max_frames=4096)
 ev = np.zeros(voices, dtype=s2.NOTE_EVENT_DTYPE); ev["kind"] = 1; ev["note"] = 36 + np.arange(voices) % 61
 s.note_events(ev)
 out = torch.zeros(4096, device="cuda")

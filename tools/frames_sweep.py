@@ -5,7 +5,7 @@ import numpy as np, torch
 import synth2_amd as s2
 
 def run(voices, frames, flat=True, lanes=0, reps=12):
-    s = s2.Synth(voices, max_frames=4096, lanes_per_voice=lanes)
+    s = s2.Synth(voices, max_frames=4096)
     ev = np.zeros(voices, dtype=s2.NOTE_EVENT_DTYPE); ev["kind"] = 1; ev["note"] = 36 + np.arange(voices) % 61
     s.note_events(ev)
     out = torch.zeros(4096, device="cuda")
@@ -17,7 +17,7 @@ def run(voices, frames, flat=True, lanes=0, reps=12):
     for _ in range(reps):
         s.fill_device(out.data_ptr(), frames, 48000, st)
         ms.append(s.last_render_ms())
-    return float(np.median(ms)), s.lanes_per_voice
+    return float(np.median(ms)), 1
 
 import itertools
 cases = [(65536, 0), (131072, 0), (16384, 0)] if len(sys.argv) < 2 else [(int(a.split(":")[0]), int(a.split(":")[1])) for a in sys.argv[1:]]
