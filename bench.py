@@ -54,6 +54,7 @@ PERIOD = 64                     # buffers between two lives of a voice (workload
 BYTES_PER_VOICE_FILL = 28 + 12
 # fp32-equivalent flops per voice-sample of the x16 path with the default patch
 FLOPS_PER_VOICE_SAMPLE = 250.0
+PROFILE_ROUND = "r03"                 # profiles/<round>/c3_summary.json: the rocprofv3 summary bench.py quotes counters from
 HBM_PEAK_GBS = 8000.0
 VALU_PEAK_TFLOPS = 157.3
 # one wave-instruction per SIMD per 2 cycles (SIMD-32, MI355X_MICROARCH.md): 1024 SIMDs x 2.4 GHz / 2
@@ -83,7 +84,7 @@ def make_events(total_voices, churn_per_64k, step, rng_seed=1):
     return ev
 
 
-def make_c3_events(total_voices, period=PERIOD):
+def make_c3_events(total_voices, period=PERIOD, frames=FRAMES):
     """workload `c3`: the event batch of every buffer of one period (the schedule repeats every `period` buffers).
     Buffer b starts the lives of voices [b * V / period, (b + 1) * V / period) at its frame 0 and carries the note-offs
     that fall inside it, each at its own 16-frame boundary."""
@@ -93,8 +94,8 @@ def make_c3_events(total_voices, period=PERIOD):
     delay = 16 * (512 + ((1103515245 * v + 12345) % (1 << 31)) % 2048)          # frames from note-on to note-off
     per = max(1, total_voices // period)
     start_buf = np.minimum(v // per, period - 1)
-    off_buf = (start_buf + delay // FRAMES) % period
-    off_frame = delay % FRAMES
+    off_buf = (start_buf + delay // frames) % period
+    off_frame = delay % frames
     batches = []
     for b in range(period):
         on = np.nonzero(start_buf == b)[0]
@@ -113,10 +114,75 @@ def make_c3_events(total_voices, period=PERIOD):
     return batches
 
 
-def cpu_oracle_rate(voices, buffers, threads):
-    """The CPU oracle (test infrastructure) timed as the reported CPU baseline: voices x 1024 frames x buffers."""
+def host_cpus():
+    """(threads this process may run at once, physical cores among them): the affinity mask cut down to the cgroup's CPU
+    quota, and the distinct (package, core) pairs of the CPUs in the mask (SMT siblings count once)."""
+    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(float(q) / float(per)))
+    except Exception:
+        pass
+    cores = set()
+    try:
+        cur = {}
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = [x.strip() for x in line.split(":", 1)]
+                cur[k] = v
+            elif not line.strip():
+                if cur.get("processor") is not None and int(cur["processor"]) in cpus:
+                    cores.add((cur.get("physical id", "0"), cur.get("core id", cur["processor"])))
+                cur = {}
+    except Exception:
+        pass
+    physical = len(cores) if cores else len(cpus)
+    usable = min(len(cpus), quota) if quota else len(cpus)
+    return usable, min(physical, usable)
+
+
+def one_cpu_per_core(n):
+    """n CPU numbers of the affinity mask on n different physical cores (for pinning the CPU baseline's threads: two
+    of them on the SMT siblings of one core would share it), or [] when the topology cannot be read"""
+    cpus = set(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else set()
+    seen, picks, cur = set(), [], {}
+    try:
+        for line in list(open("/proc/cpuinfo")) + [""]:
+            if ":" in line:
+                k, v = [x.strip() for x in line.split(":", 1)]
+                cur[k] = v
+            elif not line.strip():
+                if cur.get("processor") is not None and int(cur["processor"]) in cpus:
+                    core = (cur.get("physical id", "0"), cur.get("core id", cur["processor"]))
+                    if core not in seen:
+                        seen.add(core); picks.append(int(cur["processor"]))
+                cur = {}
+    except Exception:
+        return []
+    return picks[:n] if len(picks) >= n else []
+
+
+def cpu_oracle_rate(voices, buffers, threads, c3=False):
+    """The CPU oracle (test infrastructure) timed as the reported CPU baseline: voices x 1024 frames x buffers.
+    c3=True: the bench's own event schedule (make_c3_events), driven as the reference's caller drives Synth — events applied
+    between 16-frame sample() calls (main.rs:138-147) — after one untimed period; returns the rate over the RENDERING time
+    (the reference's O(voices) scans per note event, an artefact of an 8-voice design at this pool size, are timed apart)."""
     from oracle import s2o
     s = s2o.OracleSynth(voices)
+    if c3:
+        period = PERIOD if voices >= PERIOD else 1
+        cyc = make_c3_events(voices, period)
+        for k in range(period + 2):                        # one life of every voice: the stage mix the GPU leg is timed on
+            s.render_events(cyc[k % period], FRAMES, SR, threads=threads, per_voice=False, mix=True)
+        s2o.events_seconds(reset=True)
+        t0 = time.perf_counter()
+        for k in range(buffers):
+            s.render_events(cyc[(period + 2 + k) % period], FRAMES, SR, threads=threads, per_voice=False, mix=True)
+        dt = time.perf_counter() - t0
+        policy_s, render_s = s2o.events_seconds(reset=True)
+        return voices * FRAMES * buffers / render_s, dt, policy_s
     for v in range(voices):
         s.note_on(36 + v % 61)
     s.sample_mt(FRAMES, SR, threads)          # warm-up buffer
@@ -124,22 +190,128 @@ def cpu_oracle_rate(voices, buffers, threads):
     for _ in range(buffers):
         s.sample_mt(FRAMES, SR, threads)
     dt = time.perf_counter() - t0
-    return voices * FRAMES * buffers / dt, dt
+    return voices * FRAMES * buffers / dt, dt, 0.0
 
 
-def cpu_baseline_legs(cores, budget_s):
+def cpu_baseline_legs(budget_s):
     """§8(d): (1) one thread at the reference's own pool size (NUM_VOICES = 8, synth.rs:7) and at 1 024 voices
-    (cache-resident), (2) all cores at C3's 65 536 voices.  Each leg is sized to about budget_s seconds."""
+    (cache-resident), (2) one thread per physical core at C3's 65 536 voices on C3's event schedule.  Each leg is sized to
+    about budget_s seconds.  The oracle is rebuilt for THIS host with -march=native first."""
+    from oracle import s2o
+    s2o.use_native_build()
+    usable, physical = host_cpus()
     legs = []
-    for voices, threads in ((8, 1), (1024, 1), (65536, cores)):
-        probe, dt = cpu_oracle_rate(voices, 1, threads)
+    for voices, threads, c3 in ((8, 1, False), (1024, 1, False), (65536, physical, True)):
+        if c3:
+            probe = 1.6e7 * threads                        # (an estimate sizes the leg: a probe would cost a whole period)
+        else:
+            probe, _dt, _p = cpu_oracle_rate(voices, 1, threads)
         nb = int(max(1, min(20000, budget_s * probe / (voices * FRAMES))))
-        v, secs = cpu_oracle_rate(voices, nb, threads)
+        pins = one_cpu_per_core(threads) if threads > 1 else []
+        old_mask = os.sched_getaffinity(0) if pins else None
+        if pins:
+            s2o.pool_pin(pins); os.sched_setaffinity(0, {pins[0]})
+        try:
+            v, secs, policy_s = cpu_oracle_rate(voices, nb, threads, c3)
+        finally:
+            if pins:
+                s2o.pool_pin([]); os.sched_setaffinity(0, old_mask)
         legs.append({"value": v, "unit": "samples/s", "cores": threads, "kind": "port", "voices": voices,
+                     "physical_cores_available": physical, "hardware_threads_available": usable, "threads_pinned_one_per_core": bool(pins),
                      "ns_per_voice_sample_per_core": 1e9 * threads / v,
-                     "sample": "%d voices x %d frames x %d buffers, default patch, all notes held (amp sustain), %.1f s" % (
-                         voices, FRAMES, nb, secs)})
+                     "sample": ("%d voices x %d frames x %d buffers, default patch, %s, %.1f s%s; oracle built -O2 -march=native -ffp-contract=off" % (
+                         voices, FRAMES, nb,
+                         "the bench's C3 schedule after one untimed period, events applied between 16-frame sample() calls" if c3 else "all notes held (amp sustain)",
+                         secs, (" of which %.1f s in the reference's O(voices) note_on / note_off scans, excluded from the rate" % policy_s) if c3 else ""))})
+    one = legs[1]["value"]
+    legs[2]["scaling_vs_one_thread"] = legs[2]["value"] / (one * legs[2]["cores"])
     return legs
+
+
+def run_config_leg(name, voices, patch_text, steps, warmup, oversampled=False, bytes_per_voice=BYTES_PER_VOICE_FILL):
+    """One more configuration of BASELINE.json timed the way the headline is (N = 1, after it, so that it cannot perturb
+    it): the C3 event schedule on `voices` voices of `patch_text`, aged for two periods, `warmup` + `steps` buffers through
+    the host-buffer API.  oversampled: s2r_fill_oversampled (config [4]: the path at 4 x 48 kHz — 4 096 internal frames per
+    1 024-frame buffer, note-offs on the internal rate's 16-frame boundaries — and the decimator), one buffer at a time."""
+    import synth2_amd as s2
+    internal = FRAMES * (4 if oversampled else 1)
+    synth = s2.Synth(voices, max_frames=internal)
+    synth.load_patch(patch_text)
+    period = PERIOD
+    cyc = make_c3_events(voices, period, internal)
+    out = np.empty(FRAMES, dtype=np.float32)
+    state = {"k": 0, "in_flight": 0}
+
+    def step():
+        synth.note_events(cyc[state["k"] % period]); state["k"] += 1
+        if oversampled:
+            out[:] = synth.sample_oversampled(FRAMES, SR)
+            return
+        synth.sample_begin(FRAMES, SR); state["in_flight"] += 1
+        if state["in_flight"] == 2:
+            synth.sample_end(out); state["in_flight"] -= 1
+
+    def drain():
+        while state["in_flight"]:
+            synth.sample_end(out); state["in_flight"] -= 1
+
+    for _ in range(2 * period + 2 + warmup):
+        step()
+    drain()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    drain()
+    dt = time.perf_counter() - t0
+    synth.set_timing(True)
+    kms = []
+    for _ in range(min(max(steps, 4), 16)):
+        synth.note_events(cyc[state["k"] % period]); state["k"] += 1
+        if oversampled:
+            synth.sample_oversampled(FRAMES, SR)
+        else:
+            synth.sample(out, SR)
+        kms.append(synth.last_render_ms())
+    synth.set_timing(False)
+    kernel_ms = float(np.median(kms))
+    hbm = bytes_per_voice * voices / (kernel_ms * 1e-3) / 1e9
+    leg = {"name": name, "voices": voices, "patch": " ".join(patch_text.split()), "steps": steps,
+           "ms_per_step": dt * 1e3 / steps, "value": voices * FRAMES * steps / dt, "unit": "samples/s (output-rate voice-samples)",
+           "kernel_ms": kernel_ms, "value_kernel_only": voices * FRAMES / (kernel_ms * 1e-3),
+           "roofline": {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_voice_per_fill": bytes_per_voice},
+           "mix_checksum": float(np.abs(out).sum())}
+    if oversampled:
+        leg["internal_rate_voice_samples_per_s"] = leg["value"] * 4.0
+        leg["timed_call"] = "s2r_note_events + s2r_fill_oversampled (4 096 internal frames at 192 kHz -> 1 024 at 48 kHz), one buffer at a time"
+    else:
+        leg["timed_call"] = "s2r_note_events + s2r_fill_begin / s2r_fill_end, two buffers in flight"
+    return leg, synth
+
+
+def executed_roofline(prof, voices, kernel_ms):
+    """The VALU roofline of the launches bench.py times, from what they EXECUTED (committed rocprofv3 summary of this
+    build of the kernels: tools/profile_gpu.sh + tools/summarize_prof.py): wave-instructions against the issue rate, and
+    flop-equivalents (add / mul / other 1, fma 2, transcendental 1; a packed instruction counts for its two halves)
+    against the fp32 vector peak."""
+    if prof is None:
+        return None
+    pm = prof.get("pmc_avg_per_dispatch", {})
+    dur = prof.get("dispatch", {}).get("avg_ns")
+    if not dur or "SQ_INSTS_VALU" not in pm:
+        return None
+    n = pm["SQ_INSTS_VALU"]
+    out = {"bound": "valu-issue", "achieved": n / (dur * 1e-9), "peak": VALU_ISSUE_PEAK_PER_S, "unit": "wave-instructions/s",
+           "frac": n / (dur * 1e-9) / VALU_ISSUE_PEAK_PER_S,
+           "kernel": prof.get("dispatch", {}).get("Kernel_Name"), "kernel_ns_profiled": dur, "kernel_ms_live": kernel_ms,
+           "wave_instructions_per_launch": n, "per_voice_frame": n * 64.0 / (voices * FRAMES),
+           "note": "SQ_INSTS_VALU per launch of the TIMED steps / launch duration vs one wave-instruction per SIMD per 2 cycles (1024 SIMDs x 2.4 GHz / 2)"}
+    ex = prof.get("executed_flop_eq")
+    if ex:
+        tf = ex["flop_eq_per_launch"] / (dur * 1e-9) / 1e12
+        out["executed"] = {"flop_eq_per_launch": ex["flop_eq_per_launch"], "flop_eq_per_voice_sample": ex["flop_eq_per_launch"] / (voices * FRAMES),
+                           "achieved_tflops": tf, "peak_tflops": VALU_PEAK_TFLOPS, "frac": tf / VALU_PEAK_TFLOPS, "model": ex.get("model")}
+    return out
 
 
 def kernel_source_hash():
@@ -157,7 +329,7 @@ def committed_profile():
     """PMC figures of the render kernel from the committed rocprofv3 summary — only if it was taken on THIS build of
     the kernels (same source hash); otherwise None (a stale profile is not evidence for the line being printed)."""
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r02", "c3_summary.json")))
+        prof = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "c3_summary.json")))
     except Exception:
         return None
     if prof.get("kernel_source_hash") != kernel_source_hash():
@@ -178,6 +350,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap the all-gather with the next render")
     ap.add_argument("--reduce", action="store_true", help="N > 1: combine the partial mixes with one reduce(sum) to rank 0 instead of all-gather + rank-ordered sum")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the SVF and 4x-oversampled configurations timed after the headline")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="seconds per CPU-baseline leg (three legs)")
     args = ap.parse_args()
 
@@ -213,9 +386,7 @@ def main():
     # (s2r_note_events) then runs 2x slower and the step is host-bound.  Twenty seconds of all cores busy settle that.
     cpu_legs = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        cores = max(1, min(cores, 64))
-        cpu_legs = cpu_baseline_legs(cores, args.cpu_seconds)
+        cpu_legs = cpu_baseline_legs(args.cpu_seconds)
 
     strong = args.voices_total > 0
     if strong:
@@ -229,6 +400,7 @@ def main():
     sh = ShardedSynth(vpg, max_frames=FRAMES, rank=rank, world=world, device=dev, block_voices=args.block_voices,
                       overlap=not args.no_overlap, reduce_to_root=args.reduce)
     synth = sh.renderer
+    block_voices = synth.block_voices
     sh.load_patch("synth mySynth {\n\n}\n")       # example.synth2: empty body == default patch
     if os.environ.get("S2R_COEFF_STREAM_MODE"):       # measurement aid (see s2r_set_coeff_stream); results are bit-identical
         synth.set_coeff_stream(int(os.environ["S2R_COEFF_STREAM_MODE"]))
@@ -281,16 +453,7 @@ def main():
             host_t[0] += tb - ta; host_t[1] += tc - tb; host_t[2] += td - tc
             return
         sh.note_events(events_of(k))
-        if world == 1:
-            # the host-buffer API with two buffers in flight, as s2_bin keeps them (audio_player.rs:56-60): buffer k is
-            # queued, then buffer k - 1 is waited for and copied into the caller's memory
-            synth.sample_begin(FRAMES, SR)
-            in_flight[0] += 1
-            if in_flight[0] == 2:
-                synth.sample_end(out_host)
-                in_flight[0] -= 1
-        else:
-            sh.fill(FRAMES, SR)
+        sh.fill(FRAMES, SR)
 
     def fence():
         while in_flight[0]:
@@ -404,6 +567,19 @@ def main():
         fence()
         kernel_ms_full_plain = float(np.median(kms))
 
+    # ---- the other single-GPU configurations of BASELINE.json, each timed like the headline, after it (N = 1) ----
+    config_legs = None
+    if world == 1 and rank == 0 and not args.no_config_legs:
+        synth = None; sh = None                    # (frees the headline's handle)
+        config_legs = []
+        leg, _s = run_config_leg("config[2] as written: 65 536 voices, saw + ADSR + SVF (build-defined state-variable filter; the reference has none)",
+                                 65536, "synth c2 { lpf.kind = svf_lp; lpf.q = 1.4 }", args.steps, args.warmup, bytes_per_voice=36 + 20)
+        config_legs.append(leg); del _s
+        leg, _s = run_config_leg("config[4]'s per-GPU share: 32 768 voices, alias-suppressed saw (DPW) + SVF, 4x oversampled (192 kHz internal)",
+                                 32768, "synth c4 { osc.kind = dpw_saw; lpf.kind = svf_lp; lpf.q = 1.4 }", max(4, args.steps // 4), max(1, args.warmup // 4),
+                                 oversampled=True, bytes_per_voice=40 + 24)
+        config_legs.append(leg); del _s
+
     if rank == 0:
         value = total * FRAMES * args.steps / dt_max
         kernel_s = kernel_ms * 1e-3
@@ -411,21 +587,14 @@ def main():
         valu_tf = FLOPS_PER_VOICE_SAMPLE * vpg * FRAMES / (kernel_ms_full * 1e-3) / 1e12
         prof = committed_profile()
         traffic = None
-        traffic_note = "no rocprofv3 PMC summary of this build of the kernels under profiles/r02 (hash %s): omitted rather than quoted from another build" % kernel_source_hash()
-        valu_issue = None
+        traffic_note = "no rocprofv3 PMC summary of this build of the kernels under profiles/%s (hash %s): omitted rather than quoted from another build" % (PROFILE_ROUND, kernel_source_hash())
         if prof is not None:
             pm = prof.get("pmc_avg_per_dispatch", {})
             if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
                 # separate passes, KiB units; dword-per-lane accesses, for which the guide's x2 FETCH_SIZE correction
                 # (16 B/lane streams) is not calibrated: raw counter sum
                 traffic = (pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
-                traffic_note = "profiles/r02/c3_summary.json, same kernel sources (hash %s)" % kernel_source_hash()
-            if "SQ_INSTS_VALU" in pm and prof.get("dispatch", {}).get("avg_ns"):
-                per_s = pm["SQ_INSTS_VALU"] / (prof["dispatch"]["avg_ns"] * 1e-9)
-                valu_issue = {"wave_instructions_per_launch": pm["SQ_INSTS_VALU"],
-                              "per_voice_frame": pm["SQ_INSTS_VALU"] * 64.0 / (vpg * FRAMES),
-                              "frac_of_issue_peak": per_s / VALU_ISSUE_PEAK_PER_S,
-                              "note": "SQ_INSTS_VALU per launch / launch time vs one wave-instruction per SIMD per 2 cycles"}
+                traffic_note = "profiles/%s/c3_summary.json, same kernel sources (hash %s)" % (PROFILE_ROUND, kernel_source_hash())
         out = {
             "metric": "voice-samples/sec (mono) at 64k voices per GPU, 48 kHz, 1024-frame buffers",
             "value": value,
@@ -450,23 +619,30 @@ def main():
                                      "s2r_note_events + s2r_fill_device per rank, all-gather, rank-ordered sum, async D2H of the mix on rank 0",
                        "voices_total": total, "frames": FRAMES, "sample_rate": SR,
                        "parallelism": "voice-shard x%d, %s of partial mixes" % (world, "reduce(sum) to rank 0" if args.reduce else "all-gather + rank-ordered sum"),
-                       "block_voices": synth.block_voices},
+                       "block_voices": block_voices},
             "msamples_per_s": value / 1e6,
             "realtime_factor_64k_voices": value / (65536.0 * SR),
             "roofline": {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": "s2r_render_kernel", "kernel_ms": kernel_ms,
                          "note": "algorithmic bytes = %d B per voice per fill; the path is VALU-issue-bound, see roofline_valu" % BYTES_PER_VOICE_FILL},
-            "roofline_valu": (lambda tf_c3, tf_plain: {
+            # The bound that applies: VALU issue.  For the launches that are TIMED (not a shortcuts-off variant): the vector
+            # instructions the render kernel really executed per launch (SQ_INSTS_VALU and the per-type counters of the
+            # committed rocprofv3 summary of this build) over the launch's duration, against the SIMDs' issue rate and,
+            # weighted (fma 2, packed x2), against the fp32 vector peak.  null when no summary of this build is committed.
+            "roofline_valu": executed_roofline(prof, vpg, kernel_ms),
+            # (diagnostic, not the product path) SURVEY 8(d)'s 250 flop-equivalents per voice-sample are the REFERENCE's
+            # arithmetic; the product kernel does not execute them (flat-envelope reuse, coefficient tables, hoisted
+            # constants, packed arithmetic).  With those shortcuts OFF every one of them runs in-lane:
+            "diagnostic_all_in_lane": (lambda tf_c3, tf_plain: {
                 "bound": "valu-fp32", "achieved": tf_plain if tf_plain else tf_c3, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": (tf_plain if tf_plain else tf_c3) / VALU_PEAK_TFLOPS,
                 "flops_per_voice_sample": FLOPS_PER_VOICE_SAMPLE,
                 "kernel_ms": kernel_ms_full_plain if kernel_ms_full_plain else kernel_ms_full,
                 "frac_c3_launches": tf_c3 / VALU_PEAK_TFLOPS, "kernel_ms_c3_launches": kernel_ms_full,
-                "issue_slots": valu_issue,
                 "note": "launch time with the flat-envelope reuse and the coefficient tables OFF, i.e. all 250 flop-eq per voice-sample executed in-lane. "
-                        "`frac`: the whole pool re-triggered and held, every voice inside its mod decay, no note events (the population round 1's 0.53 was measured on); "
-                        "`frac_c3_launches`: the C3 launches of the timed region in the same mode, whose event-dense waves set the launch's length (and have no tables to run the dense-event loop on in this mode)"})(
+                        "`frac`: the whole pool re-triggered and held, every voice inside its mod decay, no note events; "
+                        "`frac_c3_launches`: the C3 launches in the same mode"})(
                 valu_tf, (FLOPS_PER_VOICE_SAMPLE * vpg * FRAMES / (kernel_ms_full_plain * 1e-3) / 1e12) if kernel_ms_full_plain else None),
             "host_time_per_step": host_split if world == 1 else None,
                "value_host_api_sync": host_api_sync,
@@ -476,6 +652,8 @@ def main():
             "value_all_voices_modulating_note": "every voice re-triggered, then 8 buffers inside the 9 600-frame mod decay; device-resident fills queued back to back, product path (tables on)",
             "mix_checksum": float(np.abs(mix_host).sum()),
         }
+        if config_legs is not None:
+            out["config_legs"] = config_legs
         if world > 1:
             out["multi_gpu_note"] = ("this path has not been run on two or more GPUs by its authors (no such box was available to them): "
                                      "tests cover it with N ranks under gloo and with one rank through RCCL")

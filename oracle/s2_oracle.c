@@ -10,9 +10,11 @@
  * scalar "sisd" tail path are both here and deliberately DISAGREE exactly where the
  * reference does (process.rs:342-345,353-356 add the gains; process.rs:287,292 multiply).
  */
+#define _GNU_SOURCE
 #include "s2_oracle.h"
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -659,13 +661,31 @@ static struct {
     int scratch_n;
 } g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, NULL, 0, NULL, NULL, 0, 0, 0, NULL, NULL, 0 };
 
+/* timing legs: worker t runs on CPU g_pin[t] (one per physical core, chosen by the caller); n == 0: unpinned */
+static int g_pin[256], g_pin_n = 0;
+static unsigned long long g_pin_gen = 0;
+void s2o_pool_pin(const int *cpus, int n) {
+    pthread_mutex_lock(&g_pool.mu);
+    g_pin_n = n < 0 ? 0 : (n > 256 ? 256 : n);
+    for (int i = 0; i < g_pin_n; i++) g_pin[i] = cpus[i];
+    g_pin_gen++;
+    pthread_mutex_unlock(&g_pool.mu);
+}
+
 static void *pool_worker(void *arg) {
     const int me = (int)(intptr_t)arg;
-    unsigned long long seen = 0;
+    unsigned long long seen = 0, pin_seen = 0;
     pthread_mutex_lock(&g_pool.mu);
     for (;;) {
         while (g_pool.gen == seen) pthread_cond_wait(&g_pool.go, &g_pool.mu);
         seen = g_pool.gen;
+        if (pin_seen != g_pin_gen) {
+            pin_seen = g_pin_gen;
+            cpu_set_t set; CPU_ZERO(&set);
+            if (me < g_pin_n) CPU_SET(g_pin[me], &set);
+            else for (int c = 0; c < CPU_SETSIZE; c++) CPU_SET(c, &set);
+            pthread_setaffinity_np(pthread_self(), sizeof set, &set);       /* (an error leaves the thread where it is) */
+        }
         if (me < g_pool.n_active) {
             pool_fn fn = g_pool.fn; void *ctx = g_pool.ctx; const int n = g_pool.n_active;
             pthread_mutex_unlock(&g_pool.mu);

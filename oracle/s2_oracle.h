@@ -130,6 +130,8 @@ void s2o_sample_mt(s2o_synth *s, float *buffer, size_t frames, uint32_t sample_r
 typedef struct { uint8_t kind; uint8_t note; uint16_t frame; float velocity; } s2o_note_event;   /* kind: 0 off, 1 on, 2 program change */
 void s2o_render_events_mt(s2o_synth *s, const s2o_note_event *events, size_t n_events, float *per_voice, float *mix,
                           size_t frames, uint32_t sample_rate, int threads);
+/* timing legs: pool worker t (t >= 1; the caller is thread 0 and pins itself) runs on CPU cpus[t]; n = 0 unpins */
+void s2o_pool_pin(const int *cpus, int n);
 /* seconds spent by s2o_render_events_mt [0] in note_on / note_off (the reference's O(V) scans) and [1] rendering */
 void s2o_events_seconds(double out[2], int reset);
 void s2o_mix_sequential(const float *per_voice, uint32_t voices, size_t frames, float *out);

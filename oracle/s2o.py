@@ -98,6 +98,7 @@ def lib():
     L.s2o_sample_mt.argtypes = [P, _f32p, C.c_size_t, C.c_uint32, C.c_int]
     L.s2o_render_events_mt.argtypes = [P, C.c_void_p, C.c_size_t, _f32p, _f32p, C.c_size_t, C.c_uint32, C.c_int]
     L.s2o_events_seconds.argtypes = [C.POINTER(C.c_double), C.c_int]
+    L.s2o_pool_pin.argtypes = [C.POINTER(C.c_int), C.c_int]
     L.s2o_mix_sequential.argtypes = [_f32p, C.c_uint32, C.c_size_t, _f32p]
     L.s2o_mix_tree.argtypes = [_f32p, C.c_uint32, C.c_size_t, Tree, _f32p]
     L.s2o_mix_tree_partial.argtypes = [_f32p, C.c_uint32, C.c_size_t, C.c_uint32, _f32p]
@@ -224,6 +225,12 @@ class OracleSynth:
     @property
     def panicked(self):
         return bool(self.p.contents.panicked)
+
+
+def pool_pin(cpus):
+    """timing legs: thread t of the pool on CPU cpus[t] (thread 0 is the caller: os.sched_setaffinity); [] unpins"""
+    arr = (C.c_int * max(1, len(cpus)))(*cpus)
+    lib().s2o_pool_pin(arr, len(cpus))
 
 
 def events_seconds(reset=True):

@@ -98,24 +98,29 @@ __device__ __forceinline__ void mix_body(const S2rMixParams &m, uint32_t block, 
             for (uint32_t r = 1; r < n_runs; ++r) acc += s_run[(g * runs_per_group + r) * 16u + f_local];
             total = (m.root_add || g > 0) ? total + acc : acc;
         }
-        if (m.stereo) { m.out[2 * f] = total; m.out[2 * f + 1] = total; }
-        else m.out[f] = total;
+        if (m.stereo) { out_store(m.done, m.out + 2 * f, total); out_store(m.done, m.out + 2 * f + 1, total); }
+        else out_store(m.done, m.out + f, total);
     }
+    signal_done(m.done, (m.frames + 15u) / 16u);
 }
 
 __global__ void __launch_bounds__(256) s2r_mix_kernel(const S2rMixParams m) {
     extern __shared__ float s_run[];                             // [total runs][16 frames]
+    tl_mark(m.timeline, m.tl_slot, 0);
     mix_body(m, blockIdx.x, s_run);
+    tl_mark(m.timeline, m.tl_slot, 1);
 }
 
 // out[i] = ((+0.0 + rows[0][i]) + rows[1][i]) + ...   (rank-order combine of shard partials)
-__global__ void s2r_sum_rows_kernel(const float *rows, uint32_t n_rows, uint32_t frames, uint32_t stride, int stereo, float *out) {
+__global__ void s2r_sum_rows_kernel(const float *rows, uint32_t n_rows, uint32_t frames, uint32_t stride, int stereo, float *out, const S2rDone done) {
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= frames) return;
-    float total = 0.0f;                                          // accum = splat(0.0), synth.rs:176
-    for (uint32_t r = 0; r < n_rows; ++r) total += rows[(size_t)r * stride + f];
-    if (stereo) { out[2u * f] = total; out[2u * f + 1u] = total; }   // audio_player.rs:224-228
-    else out[f] = total;
+    if (f < frames) {
+        float total = 0.0f;                                      // accum = splat(0.0), synth.rs:176
+        for (uint32_t r = 0; r < n_rows; ++r) total += rows[(size_t)r * stride + f];
+        if (stereo) { out_store(done, out + 2u * f, total); out_store(done, out + 2u * f + 1u, total); }   // audio_player.rs:224-228
+        else out_store(done, out + f, total);
+    }
+    signal_done(done, gridDim.x);
 }
 
 // build-defined 4x decimator: out[n] = sum over k of h[k] * x[4n + k], taps in index order,
@@ -158,8 +163,10 @@ __global__ void s2r_tev_heads_kernel(int32_t *heads, const S2rTimedEvent *tev, S
 __global__ void __launch_bounds__(256) s2r_mix_and_heads_kernel(const S2rMixParams m, uint32_t mix_blocks, int32_t *heads,
                                                                 const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n) {
     extern __shared__ float s_run[];
+    tl_mark(m.timeline, m.tl_slot, 0);
     if (blockIdx.x < mix_blocks) mix_body(m, blockIdx.x, s_run);
     else heads_body(heads, tev, tev_copy, n, (blockIdx.x - mix_blocks) * blockDim.x + threadIdx.x);
+    tl_mark(m.timeline, m.tl_slot, 1);
 }
 
 // note events folded per voice by the host (synth.rs:61-80)
@@ -261,8 +268,10 @@ hipError_t s2r_launch_decimate4(float *x_with_history, const float *taps, uint32
     return hipGetLastError();
 }
 
-hipError_t s2r_launch_sum_rows(const float *rows, uint32_t n_rows, uint32_t frames, uint32_t stride, int stereo, float *out, hipStream_t stream) {
+hipError_t s2r_launch_sum_rows(const float *rows, uint32_t n_rows, uint32_t frames, uint32_t stride, int stereo, float *out, hipStream_t stream,
+                               const S2rDone *done) {
     if (frames == 0) return hipSuccess;
-    hipLaunchKernelGGL(s2r_sum_rows_kernel, dim3((frames + 255) / 256), dim3(256), 0, stream, rows, n_rows, frames, stride, stereo, out);
+    hipLaunchKernelGGL(s2r_sum_rows_kernel, dim3((frames + 255) / 256), dim3(256), 0, stream, rows, n_rows, frames, stride, stereo, out,
+                       done ? *done : S2rDone{nullptr, 0u, nullptr});
     return hipGetLastError();
 }

@@ -61,6 +61,16 @@ struct S2rBankEntry {
 
 struct S2rTimedEvent;
 
+// How the LAST kernel of a fill tells the host that the output (in mapped host memory) is complete: the last workgroup
+// to finish (a counter in device memory, reset by that workgroup) stores `value` into a word of mapped host memory the
+// host polls — a few hundred nanoseconds after the data, where waiting on a HIP event costs the caller tens of
+// microseconds between the GPU finishing and the wait returning.  flag == nullptr: nothing is signalled.
+struct S2rDone {
+    uint32_t *flag;          // mapped host memory (device view)
+    uint32_t value;
+    uint32_t *counter;       // device memory, 0 between launches
+};
+
 // Coefficient tables of ONE patch at one sample rate.  The x16 ADSR (old/simdtest.rs:270-331) makes
 // the mod envelope's value a function of the frame offset t alone while the voice is in its attack or decay stage
 // (the release offset is clamped to attack + decay, simdtest.rs:283), of t alone in a release that starts at that
@@ -112,6 +122,7 @@ struct S2rRenderParams {
     float *direct_out;       // single-workgroup shard with the root add: the final mix, written by the render
                              // kernel itself ((+0.0) + the block's sum, what s2r_mix_kernel computes for one row)
     int32_t direct_stereo;   // interleaved L,R
+    S2rDone done;            // with direct_out: told to the host when the output is written
     float *per_voice;        // [n_voices][frames] or nullptr (mix-disabled debug/parity path)
     const float *sin_table;  // 1024 floats (tables.rs)
     // coefficient tables: everything of a frame that depends on the mod envelope alone, as a
@@ -122,6 +133,9 @@ struct S2rRenderParams {
     int32_t *voice_ev_head;     // [padded voices] index of the voice's first timed event, -1 = none
     // diagnostic builds only (-DS2R_STAMPS, tools/stamps.py): [waves][16] s_memtime stamps of the render kernel's phases
     unsigned long long *stamps;
+    // ... and (tools/gpu_timeline.py) [launches][2] s_memrealtime of this launch's first entry and last exit, slot `tl_slot`
+    unsigned long long *timeline;
+    uint32_t tl_slot;
     // patch bank (bank_size > 1: s2r_render_general_kernel<ANY, true>; the fields above then hold patch 0)
     const S2rBankEntry *bank;
     uint32_t bank_size;
@@ -191,6 +205,9 @@ struct S2rMixParams {
     int32_t root_add;             // 1: out = (+0.0) + total  (synth.rs:176), 0: partial only
     int32_t stereo;               // 1: write interleaved L,R (audio_player.rs:224-228)
     float *out;
+    S2rDone done;                 // told to the host when `out` (mapped host memory) is complete
+    unsigned long long *timeline; // diagnostic builds only: as S2rRenderParams.timeline
+    uint32_t tl_slot;
 };
 
 hipError_t s2r_launch_tables(const S2rTabBuild &b, hipStream_t stream);
@@ -204,4 +221,5 @@ hipError_t s2r_launch_tev_heads(int32_t *heads, const S2rTimedEvent *tev, S2rTim
 // last 62 inputs copied to the front of x afterwards (second launch) for the next call
 hipError_t s2r_launch_decimate4(float *x_with_history, const float *taps, uint32_t n_out, float *out, hipStream_t stream);
 // out[i] = ((+0.0 + rows[0][i]) + rows[1][i]) + ...; rows are `stride` floats apart; stereo: interleaved L, R with L == R
-hipError_t s2r_launch_sum_rows(const float *rows, uint32_t n_rows, uint32_t frames, uint32_t stride, int stereo, float *out, hipStream_t stream);
+hipError_t s2r_launch_sum_rows(const float *rows, uint32_t n_rows, uint32_t frames, uint32_t stride, int stereo, float *out, hipStream_t stream,
+                               const S2rDone *done);

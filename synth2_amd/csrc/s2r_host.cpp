@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <atomic>
 #include <condition_variable>
@@ -97,8 +98,14 @@ struct EventSlot {
     S2rVoiceEvent *dev = nullptr;
     S2rTimedEvent *thost = nullptr;  // pinned, mapped: timed events of one fill
     S2rTimedEvent *tdev = nullptr;
+    // Who still reads the slot's pinned records: nobody (0); the kernels in front of `done`, a HIP event recorded behind
+    // them (1); or a fill whose completion word — index `idx`, value `seq` — the host can look at (2).  An event record
+    // between two kernels of a stream costs the GPU ~3 us of idle time at that boundary (measured, tools/gpu_timeline.py:
+    // boundaries of 4.5-5.0 us with the records, 1.7-2.4 without), so the fills that are tracked by a completion word
+    // record none.
     hipEvent_t done = nullptr;
-    bool in_flight = false;
+    int state = 0;
+    uint32_t idx = 0, seq = 0;
 };
 
 }  // namespace
@@ -147,6 +154,11 @@ struct s2r_synth {
     float *out_dev = nullptr;
     float *out_host = nullptr;                   // pinned and device-mapped, 2*max_frames
     float *out_host_dev = nullptr;               // the device's view of out_host
+    // Completion words (S2rDone): mapped host memory the last kernel of a fill writes its sequence number to — [0], [1]
+    // the two ring slots of s2r_fill_begin / s2r_fill_end, [2] the synchronous fills — and the arrival counter in HBM
+    uint32_t *done_host = nullptr, *done_dev = nullptr, *done_counter = nullptr;
+    uint32_t done_seq = 0;                       // last value handed out
+    uint32_t ring_seq[2] = {0, 0};               // what done_host[slot] must show before s2r_fill_end copies slot's buffer (0: wait on the event)
     // s2r_fill_begin / s2r_fill_end: two more mapped output buffers, the fills in flight (oldest first)
     float *ring_host[2] = {nullptr, nullptr}, *ring_dev[2] = {nullptr, nullptr};
     hipEvent_t ring_done[2] = {nullptr, nullptr};
@@ -165,6 +177,7 @@ struct s2r_synth {
     bool tab_dirty = true; uint32_t tab_rate = 0;
     float *bank_tab_dev = nullptr; size_t bank_tab_cap = 0;      // the patch bank's coefficient tables (floats)
     unsigned long long *stamps_dev = nullptr;            // diagnostic builds (-DS2R_STAMPS): per-wave phase stamps of the last fill
+    unsigned long long *timeline_dev = nullptr; uint32_t timeline_n = 0, timeline_cap = 0;   // ... and the launches' timeline
     bool use_tab = true, use_arg_events = true;
     float pitch_table[256];
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -299,16 +312,30 @@ int launch_deferred_mix(s2r_synth *s, hipStream_t stream) {
     if (!s->dmix.active) return S2R_OK;
     s->dmix.active = false;
     S2R_HIP(s, s2r_launch_mix(s->dmix.m, stream));
-    if (s->dmix.ring_slot >= 0) S2R_HIP(s, hipEventRecord(s->ring_done[s->dmix.ring_slot], stream));
     return S2R_OK;
 }
 
-int flush_events(s2r_synth *s, hipStream_t stream, EventSlot **timed_slot, const S2rTimedEvent **tev_dev) {
+// waits until nothing on the device reads the slot's pinned records any more
+int slot_release(s2r_synth *s, EventSlot &sl) {
+    if (sl.state == 1) S2R_HIP(s, hipEventSynchronize(sl.done));
+    else if (sl.state == 2 && (int32_t)(*(volatile uint32_t *)(s->done_host + sl.idx) - sl.seq) < 0) {
+        // (four slots rotate and at most two fills are in flight, so this is the rare path: the fill's last kernel — its
+        // mix, possibly still deferred — has not reported yet)
+        int rc = launch_deferred_mix(s, s->stream);
+        if (rc != S2R_OK) return rc;
+        S2R_HIP(s, hipStreamSynchronize(s->stream));
+    }
+    sl.state = 0;
+    return S2R_OK;
+}
+
+// `done`: the completion word of the fill these events belong to (nullptr: none; the slot is then guarded by an event)
+int flush_events(s2r_synth *s, hipStream_t stream, EventSlot **timed_slot, const S2rTimedEvent **tev_dev, const S2rDone *done = nullptr) {
     *timed_slot = nullptr; *tev_dev = nullptr;
     if (s->pending.empty() && s->tpending.empty()) return S2R_OK;
     EventSlot &sl = s->slots[s->next_slot];
     s->next_slot = (s->next_slot + 1) % kEventSlots;
-    if (sl.in_flight) { S2R_HIP(s, hipEventSynchronize(sl.done)); sl.in_flight = false; }
+    { int rc = slot_release(s, sl); if (rc != S2R_OK) return rc; }
     if (!s->pending.empty() && !s->tpending.empty()) {
         // The fill has timed events anyway (the render kernel will walk per-voice event chains): the events of its first
         // frame join them as frame-0 records at the head of their voice's chain — one launch (the chain heads) instead
@@ -345,7 +372,7 @@ int flush_events(s2r_synth *s, hipStream_t stream, EventSlot **timed_slot, const
         uint32_t cap = s->tev_capacity;
         while (cap < nt) cap *= 2u;
         for (EventSlot &e : s->slots) {
-            if (e.in_flight) { S2R_HIP(s, hipEventSynchronize(e.done)); e.in_flight = false; }
+            e.state = 0;                                       // (both streams were just waited for)
             S2R_HIP(s, hipHostFree(e.thost)); e.thost = nullptr; e.tdev = nullptr;
             S2R_HIP(s, hipHostMalloc((void **)&e.thost, (size_t)cap * sizeof(S2rTimedEvent), hipHostMallocMapped));
             S2R_HIP(s, hipHostGetDevicePointer((void **)&e.tdev, e.thost, 0));
@@ -359,16 +386,17 @@ int flush_events(s2r_synth *s, hipStream_t stream, EventSlot **timed_slot, const
         if (s->dmix.active && stream == s->stream) {           // the previous fill's mix rides with this fill's chain heads
             s->dmix.active = false;
             S2R_HIP(s, s2r_launch_mix_and_heads(s->dmix.m, s->voice_ev_head, sl.tdev, s->tev_copy, nt, stream));
-            if (s->dmix.ring_slot >= 0) S2R_HIP(s, hipEventRecord(s->ring_done[s->dmix.ring_slot], stream));
         } else {
             S2R_HIP(s, s2r_launch_tev_heads(s->voice_ev_head, sl.tdev, s->tev_copy, nt, stream));
         }
         *timed_slot = &sl; *tev_dev = s->tev_copy;         // the kernels read the HBM copy
         for (const S2rTimedEvent &e : s->tpending) s->tlast[e.voice] = -1;
         s->tpending.clear();
+    } else if (done) {
+        sl.state = 2; sl.idx = (uint32_t)(done->flag - s->done_dev); sl.seq = done->value;
     } else {
         S2R_HIP(s, hipEventRecord(sl.done, stream));
-        sl.in_flight = true;
+        sl.state = 1;
     }
     for (const S2rVoiceEvent &e : s->pending) s->pending_slot[e.voice] = -1;
     s->pending.clear();
@@ -492,7 +520,7 @@ S2rRenderParams make_params(s2r_synth *s, size_t frames, uint32_t sample_rate) {
 // events -> render -> (mix) on `stream`; the partial or final mix lands in `dev_out`
 // `defer_ring_slot` >= 0 (s2r_fill_begin): the fill's mix is left to the next fill_begin / fill_end (DeferredMix)
 int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t stream, float *dev_out,
-                 bool root_add, bool stereo, float *per_voice_dev, int defer_ring_slot = -1) {
+                 bool root_add, bool stereo, float *per_voice_dev, int defer_ring_slot = -1, const S2rDone *done = nullptr) {
     if (s->dmix.active && stream != s->stream) {
         // a fill on a caller's stream behind one in flight on ours: that one's mix reads the partial rows this fill
         // is about to overwrite
@@ -508,7 +536,7 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
     EventSlot *timed_slot = nullptr;
     const S2rTimedEvent *tev_dev = nullptr;
     if (!arg_events) {
-        int rc = flush_events(s, stream, &timed_slot, &tev_dev);
+        int rc = flush_events(s, stream, &timed_slot, &tev_dev, done);
         if (rc != S2R_OK) return rc;
     }
     {   // (no chain heads in this fill to take the previous fill's mix along: it goes alone, before the render kernel
@@ -574,6 +602,7 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
     if (tables_wanted(s)) p.tab = s->tab;
     else if (bank_kernel) { p.tab = S2rTabRef{}; p.tab.base = s->bank_tab_dev; }      // the per-lane-patch kernel adds each entry's tab_off
     p.stamps = s->stamps_dev;
+    if (s->timeline_dev && s->timeline_n < s->timeline_cap) { p.timeline = s->timeline_dev; p.tl_slot = s->timeline_n++; }
     p.per_voice = per_voice_dev;
     p.tev = tev_dev;
     p.voice_ev_head = s->voice_ev_head;
@@ -589,13 +618,13 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
     }
     // a shard of one workgroup needs no mix launch: its only partial row, root-added, is the output
     const bool direct = dev_out != nullptr && root_add && s->n_blocks == 1;
-    if (direct) { p.direct_out = dev_out; p.direct_stereo = stereo ? 1 : 0; }
+    if (direct) { p.direct_out = dev_out; p.direct_stereo = stereo ? 1 : 0; if (done) p.done = *done; }
     if (s->timing) S2R_HIP(s, hipEventRecord(s->t0, stream));      // brackets the render kernel alone
     S2R_HIP(s, s2r_launch_render(a, s->block_voices, stream));
     if (s->timing) { S2R_HIP(s, hipEventRecord(s->t1, stream)); s->timed = true; }
     if (timed_slot) {                     // the render kernel was the last reader of the slot's records
-        S2R_HIP(s, hipEventRecord(timed_slot->done, stream));
-        timed_slot->in_flight = true;
+        if (done) { timed_slot->state = 2; timed_slot->idx = (uint32_t)(done->flag - s->done_dev); timed_slot->seq = done->value; }
+        else { S2R_HIP(s, hipEventRecord(timed_slot->done, stream)); timed_slot->state = 1; }
     }
     if (dev_out && !direct) {
         S2rMixParams m{};
@@ -608,6 +637,8 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
         m.root_add = root_add ? 1 : 0;
         m.stereo = stereo ? 1 : 0;
         m.out = dev_out;
+        if (done) m.done = *done;
+        if (s->timeline_dev && s->timeline_n < s->timeline_cap) { m.timeline = s->timeline_dev; m.tl_slot = s->timeline_n++; }
         if (defer_ring_slot >= 0 && stream == s->stream) { s->dmix.active = true; s->dmix.m = m; s->dmix.ring_slot = defer_ring_slot; }
         else S2R_HIP(s, s2r_launch_mix(m, stream));
     }
@@ -622,7 +653,8 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
 // A device-list handle's fill: every shard renders on its own device and stream (shard 0 launched by this thread, the
 // others by their threads) and leaves its partial mix in row k of rows_dev[slot] on the parent's device; the parent's
 // stream waits for the rows and adds them in shard order rooted at +0.0 (synth.rs:176,195) into `dev_out`.
-int enqueue_multi(s2r_synth *s, size_t frames, uint32_t sample_rate, float *dev_out, bool stereo, float *per_voice_host = nullptr) {
+int enqueue_multi(s2r_synth *s, size_t frames, uint32_t sample_rate, float *dev_out, bool stereo, float *per_voice_host = nullptr,
+                  const S2rDone *done = nullptr) {
     const uint32_t n = (uint32_t)s->kids.size();
     const uint32_t slot = s->rows_slot;
     s->rows_slot ^= 1u;
@@ -660,14 +692,30 @@ int enqueue_multi(s2r_synth *s, size_t frames, uint32_t sample_rate, float *dev_
     if (per_voice_host) return S2R_OK;
     S2R_HIP(s, hipSetDevice(s->device));
     for (uint32_t k = 0; k < n; k++) S2R_HIP(s, hipStreamWaitEvent(s->stream, s->kid_done[slot][k], 0));
-    S2R_HIP(s, s2r_launch_sum_rows(s->rows_dev[slot], n, (uint32_t)frames, s->cfg.max_frames, stereo ? 1 : 0, dev_out, s->stream));
+    S2R_HIP(s, s2r_launch_sum_rows(s->rows_dev[slot], n, (uint32_t)frames, s->cfg.max_frames, stereo ? 1 : 0, dev_out, s->stream, done));
+    return S2R_OK;
+}
+
+// Waits for the fill whose last kernel stores `seq` into completion word `idx`: polls the word (mapped host memory) for
+// a bounded time, then falls back to the stream — an error on the device never leaves the caller spinning.
+int wait_done(s2r_synth *s, uint32_t idx, uint32_t seq) {
+    volatile uint32_t *f = s->done_host + idx;
+    for (int round = 0; round < 400; round++) {               // ~2-4 ms in all
+        for (int i = 0; i < 4000; i++) {
+            if ((int32_t)(*f - seq) >= 0) { std::atomic_thread_fence(std::memory_order_acquire); return S2R_OK; }
+            __builtin_ia32_pause();
+        }
+    }
+    S2R_HIP(s, hipStreamSynchronize(s->stream));
+    if ((int32_t)(*f - seq) < 0) return set_err(s, S2R_ERR_HIP, "the fill's last kernel finished without signalling completion");
     return S2R_OK;
 }
 
 // the fill of any handle on ITS stream: the final mix (root-added) lands in `dev_out`
-int enqueue_root(s2r_synth *s, size_t frames, uint32_t sample_rate, float *dev_out, bool stereo, int defer_ring_slot = -1) {
-    if (!s->kids.empty()) return enqueue_multi(s, frames, sample_rate, dev_out, stereo);
-    return enqueue_fill(s, frames, sample_rate, s->stream, dev_out, true, stereo, nullptr, defer_ring_slot);
+int enqueue_root(s2r_synth *s, size_t frames, uint32_t sample_rate, float *dev_out, bool stereo, int defer_ring_slot = -1,
+                 const S2rDone *done = nullptr) {
+    if (!s->kids.empty()) return enqueue_multi(s, frames, sample_rate, dev_out, stereo, nullptr, done);
+    return enqueue_fill(s, frames, sample_rate, s->stream, dev_out, true, stereo, nullptr, defer_ring_slot, done);
 }
 
 int fill_host(s2r_synth *s, float *out, size_t frames, uint32_t sample_rate, bool stereo) {
@@ -678,10 +726,12 @@ int fill_host(s2r_synth *s, float *out, size_t frames, uint32_t sample_rate, boo
     S2R_HIP(s, hipSetDevice(s->device));
     // the last kernel of the fill writes the few KiB of output straight into mapped host memory: no copy
     // command between the launch and the wait
-    rc = enqueue_root(s, frames, sample_rate, s->out_host_dev, stereo);
+    const S2rDone done{s->done_dev + 2, ++s->done_seq, s->done_counter + 2};
+    rc = enqueue_root(s, frames, sample_rate, s->out_host_dev, stereo, -1, &done);
     if (rc != S2R_OK) return rc;
     const size_t n = frames * (stereo ? 2 : 1);
-    S2R_HIP(s, hipStreamSynchronize(s->stream));
+    rc = wait_done(s, 2, done.value);
+    if (rc != S2R_OK) return rc;
     std::memcpy(out, s->out_host, n * sizeof(float));
     return S2R_OK;
 }
@@ -710,6 +760,8 @@ void release_all(s2r_synth *s) {
     if (s->block_partials) (void)hipFree(s->block_partials);
     if (s->out_dev) (void)hipFree(s->out_dev);
     if (s->out_host) (void)hipHostFree(s->out_host);
+    if (s->done_host) (void)hipHostFree(s->done_host);
+    if (s->done_counter) (void)hipFree(s->done_counter);
     for (int k = 0; k < 2; k++) {
         if (s->ring_host[k]) (void)hipHostFree(s->ring_host[k]);
         if (s->ring_done[k]) (void)hipEventDestroy(s->ring_done[k]);
@@ -720,6 +772,7 @@ void release_all(s2r_synth *s) {
     if (s->tev_copy) (void)hipFree(s->tev_copy);
     if (s->tab_dev) (void)hipFree(s->tab_dev);
     if (s->stamps_dev) (void)hipFree(s->stamps_dev);
+    if (s->timeline_dev) (void)hipFree(s->timeline_dev);
     if (s->bank_tab_dev) (void)hipFree(s->bank_tab_dev);
     if (s->t0) (void)hipEventDestroy(s->t0);
     if (s->t1) (void)hipEventDestroy(s->t1);
@@ -834,6 +887,11 @@ static int create_single(const s2r_config *cfg, std::shared_ptr<S2rVoicePool> po
         CREATE_HIP(hipHostGetDevicePointer((void **)&s->ring_dev[k], s->ring_host[k], 0));
         CREATE_HIP(hipEventCreateWithFlags(&s->ring_done[k], hipEventDisableTiming));
     }
+    CREATE_HIP(hipHostMalloc((void **)&s->done_host, 16 * sizeof(uint32_t), hipHostMallocMapped));
+    std::memset(s->done_host, 0, 16 * sizeof(uint32_t));
+    CREATE_HIP(hipHostGetDevicePointer((void **)&s->done_dev, s->done_host, 0));
+    CREATE_HIP(hipMalloc((void **)&s->done_counter, 4 * sizeof(uint32_t)));
+    CREATE_HIP(hipMemsetAsync(s->done_counter, 0, 4 * sizeof(uint32_t), s->stream));
     s->tev_capacity = shard_voices < 4096u ? 4096u : shard_voices;
     s->tlast.assign(shard_voices, -1);
     s->tfirst.assign(shard_voices, -1);
@@ -932,6 +990,11 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
         CREATE_HIP(hipHostGetDevicePointer((void **)&s->ring_dev[k], s->ring_host[k], 0));
         CREATE_HIP(hipEventCreateWithFlags(&s->ring_done[k], hipEventDisableTiming));
     }
+    CREATE_HIP(hipHostMalloc((void **)&s->done_host, 16 * sizeof(uint32_t), hipHostMallocMapped));
+    std::memset(s->done_host, 0, 16 * sizeof(uint32_t));
+    CREATE_HIP(hipHostGetDevicePointer((void **)&s->done_dev, s->done_host, 0));
+    CREATE_HIP(hipMalloc((void **)&s->done_counter, 4 * sizeof(uint32_t)));
+    CREATE_HIP(hipMemsetAsync(s->done_counter, 0, 4 * sizeof(uint32_t), s->stream));
     CREATE_HIP(hipStreamSynchronize(s->stream));
     // A shard on another device writes its row straight into the parent's buffer when the devices are peers (one
     // 4 KiB write over xGMI by its mix kernel: SURVEY 5's preferred shape); otherwise into a row of its own that a
@@ -1125,11 +1188,13 @@ int s2r_fill_begin(s2r_synth *s, size_t frames, uint32_t sample_rate_hz) {
     const uint32_t slot = (s->ring_head + s->ring_count) & 1u;
     if (frames) {
         // the last kernel of the fill writes the mix straight into this slot's mapped host buffer
-        rc = enqueue_root(s, frames, sample_rate_hz, s->ring_dev[slot], false, (int)slot);
+        const S2rDone done{s->done_dev + slot, ++s->done_seq, s->done_counter + slot};
+        rc = enqueue_root(s, frames, sample_rate_hz, s->ring_dev[slot], false, (int)slot, &done);
         if (rc != S2R_OK) return rc;
-    }
-    // (a deferred mix records the slot's event when it is launched: by the next fill_begin or by fill_end)
-    if (!(s->dmix.active && s->dmix.ring_slot == (int)slot)) S2R_HIP(s, hipEventRecord(s->ring_done[slot], s->stream));
+        s->ring_seq[slot] = done.value;
+    } else s->ring_seq[slot] = 0;
+    // (a fill is tracked by its completion word; an empty one by the event)
+    if (!frames) S2R_HIP(s, hipEventRecord(s->ring_done[slot], s->stream));
     s->ring_frames[slot] = frames;
     s->ring_count++;
     return S2R_OK;
@@ -1150,7 +1215,8 @@ int s2r_fill_end(s2r_synth *s, float *mono_out, size_t capacity) {
         int rc = launch_deferred_mix(s, s->stream);
         if (rc != S2R_OK) return rc;
     }
-    S2R_HIP(s, hipEventSynchronize(s->ring_done[slot]));
+    if (s->ring_seq[slot]) { int rc = wait_done(s, slot, s->ring_seq[slot]); if (rc != S2R_OK) return rc; }
+    else S2R_HIP(s, hipEventSynchronize(s->ring_done[slot]));
     if (s->ring_frames[slot]) std::memcpy(mono_out, s->ring_host[slot], s->ring_frames[slot] * sizeof(float));
     s->ring_head ^= 1u;
     s->ring_count--;
@@ -1218,7 +1284,7 @@ int s2r_fill_device_root(s2r_synth *s, float *dev_out, size_t frames, uint32_t s
 
 int s2r_sum_partials_device(const float *dev_rows, uint32_t n_rows, size_t frames, float *dev_out, void *hip_stream) {
     if (!dev_rows || !dev_out || n_rows == 0) return S2R_ERR_INVALID;
-    return s2r_launch_sum_rows(dev_rows, n_rows, (uint32_t)frames, (uint32_t)frames, 0, dev_out, (hipStream_t)hip_stream) == hipSuccess ? S2R_OK : S2R_ERR_HIP;
+    return s2r_launch_sum_rows(dev_rows, n_rows, (uint32_t)frames, (uint32_t)frames, 0, dev_out, (hipStream_t)hip_stream, nullptr) == hipSuccess ? S2R_OK : S2R_ERR_HIP;
 }
 
 int s2r_render_voices(s2r_synth *s, float *per_voice_out, size_t frames, uint32_t sample_rate_hz) {
@@ -1421,6 +1487,32 @@ extern "C" uint32_t s2r_debug_read_stamps(s2r_synth *s, unsigned long long *out,
     return n;
 #else
     (void)s; (void)out; (void)max_waves;
+    return 0;
+#endif
+}
+
+// Diagnostic builds only (tools/gpu_timeline.py): arm (`out` == nullptr: room for max_launches render and mix launches from
+// now on) or read back [n][2] = {first entry, last exit} in ticks of the GPU's 100 MHz clock, in launch order (a render
+// launch and the mix that follows it take consecutive slots); returns the number of launches recorded.
+extern "C" uint32_t s2r_debug_timeline(s2r_synth *s, unsigned long long *out, uint32_t max_launches) {
+#if defined(S2R_STAMPS)
+    if (!s) return 0;
+    if (hipSetDevice(s->device) != hipSuccess) return 0;
+    if (!out) {
+        if (s->timeline_dev) { (void)hipFree(s->timeline_dev); s->timeline_dev = nullptr; }
+        std::vector<unsigned long long> init((size_t)max_launches * 2);
+        for (uint32_t i = 0; i < max_launches; i++) { init[2 * i] = ~0ull; init[2 * i + 1] = 0ull; }
+        if (hipMalloc((void **)&s->timeline_dev, init.size() * sizeof(unsigned long long)) != hipSuccess) return 0;
+        (void)hipMemcpy(s->timeline_dev, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice);
+        s->timeline_n = 0; s->timeline_cap = max_launches;
+        return max_launches;
+    }
+    (void)hipStreamSynchronize(s->stream);
+    const uint32_t n = s->timeline_n < max_launches ? s->timeline_n : max_launches;
+    if (hipMemcpy(out, s->timeline_dev, (size_t)n * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
+#else
+    (void)s; (void)out; (void)max_launches;
     return 0;
 #endif
 }

@@ -604,6 +604,46 @@ __device__ __forceinline__ float frame_sisd(const P &p, VoiceRegs &r, uint32_t o
 }
 
 
+// The end of a fill's last kernel (S2rDone): every workgroup, once its part of the output has left for host memory,
+// counts itself in; the last one of `n_workgroups` resets the counter and stores the fill's sequence number where the
+// host is polling.  Called by every thread of the workgroup.  The output lives in mapped, coherent host memory
+// (hipHostMalloc's default): stores to it are not held in the L2, so a wave's `s_waitcnt vmcnt(0)` says they are on
+// (hipHostMalloc's default) and is stored at system scope (out_store): a wave's `s_waitcnt vmcnt(0)` then says those
+// stores are performed in host memory, and the flag store that follows the last such wait cannot overtake them — no
+// agent- or system-scope cache write-back (2-6 us with a fill's partial rows freshly dirtied in the L2) is needed.
+// diagnostic builds (-DS2R_STAMPS): a launch's first entry and last exit on the GPU's own 100 MHz clock (tools/gpu_timeline.py)
+__device__ __forceinline__ void tl_mark(unsigned long long *timeline, uint32_t slot, int which) {
+#if defined(S2R_STAMPS)
+    if (timeline && threadIdx.x == 0) {
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        if (which == 0) atomicMin(&timeline[2u * slot], t); else atomicMax(&timeline[2u * slot + 1u], t);
+    }
+#else
+    (void)timeline; (void)slot; (void)which;
+#endif
+}
+
+// ... so the output itself is stored at SYSTEM scope when a completion word follows it (global_store ... sc0 sc1: written
+// through to host memory, and acknowledged to the wave — vmcnt — only once performed there; a plain store to mapped
+// host memory may wait in the L2 until the kernel ends, which is later than the flag)
+__device__ __forceinline__ void out_store(const S2rDone &d, float *p, float v) {
+    if (d.flag != nullptr) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else *p = v;
+}
+
+__device__ __forceinline__ void signal_done(const S2rDone &d, uint32_t n_workgroups) {
+    if (d.flag == nullptr) return;                               // (uniform over the launch)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's output stores are acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t arrived = __hip_atomic_fetch_add(d.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived + 1u == n_workgroups) {
+            __hip_atomic_store(d.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(d.flag, d.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // minimum of a value over the wavefront, in a scalar register: four DPP row shifts, two row broadcasts (the classic
 // GFX9 reduction; ~35 cycles of issue for a lone wave where a ballot round trip costs ~50 and answers less)
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {

@@ -35,10 +35,16 @@ def main():
     for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
         rows = [r for r in csv.DictReader(open(f)) if want in r["Kernel_Name"]]
         if rows:
-            r = rows[-1]
+            rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+            # the resources of the kernel the TIMED steps run (bench.py's launch order below), not of whichever variant
+            # of the template happens to be first or last in the trace
+            w0 = SETUP + int(os.environ.get("S2R_PROF_WARMUP", "4"))
+            r = rows[min(w0, len(rows) - 1)]
             out["dispatch"] = {k: r[k] for k in ("Kernel_Name", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count",
                                                   "SGPR_Count", "Workgroup_Size_X", "Grid_Size_X") if k in r}
-            rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+            out["dispatch_per_kernel_name"] = {}
+            for q in rows:
+                out["dispatch_per_kernel_name"].setdefault(q["Kernel_Name"][:100], {k: q[k] for k in ("LDS_Block_Size", "Scratch_Size", "VGPR_Count", "SGPR_Count") if k in q})
             d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
             out["dispatch"]["avg_ns"] = sum(d) / len(d)
             out["dispatch"]["n"] = len(d)
@@ -61,7 +67,7 @@ def main():
     # where every group streams coefficients, are reported separately.
     w = SETUP + int(os.environ.get("S2R_PROF_WARMUP", "4")); k = int(os.environ.get("S2R_PROF_STEPS", "16"))
     counters = defaultdict(list)
-    for sub in ("pmc1", "pmc2", "pmc_fetch", "pmc_write"):
+    for sub in ("pmc1", "pmc2", "pmc3", "pmc4", "pmc_fetch", "pmc_write"):
         for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
             rows = [r for r in csv.DictReader(open(f)) if want in r.get("Kernel_Name", "")]
             rows.sort(key=lambda r: int(r["Dispatch_Id"]))
