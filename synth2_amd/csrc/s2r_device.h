@@ -136,7 +136,6 @@ struct S2rRenderParams {
     // ... and (tools/gpu_timeline.py) [launches][2] s_memrealtime of this launch's first entry and last exit, slot `tl_slot`
     unsigned long long *timeline;
     uint32_t tl_slot;
-    uint32_t dbg_split;         // diagnostic builds: 1 = the filter waves of the split kernel skip their arithmetic, 2 = the oscillator waves do
     // patch bank (bank_size > 1: s2r_render_general_kernel<ANY, true>; the fields above then hold patch 0)
     const S2rBankEntry *bank;
     uint32_t bank_size;

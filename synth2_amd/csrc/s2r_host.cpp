@@ -602,9 +602,6 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
     if (tables_wanted(s)) p.tab = s->tab;
     else if (bank_kernel) { p.tab = S2rTabRef{}; p.tab.base = s->bank_tab_dev; }      // the per-lane-patch kernel adds each entry's tab_off
     p.stamps = s->stamps_dev;
-#if defined(S2R_STAMPS)
-    { static const uint32_t dbg = [] { const char *e = std::getenv("S2R_DBG_SPLIT"); return e ? (uint32_t)std::atoi(e) : 0u; }(); p.dbg_split = dbg; }
-#endif
     if (s->timeline_dev && s->timeline_n < s->timeline_cap) { p.timeline = s->timeline_dev; p.tl_slot = s->timeline_n++; }
     p.per_voice = per_voice_dev;
     p.tev = tev_dev;

@@ -845,17 +845,12 @@ __device__ __forceinline__ f4 pk_add4(f4 a, f4 b) {
 //   AFLAT (with SMALL): every started voice of the wave sits in an amplitude stage of slope +-0 (sustain, end) for
 //   the whole run, so slope * (t - base) + y0 is (+-0) + y0 with the product's sign fixed by the slope's (t >= base
 //   inside a stage): one evaluation per chunk, at its first frame, is every frame's value bit for bit.
-//   SVR (the split kernel, s2r_render_onepole.inc): the filter's input (osc + gain) + noise of the chunk's 16 frames was
-//   computed by the voice's OSCILLATOR wave (osc_chunk below) and waits in LDS, sv_ring[frame * 64] for this lane: the
-//   phases, the oscillator and the noise are not evaluated here, r.phase is not touched.
-template <int OSC, int SRC, int FILT = 0, bool FMV = false, int NZ = 0, bool AFLAT = false, bool SVR = false>
+template <int OSC, int SRC, int FILT = 0, bool FMV = false, int NZ = 0, bool AFLAT = false>
 __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &r, const EnvRun &ea, const EnvRun &em,
                                            const FlatCache &fc, const OscK &k, uint32_t o_chunk, const float *tab,
                                            const uint64_t *sT, const float *sSin, bool live, uint32_t tile_m0,
-                                           float *pv_dst, const FiltCoef *fcoef = nullptr, Filt2 *f2 = nullptr,
-                                           const float *sv_ring = nullptr) {
+                                           float *pv_dst, const FiltCoef *fcoef = nullptr, Filt2 *f2 = nullptr) {
     constexpr bool SMALL = NZ >= 1, ALIGNED = NZ == 2;
-    static_assert(!SVR || !FMV, "the split kernel renders patches without oscillator FM");
     tile_set_base(tile_m0);
     // table planes: the filter's coefficients (x and 1 - x for the one-pole, alpha / beta / gamma for the others), then
     // under FM pow(2, mod * amt_osc).  Four 16-byte loads per plane (dword-aligned: the index follows the voice's
@@ -872,12 +867,7 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
             if (FMV) pq[q] = load_f4u(tab + p.tab.fm_plane * plane + 4 * q);
         }
     }
-    f4 svq[4];
-    if (SVR) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { svq[q].x = sv_ring[(4 * q) * 64]; svq[q].y = sv_ring[(4 * q + 1) * 64]; svq[q].z = sv_ring[(4 * q + 2) * 64]; svq[q].w = sv_ring[(4 * q + 3) * 64]; }
-    }
-    const double rcp_period = (OSC == S2R_OSC_SINE && !FMV && !SVR) ? s2r_rcp_f64(k.period) : 0.0;   // constant over the run: hoisted by the compiler
+    const double rcp_period = (OSC == S2R_OSC_SINE && !FMV) ? s2r_rcp_f64(k.period) : 0.0;   // constant over the run: hoisted by the compiler
     // a lane without a started voice: see a0 / ampq below.  Its filter history must be 0 for that (frames
     // of the general path, which selects per frame instead, leave a running value in it)
     // — and its amplitude line is 0 * (t - 0) + 0 = +0 and, where the coefficient is the run's constant, x = 1
@@ -900,12 +890,7 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         f4 t;
-        if (SVR) {
-            // (the noise went into sv on the oscillator side; only the frame offsets are needed here, for the amplitude line)
-            if (SMALL) { t = t_small; t_small = t_small + splat(4.0f); }
-            else { const u4 ou = (u4)(o_chunk + 4u * q) + (u4){0u, 1u, 2u, 3u}; t = __builtin_convertvector(ou, f4); }
-            nz[q] = splat(0.0f);
-        } else if (ALIGNED) {
+        if (ALIGNED) {
             t = t_small;
             t_small = t_small + splat(4.0f);
             // f_j = h_j * 2^-16 for the quad's four frames, stepped from the previous pair: h_(j+2) = h_j + 2 * 0x79b9
@@ -965,9 +950,6 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
         if (SRC == 2 && !live) a0 = splat(0.0f);                 // SRC 1: such a lane reads the tables' x = 1, 1 - x = 0 entries
         // the quad's oscillator constants: the run's (k), or under FM each frame's period and 1 / period (from the
         // tables' pow2 plane) with the rest by exact scalings (make_osck)
-        f4 sv;
-        if (SVR) sv = svq[q];
-        else {
         const f4 period = FMV ? pq[q] : splat(k.period), inv_period = FMV ? iq[q] : splat(k.inv_period);
         f4 ph;
         float phc = r.phase;
@@ -1000,8 +982,7 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
         } else {
             osc = sine_quad<FMV>(x, period, rcp_period, sSin);
         }
-        sv = pk_add4(osc + splat(p.osc_gain), nz[q]);            // process.rs:342-345 (ADD), :358
-        }
+        const f4 sv = pk_add4(osc + splat(p.osc_gain), nz[q]);   // process.rs:342-345 (ADD), :358
         f4 y;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1025,104 +1006,6 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
 #pragma unroll
         for (int q = 0; q < 4; ++q) *reinterpret_cast<f4u *>(pv_dst + 4 * q) = outs[q];
     }
-}
-
-
-// ---------------------------------------------------------------------------------------
-// The OSCILLATOR side of the split kernel (s2r_render_onepole.inc): one 16-frame chunk of the filter's input,
-//   sv[i] = (osc[i] + osc.gain) + (noise(o + i) + noise level)        process.rs:342-358 (both ADDs of the x16 path)
-// with the phase accumulation of oscillators.rs:391-400 — operation for operation the first half of chunk_fast, without
-// anything that depends on an envelope — stored for the voice's FILTER wave at ring[frame * 64 + lane] by address-free
-// stores (M0 = the slot's LDS byte address).  Preconditions as chunk_fast's: period > 0 finite, 0 <= phase < 1, no
-// oscillator FM; NZ as there (0: any offsets and noise level; 1: offsets below 2^24 and a noise level of +0.0;
-// 2: on top of that chunk starts on multiples of 16 and rotl(seed, 5) with a zero low nibble).
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void ring_store4(int q, f4 v) {
-#define S2R_RST4(Q)                                                                                             \
-    asm volatile("ds_write_addtid_b32 %0 offset:%c4\n\tds_write_addtid_b32 %1 offset:%c5\n\t"                     \
-                 "ds_write_addtid_b32 %2 offset:%c6\n\tds_write_addtid_b32 %3 offset:%c7"                          \
-                 : : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "n"((4 * Q) * 256), "n"((4 * Q + 1) * 256),         \
-                     "n"((4 * Q + 2) * 256), "n"((4 * Q + 3) * 256) : "memory")
-    switch (q) { case 0: S2R_RST4(0); break; case 1: S2R_RST4(1); break; case 2: S2R_RST4(2); break; default: S2R_RST4(3); break; }
-#undef S2R_RST4
-}
-
-template <int OSC, int NZ>
-__device__ __forceinline__ void osc_chunk(const S2rRenderParams &p, float &phase, uint32_t seed_rot, const OscK &k, uint32_t o_chunk,
-                                          const float *sSin, uint32_t slot_m0) {
-    constexpr bool SMALL = NZ >= 1, ALIGNED = NZ == 2;
-    tile_set_base(slot_m0);
-    const double rcp_period = (OSC == S2R_OSC_SINE) ? s2r_rcp_f64(k.period) : 0.0;
-    f4 nz[4];
-    const float t_chunk = (float)o_chunk;
-    const uint32_t o_lo = o_chunk & 0xffffu;
-    uint32_t o01 = pk_add_u16(o_lo | (o_lo << 16), 0x00010000u), o23 = pk_add_u16(o01, 0x00020002u);
-    const uint32_t seed_pair = (seed_rot & 0xffffu) | (seed_rot << 16);
-    (void)t_chunk;
-    const float h0f = (float)(((seed_rot ^ o_chunk) * 0x79b9u) & 0xffffu) * 0x1p-16f;
-    constexpr float kK1 = (float)0x79b9u * 0x1p-16f, kK2 = (float)((2u * 0x79b9u) & 0xffffu) * 0x1p-16f;
-    fp2 fpair = {h0f, __builtin_amdgcn_fractf(h0f + kK1)};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (ALIGNED) {
-            f4 f;
-            f.x = fpair.x; f.y = fpair.y;
-            fpair = fpair + (fp2){kK2, kK2};
-            fpair.x = __builtin_amdgcn_fractf(fpair.x); fpair.y = __builtin_amdgcn_fractf(fpair.y);
-            f.z = fpair.x; f.w = fpair.y;
-            fpair = fpair + (fp2){kK2, kK2};
-            fpair.x = __builtin_amdgcn_fractf(fpair.x); fpair.y = __builtin_amdgcn_fractf(fpair.y);
-            nz[q] = vfma(vfma(f, splat(0x1.0001p-16f), f), splat(2.0f), splat(-1.0f));
-        } else if (SMALL) {
-            nz[q] = hash_noise4_low16(seed_pair, o01, o23);
-            o01 = pk_add_u16(o01, 0x00040004u); o23 = pk_add_u16(o23, 0x00040004u);
-        } else {
-            const u4 ou = (u4)(o_chunk + 4u * q) + (u4){0u, 1u, 2u, 3u};
-            const f4 t = __builtin_convertvector(ou, f4);
-            nz[q] = hash_noise4(seed_rot, t) + splat(p.noise_level);
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f4 period = splat(k.period), inv_period = splat(k.inv_period);
-        f4 ph;
-        float phc = phase;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            ph[j] = phc;
-            phc = __builtin_amdgcn_fractf(phc + inv_period[j]);          // oscillators.rs:377-381 (see chunk_fast)
-        }
-        phase = phc;
-        const f4 x = period * ph;                                // == fmodf(fma(period, ph, +0), period), see chunk_fast
-        f4 osc;
-        if (OSC == S2R_OSC_SAW) {
-            osc = vfma(splat(k.a), x, splat(1.0f));              // oscillators.rs:107-112
-        } else if (OSC == S2R_OSC_SQUARE) {
-            const u4 d = (u4)(x - splat(k.a));
-            osc = -(f4)((d & 0x80000000u) | 0x3f800000u);        // oscillators.rs:68-76, by the sign of x - half
-        } else if (OSC == S2R_OSC_TRIANGLE) {
-            const f4 ka = splat(k.a);
-            const f4 first = vfma(splat(k.b), x, splat(1.0f)), second = vfma(splat(k.c), x - ka, splat(-1.0f));     // oscillators.rs:156-172
-            const u4 lt = (u4)((i4)(u4)(x - ka) >> 31);
-            osc = (f4)(((u4)first & lt) | ((u4)second & ~lt));
-        } else {
-            osc = sine_quad<false>(x, period, rcp_period, sSin);
-        }
-        ring_store4(q, pk_add4(osc + splat(p.osc_gain), nz[q])); // process.rs:342-345 (ADD), :358
-    }
-}
-
-// One frame of the same on the general path (any phase, any period: the exact fmodf where it is needed), for the waves
-// whose voices do not meet osc_chunk's preconditions
-template <int OSC>
-__device__ __forceinline__ float osc_frame(const S2rRenderParams &p, float &phase, uint32_t seed_rot, const OscK &k, uint32_t o,
-                                           const float *sSin) {
-    const float ph = phase;                                      // oscillators.rs:391-400
-    phase = s2r_fmod1(ph + k.inv_period);
-    const float off = __builtin_fmaf(k.period, ph, 0.0f);        // phased_offset_x16, :235
-    const float osc = osc_value<OSC>(k, off, sSin);
-    const float nzv = hash_noise(seed_rot, (float)o) + p.noise_level;    // process.rs:347-356 (ADD)
-    return (osc + p.osc_gain) + nzv;                             // process.rs:342-345 (ADD), :358
 }
 
 }  // namespace

@@ -72,10 +72,5 @@ for rep in range(3):
     if ev_w.size:
         nb = [w for w in ev_w if w + 1 < waves and t[w + 1, 11] == 0][:6]
         print("   event wave vs its neighbour without events: " + "  ".join("w%d(ev %d dense %d runs %d) work %d vs %d (runs %d) |" % (w, t[w, 11], t[w, 12], t[w, 14], work[w], work[w + 1], t[w + 1, 14]) for w in nb))
-    if np.any(st[:, 4]):                                        # split kernel: the oscillator waves (slots 4..6) and the filter waves' waits (7)
-        o_span = (st[:, 5] - st[:, 4]).astype(np.int64); o_wait = st[:, 6].astype(np.int64); f_wait = st[:, 7].astype(np.int64)
-        print("   split kernel: oscillator wave span median %d max %d cycles, of which waiting for ring space median %d max %d; filter waves waiting for a chunk median %d max %d" % (
-            int(np.median(o_span)), int(o_span.max()), int(np.median(o_wait)), int(o_wait.max()), int(np.median(f_wait)), int(f_wait.max())))
-        print("   oscillator waves start %d cycles (median) after their filter waves' entry" % int(np.median(st[:, 4].astype(np.int64) - t[:, 0])))
     for n, c in zip(names, cols):
         print("   %-12s median %7d   p99 %7d   max %7d   | last-exiting wave %d: %7d" % (n, int(np.median(c)), int(np.percentile(c, 99)), int(c.max()), slow, int(c[slow])))
