@@ -349,6 +349,8 @@ def main():
     ap.add_argument("--block-voices", type=int, default=0)
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap the all-gather with the next render")
     ap.add_argument("--reduce", action="store_true", help="N > 1: combine the partial mixes with one reduce(sum) to rank 0 instead of all-gather + rank-ordered sum")
+    ap.add_argument("--device-list", default="", help="ONE process over these devices (comma-separated ordinals, e.g. 0,1,2,3 or 0,0 on a one-GPU box): "
+                    "the C ABI's device-list handle instead of one process per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the SVF and 4x-oversampled configurations timed after the headline")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="seconds per CPU-baseline leg (three legs)")
@@ -397,8 +399,13 @@ def main():
         vpg = args.voices_per_gpu
     total = vpg * world
     from synth2_amd.sharded import ShardedSynth
+    dev_list = [int(x) for x in args.device_list.split(",")] if args.device_list else None
+    if dev_list:
+        if world != 1:
+            sys.exit("--device-list is the one-process form: do not launch it under torch.distributed.run")
+        total = vpg * len(dev_list)
     sh = ShardedSynth(vpg, max_frames=FRAMES, rank=rank, world=world, device=dev, block_voices=args.block_voices,
-                      overlap=not args.no_overlap, reduce_to_root=args.reduce)
+                      overlap=not args.no_overlap, reduce_to_root=args.reduce, devices=dev_list)
     synth = sh.renderer
     block_voices = synth.block_voices
     sh.load_patch("synth mySynth {\n\n}\n")       # example.synth2: empty body == default patch
@@ -599,7 +606,7 @@ def main():
             "metric": "voice-samples/sec (mono) at 64k voices per GPU, 48 kHz, 1024-frame buffers",
             "value": value,
             "unit": "samples/s",
-            "n_gpus": world,
+            "n_gpus": len(set(dev_list)) if dev_list else world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt_max * 1e3 / args.steps,
@@ -618,7 +625,8 @@ def main():
                        "timed_call": "s2r_note_events + s2r_fill_begin / s2r_fill_end: the host-buffer API with two buffers in flight (s2_bin's own arrangement); voice state resident in HBM, events H2D and every mix's D2H into the caller's buffer inside the timed region" if world == 1 else
                                      "s2r_note_events + s2r_fill_device per rank, all-gather, rank-ordered sum, async D2H of the mix on rank 0",
                        "voices_total": total, "frames": FRAMES, "sample_rate": SR,
-                       "parallelism": "voice-shard x%d, %s of partial mixes" % (world, "reduce(sum) to rank 0" if args.reduce else "all-gather + rank-ordered sum"),
+                       "parallelism": ("one process, one handle over the device list %s: policy run once, every shard on its own device's stream, rows added in shard order on the first device" % dev_list) if dev_list else
+                                      "voice-shard x%d, %s of partial mixes" % (world, "reduce(sum) to rank 0" if args.reduce else "all-gather + rank-ordered sum"),
                        "block_voices": block_voices},
             "msamples_per_s": value / 1e6,
             "realtime_factor_64k_voices": value / (65536.0 * SR),

@@ -117,7 +117,8 @@ typedef struct {
      * renders the pool on devices[0..N) — the pool is cut into N shards (contiguous ranges when shard_interleave is
      * 0, else dealt out in runs of shard_interleave voices), shard k lives on devices[k] (an ordinal may repeat), the
      * allocation policy of synth.rs:61-120 runs ONCE per event on the calling thread and the event is routed to the
-     * shard that holds the chosen voice; every fill each shard leaves its partial mix in row k of a buffer on
+     * shard that holds the chosen voice (the shards' kernels are launched by the calling thread too, shard after
+     * shard, each on its device's stream); every fill each shard leaves its partial mix in row k of a buffer on
      * devices[0] (a peer-to-peer write over xGMI, 4 KiB) and devices[0] adds the rows in shard order rooted at +0.0
      * (synth.rs:176,195) — with contiguous shards the very association one device produces with mix_groups = N.
      * shard_begin / shard_voices / shard_index / shard_count must be 0 (or shard_count 1) then; total_voices must be

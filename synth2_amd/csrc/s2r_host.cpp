@@ -10,13 +10,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
-#include <condition_variable>
-#include <functional>
 #include <memory>
-#include <mutex>
 #include <new>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "s2r.h"
@@ -115,6 +111,7 @@ struct s2r_synth {
     int device = 0;
     uint32_t shard_begin = 0, shard_voices = 0, padded_voices = 0, block_voices = 256, n_blocks = 0, mix_groups = 1;
     uint32_t interleave = 0, shard_index = 0, shard_count = 1;   // round-robin sharding (s2r_config.shard_interleave)
+    FastDiv div_interleave, div_count, div_per_kid;              // ... and its divisions (interleave, shard count, voices per contiguous shard)
     std::vector<s2r_patch> bank;                 // bank[0] is "the" patch of the reference's Synth
     uint32_t program = 0;                        // current program: the patch the next note_on gives its voice
     S2rBankEntry *bank_dev = nullptr;            // S2R_MAX_BANK entries, resolved for bank_rate
@@ -130,8 +127,6 @@ struct s2r_synth {
     std::vector<float *> kid_stage;              // per kid: a row on ITS device when it cannot write the parent's rows directly
     std::vector<hipEvent_t> kid_done[2];         // per slot, per kid: its partial row is in rows_dev[slot]
     uint32_t rows_slot = 0;
-    struct Workers;
-    Workers *workers = nullptr;                  // one host thread per further shard: the shards' launches run side by side
     std::vector<uint32_t> seed_override;         // per pool voice; 0 = reference behaviour
     // event folding (one record per touched shard voice between two fills)
     std::vector<S2rVoiceEvent> pending;
@@ -187,61 +182,7 @@ struct s2r_synth {
 };
 
 
-// The shards of a device-list handle are launched side by side: shard 0 by the calling thread, every further shard by a
-// host thread of its own that lives as long as the handle.  A thread spins briefly for its next job (fills follow each
-// other within microseconds in a render loop) before it blocks.
-struct s2r_synth::Workers {
-    struct Slot {
-        std::thread th;
-        std::mutex mu; std::condition_variable cv;
-        std::function<int()> job;
-        std::atomic<int> state{0};      // 0 idle, 1 job posted, 2 done, 3 quit
-        int rc = 0;
-    };
-    std::vector<std::unique_ptr<Slot>> slots;
-    explicit Workers(uint32_t n) {
-        for (uint32_t i = 0; i < n; i++) {
-            slots.emplace_back(new Slot());
-            Slot *sl = slots.back().get();
-            sl->th = std::thread([sl]() {
-                for (;;) {
-                    int st = 0;
-                    for (int spin = 0; spin < 20000 && (st = sl->state.load(std::memory_order_acquire)) != 1 && st != 3; spin++) __builtin_ia32_pause();
-                    if (st != 1 && st != 3) {
-                        std::unique_lock<std::mutex> lk(sl->mu);
-                        sl->cv.wait(lk, [&] { st = sl->state.load(std::memory_order_acquire); return st == 1 || st == 3; });
-                    }
-                    if (st == 3) return;
-                    sl->rc = sl->job();
-                    sl->state.store(2, std::memory_order_release);
-                }
-            });
-        }
-    }
-    void post(uint32_t i, std::function<int()> job) {
-        Slot *sl = slots[i].get();
-        sl->job = std::move(job);
-        { std::lock_guard<std::mutex> lk(sl->mu); sl->state.store(1, std::memory_order_release); }
-        sl->cv.notify_one();
-    }
-    int wait(uint32_t i) {
-        Slot *sl = slots[i].get();
-        while (sl->state.load(std::memory_order_acquire) != 2) __builtin_ia32_pause();
-        sl->state.store(0, std::memory_order_release);
-        return sl->rc;
-    }
-    ~Workers() {
-        for (auto &sl : slots) {
-            { std::lock_guard<std::mutex> lk(sl->mu); sl->state.store(3, std::memory_order_release); }
-            sl->cv.notify_one();
-            sl->th.join();
-        }
-    }
-};
-
 namespace {
-
-s2r_synth::Workers *new_workers(uint32_t n) { return n ? new (std::nothrow) s2r_synth::Workers(n) : nullptr; }
 
 int set_err(s2r_synth *s, int code, const char *fmt, ...) {
     if (s) {
@@ -264,21 +205,22 @@ inline int64_t to_local(const s2r_synth *s, uint32_t pool_index) {
         if (pool_index < s->shard_begin || pool_index >= s->shard_begin + s->shard_voices) return -1;
         return (int64_t)(pool_index - s->shard_begin);
     }
-    const uint32_t run = pool_index / s->interleave;
-    if (run % s->shard_count != s->shard_index) return -1;
-    return (int64_t)((run / s->shard_count) * s->interleave + pool_index % s->interleave);
+    const uint32_t run = s->div_interleave.div(pool_index), within = pool_index - run * s->interleave;
+    const uint32_t lrun = s->div_count.div(run);
+    if (run - lrun * s->shard_count != s->shard_index) return -1;
+    return (int64_t)(lrun * s->interleave + within);
 }
 inline uint32_t to_pool(const s2r_synth *s, uint32_t local) {
     if (s->interleave == 0) return s->shard_begin + local;
-    return ((local / s->interleave) * s->shard_count + s->shard_index) * s->interleave + local % s->interleave;
+    const uint32_t lrun = s->div_interleave.div(local);
+    return (lrun * s->shard_count + s->shard_index) * s->interleave + (local - lrun * s->interleave);
 }
 
 // the handle that renders pool voice `pool_index` — this one, or for a device-list handle the shard that holds it — and
 // the voice's index there; nullptr when another process' handle renders it
 inline s2r_synth *shard_of(s2r_synth *s, uint32_t pool_index, uint32_t *local) {
     if (!s->kids.empty()) {
-        const uint32_t n = (uint32_t)s->kids.size();
-        const uint32_t k = s->interleave ? (pool_index / s->interleave) % n : pool_index / (s->shard_voices / n);
+        const uint32_t k = s->interleave ? s->div_count.mod(s->div_interleave.div(pool_index)) : s->div_per_kid.div(pool_index);
         s = s->kids[k];
     }
     const int64_t mine = to_local(s, pool_index);
@@ -650,8 +592,7 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
 }
 
 
-// A device-list handle's fill: every shard renders on its own device and stream (shard 0 launched by this thread, the
-// others by their threads) and leaves its partial mix in row k of rows_dev[slot] on the parent's device; the parent's
+// A device-list handle's fill: every shard renders on its own device and stream and leaves its partial mix in row k of rows_dev[slot] on the parent's device; the parent's
 // stream waits for the rows and adds them in shard order rooted at +0.0 (synth.rs:176,195) into `dev_out`.
 int enqueue_multi(s2r_synth *s, size_t frames, uint32_t sample_rate, float *dev_out, bool stereo, float *per_voice_host = nullptr,
                   const S2rDone *done = nullptr) {
@@ -674,19 +615,21 @@ int enqueue_multi(s2r_synth *s, size_t frames, uint32_t sample_rate, float *dev_
         }
         float *row = s->rows_dev[slot] + (size_t)k * s->cfg.max_frames;
         float *dst = s->kid_stage[k] ? s->kid_stage[k] : row;
-        int rc = enqueue_fill(kid, frames, sample_rate, kid->stream, dst, false, false, nullptr);
+        // (the shard's own completion word: its event slots are then tracked without an event record per fill)
+        const S2rDone kd{kid->done_dev + slot, ++kid->done_seq, kid->done_counter + slot};
+        int rc = enqueue_fill(kid, frames, sample_rate, kid->stream, dst, false, false, nullptr, -1, &kd);
         if (rc != S2R_OK) return rc;
         if (s->kid_stage[k]) S2R_HIP(kid, hipMemcpyPeerAsync(row, s->device, dst, kid->device, frames * sizeof(float), kid->stream));
         S2R_HIP(kid, hipEventRecord(s->kid_done[slot][k], kid->stream));
         return S2R_OK;
     };
-    for (uint32_t k = 1; k < n; k++) s->workers->post(k - 1u, [shard_job, k]() { return shard_job(k); });
-    int rc = shard_job(0);
-    for (uint32_t k = 1; k < n; k++) {
-        const int rk = s->workers->wait(k - 1u);
-        if (rk != S2R_OK && rc == S2R_OK) { rc = rk; s->err = "shard " + std::to_string(k) + ": " + s->kids[k]->err; }
-    }
-    if (rc != S2R_OK) { if (s->err.empty()) s->err = "shard 0: " + s->kids[0]->err; return rc; }
+    // The shards are launched by the calling thread, one after the other.  (One host thread per shard was built and
+    // measured: HIP serialises the launches of a process — fill_begin 32 / 50 / 80 us on threads against 40 / 76 / 130 us
+    // in sequence at 2 / 4 / 8 shards — while the threads cost the caller's own event processing more than that:
+    // tools/devlist_host_cost.py.)
+    int rc = S2R_OK;
+    for (uint32_t k = 0; k < n && rc == S2R_OK; k++) { rc = shard_job(k); if (rc != S2R_OK) s->err = "shard " + std::to_string(k) + ": " + s->kids[k]->err; }
+    if (rc != S2R_OK) return rc;
     s->pool->advance(frames - s->fill_time);      // the shared clock, once
     s->fill_time = 0;
     if (per_voice_host) return S2R_OK;
@@ -738,7 +681,6 @@ int fill_host(s2r_synth *s, float *out, size_t frames, uint32_t sample_rate, boo
 
 void release_all(s2r_synth *s) {
     if (!s) return;
-    delete s->workers; s->workers = nullptr;        // (joins the shard threads before their handles go)
     for (s2r_synth *kid : s->kids) release_all(kid);
     s->kids.clear();
     (void)hipSetDevice(s->device);
@@ -835,6 +777,7 @@ static int create_single(const s2r_config *cfg, std::shared_ptr<S2rVoicePool> po
     s->shard_begin = cfg->shard_interleave ? 0u : cfg->shard_begin;
     s->interleave = cfg->shard_interleave; s->shard_index = cfg->shard_index; s->shard_count = cfg->shard_interleave ? cfg->shard_count : 1u;
     s->shard_voices = shard_voices;
+    s->div_interleave.set(s->interleave); s->div_count.set(s->shard_count);
     s->block_voices = bv;
     s->n_blocks = (shard_voices + bv - 1) / bv;
     s->padded_voices = s->n_blocks * bv;
@@ -951,6 +894,7 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
     s->shard_voices = cfg->total_voices;
     s->block_voices = bv;
     s->interleave = cfg->shard_interleave; s->shard_count = n;
+    s->div_interleave.set(s->interleave); s->div_count.set(n); s->div_per_kid.set(cfg->total_voices / n);
     s->bank.resize(1);
     s2r_default_patch(&s->bank[0]);
     s->pool.reset(new S2rVoicePool(cfg->total_voices));
@@ -1015,7 +959,6 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
         if (!direct) CREATE_HIP(hipMalloc((void **)&s->kid_stage[k], (size_t)cfg->max_frames * sizeof(float)));
     }
 #undef CREATE_HIP
-    s->workers = new_workers(n - 1u);
     *out = s;
     return S2R_OK;
 }

@@ -753,6 +753,9 @@ __device__ __forceinline__ void apply_arg_events(const S2rRenderArgs &a, uint32_
 // the store of every voice-frame is a sixth of the chunk otherwise.  tile_set_base() puts the tile's LDS byte address
 // (wave-uniform) into M0 once per chunk; nothing the compiler generates for these kernels touches M0 in between
 // (tests/test_abi_c.py::test_m0_is_ours_between_the_tile_stores checks the disassembly).
+// (No "m0" in the clobber list, deliberately: declaring it makes the compiler save and restore M0 around every one of these
+// statements; that nothing else in the kernels reads or writes M0 between the set and the stores is what
+// tests/test_isa_contracts.py asserts on the shipped ISA instead.)
 __device__ __forceinline__ void tile_set_base(uint32_t tile_m0) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(tile_m0) : "memory");
 }

@@ -21,6 +21,22 @@
 #include <utility>
 #include <vector>
 
+// x / d and x % d for a divisor fixed at create (shard geometry): every note event of a sharded handle is mapped from its
+// pool index to (shard, local voice), and a hardware division per step of that map is what the event path cannot afford
+// (2 048 events per buffer, six divisions each: tens of microseconds).  Round-up multiply-shift (Granlund-Montgomery):
+// exact for every 32-bit x.
+struct FastDiv {
+    uint32_t d = 1, mul = 0, sh1 = 0, sh2 = 0;
+    void set(uint32_t div) {
+        d = div ? div : 1u;
+        uint32_t l = 0; while ((1ull << l) < d) l++;
+        mul = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1ull);
+        sh1 = l ? 1u : 0u; sh2 = l ? l - 1u : 0u;
+    }
+    inline uint32_t div(uint32_t x) const { const uint32_t t = (uint32_t)(((uint64_t)mul * x) >> 32); return (t + ((x - t) >> sh1)) >> sh2; }
+    inline uint32_t mod(uint32_t x) const { return x - div(x) * d; }
+};
+
 struct S2rHostVoice {
     uint8_t note = 0;
     bool started = false;

@@ -20,6 +20,11 @@ The renderer and the row-combine are injectable so the exchange logic can be exe
 with gloo (tests/test_sharded_gloo.py feeds it partial rows made by the CPU oracle); the
 defaults are the HIP path and nothing else — there is no CPU fallback here.
 
+``devices=[d0, d1, ...]`` (one process, several GPUs) hands the whole job to ONE libs2r handle over a device list
+(s2r_config.devices: the allocation policy run once per event, every shard launched on its own device's stream, the rows
+written peer-to-peer into d0's buffer and added there in shard order) — no torch.distributed at all; this class is then a
+thin wrapper around it.
+
 Of the RCCL path what a one-GPU box can run has run: ONE rank through ``backend="nccl"`` (``force_exchange``:
 tests/test_gpu_parity.py::test_sharded_exchange_through_rccl_with_one_rank — all-gather with and without overlap, and the
 reduce, bit-identical to the plain path) and N ranks under gloo; the first N-GPU execution is the driver's bench.
@@ -32,7 +37,22 @@ from . import synth as _synth
 
 class ShardedSynth:
     def __init__(self, voices_per_rank, max_frames=1024, rank=0, world=1, device=None, renderer=None,
-                 combine=None, block_voices=0, overlap=True, interleave=64, reduce_to_root=False, force_exchange=False):
+                 combine=None, block_voices=0, overlap=True, interleave=64, reduce_to_root=False, force_exchange=False, devices=None):
+        self.devices = list(devices) if devices else None
+        if self.devices:
+            # one process over a device list: everything happens inside the C ABI (s2r_config.devices)
+            assert world == 1 and renderer is None
+            n = len(self.devices)
+            self.rank, self.world = 0, 1
+            self.voices_per_rank = voices_per_rank
+            self.total_voices = voices_per_rank * n
+            self.max_frames = max_frames
+            self.device = torch.device("cuda", self.devices[0])
+            self.renderer = _synth.Synth(self.total_voices, max_frames=max_frames, block_voices=block_voices,
+                                         shard_interleave=interleave if n > 1 else 0, devices=self.devices)
+            self._host_target = None
+            self._out = None
+            return
         self.rank, self.world = rank, world
         self.voices_per_rank = voices_per_rank
         self.total_voices = voices_per_rank * world
@@ -107,6 +127,14 @@ class ShardedSynth:
     def fill(self, frames, sample_rate=48000):
         """Render one buffer.  With overlap on, the exchange of buffer k runs on the collective's own
         stream while buffer k+1 renders; call flush() before reading ``mix``."""
+        if self.devices:
+            import numpy as np
+            if self._out is None or self._out.size != frames:
+                self._out = np.empty(frames, dtype=np.float32)
+            self.renderer.sample(self._out, sample_rate)
+            if self._host_target is not None:
+                self._host_target[:frames].copy_(torch.from_numpy(self._out))
+            return
         slot = self._k & 1
         self._k += 1
         part = self.partial[slot]
@@ -148,6 +176,8 @@ class ShardedSynth:
             self._finish(pending)
 
     def flush(self):
+        if self.devices:
+            return
         if self._pending is not None:
             self._finish(self._pending)
             self._pending = None

@@ -23,6 +23,15 @@ int main() {
             (void)pool.next_voice();
         }
     }
+    // the shard maps' division (FastDiv): exact for every divisor kind and the whole 32-bit range
+    for (uint32_t d : {1u, 2u, 3u, 7u, 8u, 61u, 64u, 100u, 255u, 256u, 1000u, 65536u, 131072u, 1048576u, 3000000001u, 0xffffffffu}) {
+        FastDiv f; f.set(d);
+        for (uint64_t x = 0; x <= 0xffffffffull; x += (x < 70000 ? 1 : 65521 + rng() % 4096)) {
+            if (f.div((uint32_t)x) != (uint32_t)x / d || f.mod((uint32_t)x) != (uint32_t)x % d) { printf("FastDiv wrong: %u / %u\n", (uint32_t)x, d); return 3; }
+        }
+        for (uint32_t x : {0xffffffffu, 0xfffffffeu, 0x80000000u, 0x7fffffffu})
+            if (f.div(x) != x / d) { printf("FastDiv wrong: %u / %u\n", x, d); return 3; }
+    }
     const std::string base = "synth lead { osc.kind = sine; osc.gain = 0.25 noise = 0.125, lpf.freq = 1234.5 // c\n lpf.kind = bp2; lpf.q = 2 # x\n amp_env.attack = 1 }";
     int ok = 0, bad = 0;
     for (int k = 0; k < 60000; k++) {

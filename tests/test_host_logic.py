@@ -219,3 +219,30 @@ def test_u16_over_65535_two_operation_quotient():
     # and the noise value built from it is never a zero, which is what lets a 0.0 noise level skip its add
     n = (got.astype(np.float64) * 2.0 - 1.0).astype(np.float32)
     assert not np.any(n == 0.0)
+
+
+def test_rust_shim_and_integration_excerpt_follow_the_header():
+    """the (uncompilable here) Rust shim declares only entry points the header has, with the header's ABI version, and the
+    excerpt INTEGRATION.md prints is made of lines of that file"""
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "s2r.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(s2r_[a-z0-9_]+)\s*\(", hdr))
+    rs = open(os.path.join(ROOT, "rust", "s2_lib_gpu", "src", "lib.rs")).read()
+    used = set(re.findall(r"pub fn (s2r_[a-z0-9_]+)\(", rs))
+    assert used and used <= declared, sorted(used - declared)
+    assert {"s2r_fill_begin", "s2r_fill_end", "s2r_set_patch_bank", "s2r_fill_stereo", "s2r_fill_oversampled", "s2r_abi_version"} <= used
+    ver = int(re.search(r"#define S2R_ABI_VERSION (\d+)", hdr).group(1))
+    assert "pub const S2R_ABI_VERSION: u32 = %d;" % ver in rs
+    # struct layouts: the field lists of s2r_config, in order
+    cfg_c = hdr[:hdr.index("} s2r_config;")]
+    cfg_c = cfg_c[cfg_c.rindex("typedef struct {"):]
+    fields_c = re.findall(r"\b(?:uint32_t|int32_t)\s+([a-z0-9_]+)(?:\[[A-Z_0-9]+\])?;", cfg_c)
+    cfg_rs = re.search(r"pub struct S2rConfig \{(.*?)\}", rs, re.S).group(1)
+    fields_rs = re.findall(r"pub ([a-z0-9_]+):", cfg_rs)
+    assert fields_c == fields_rs, (fields_c, fields_rs)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    excerpt = re.search(r"```rust\n(.*?)```", doc, re.S).group(1)
+    rs_lines = {l.strip() for l in rs.splitlines()}
+    for line in excerpt.splitlines():
+        line = line.strip()
+        if line.startswith("pub fn "):
+            assert line in rs_lines, "INTEGRATION.md prints a line that is not in lib.rs: " + line

@@ -81,6 +81,19 @@ def main():
     out["pmc_avg_per_dispatch"] = {n: mean(v[w:w + k]) for n, v in sorted(counters.items())}
     out["pmc_avg_first_launches"] = {n: mean(v[:8]) for n, v in sorted(counters.items())}
     out["pmc_dispatches"] = {n: len(v) for n, v in sorted(counters.items())}
+    pm = out["pmc_avg_per_dispatch"]
+    if pm.get("SQ_INSTS_VALU_FLOPS_FP32") is not None:
+        # SQ_INSTS_VALU_FLOPS_FP32 counts flops per LANE per wave-instruction (add / mul 1, fma 2, a packed instruction its two
+        # halves): checked against the per-type counters of the same launches — ADD + MUL + 2 FMA is its value without the
+        # packed instructions' second halves.  x 64 lanes = flops; integer and conversion instructions count 1 per lane.
+        lanes = 64.0
+        fp = (pm["SQ_INSTS_VALU_FLOPS_FP32"] + (pm.get("SQ_INSTS_VALU_FLOPS_FP32_TRANS") or 0.0) + (pm.get("SQ_INSTS_VALU_FLOPS_FP64") or 0.0)) * lanes
+        other = ((pm.get("SQ_INSTS_VALU_IOPS") or 0.0) + (pm.get("SQ_INSTS_VALU_CVT") or 0.0)) * lanes
+        unpacked = (pm.get("SQ_INSTS_VALU_ADD_F32") or 0.0) + (pm.get("SQ_INSTS_VALU_MUL_F32") or 0.0) + 2.0 * (pm.get("SQ_INSTS_VALU_FMA_F32") or 0.0)
+        out["executed_flop_eq"] = {
+            "flop_eq_per_launch": fp + other, "fp32_flops_per_launch": fp, "int_and_cvt_ops_per_launch": other,
+            "packed_second_halves_per_lane": pm["SQ_INSTS_VALU_FLOPS_FP32"] - unpacked,
+            "model": "64 x (SQ_INSTS_VALU_FLOPS_FP32 [+ _TRANS + FP64] + SQ_INSTS_VALU_IOPS + SQ_INSTS_VALU_CVT) per launch, timed steps"}
     out["pmc_phase"] = "dispatches %d..%d of the render kernel (bench.py's timed steps)" % (w, w + k - 1)
     json.dump(out, sys.stdout, indent=1)
     print()
