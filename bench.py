@@ -182,7 +182,15 @@ def cpu_oracle_rate(voices, buffers, threads, c3=False):
             s.render_events(cyc[(period + 2 + k) % period], FRAMES, SR, threads=threads, per_voice=False, mix=True)
         dt = time.perf_counter() - t0
         policy_s, render_s = s2o.events_seconds(reset=True)
-        return voices * FRAMES * buffers / render_s, dt, policy_s
+        rate = voices * FRAMES * buffers / render_s
+        # the same population on ONE thread (two buffers): what the all-cores rate is a multiple of
+        one = None
+        if threads > 1:
+            for k in range(2):
+                s.render_events(cyc[(period + 2 + buffers + k) % period], FRAMES, SR, threads=1, per_voice=False, mix=True)
+            _p1, r1 = s2o.events_seconds(reset=True)
+            one = voices * FRAMES * 2 / r1
+        return rate, dt, policy_s, one
     for v in range(voices):
         s.note_on(36 + v % 61)
     s.sample_mt(FRAMES, SR, threads)          # warm-up buffer
@@ -190,7 +198,7 @@ def cpu_oracle_rate(voices, buffers, threads, c3=False):
     for _ in range(buffers):
         s.sample_mt(FRAMES, SR, threads)
     dt = time.perf_counter() - t0
-    return voices * FRAMES * buffers / dt, dt, 0.0
+    return voices * FRAMES * buffers / dt, dt, 0.0, None
 
 
 def cpu_baseline_legs(budget_s):
@@ -205,14 +213,14 @@ def cpu_baseline_legs(budget_s):
         if c3:
             probe = 1.6e7 * threads                        # (an estimate sizes the leg: a probe would cost a whole period)
         else:
-            probe, _dt, _p = cpu_oracle_rate(voices, 1, threads)
+            probe = cpu_oracle_rate(voices, 1, threads)[0]
         nb = int(max(1, min(20000, budget_s * probe / (voices * FRAMES))))
         pins = one_cpu_per_core(threads) if threads > 1 else []
         old_mask = os.sched_getaffinity(0) if pins else None
         if pins:
             s2o.pool_pin(pins); os.sched_setaffinity(0, {pins[0]})
         try:
-            v, secs, policy_s = cpu_oracle_rate(voices, nb, threads, c3)
+            v, secs, policy_s, one_thread = cpu_oracle_rate(voices, nb, threads, c3)
         finally:
             if pins:
                 s2o.pool_pin([]); os.sched_setaffinity(0, old_mask)
@@ -223,8 +231,9 @@ def cpu_baseline_legs(budget_s):
                          voices, FRAMES, nb,
                          "the bench's C3 schedule after one untimed period, events applied between 16-frame sample() calls" if c3 else "all notes held (amp sustain)",
                          secs, (" of which %.1f s in the reference's O(voices) note_on / note_off scans, excluded from the rate" % policy_s) if c3 else ""))})
-    one = legs[1]["value"]
-    legs[2]["scaling_vs_one_thread"] = legs[2]["value"] / (one * legs[2]["cores"])
+        if c3 and one_thread:
+            legs[-1]["one_thread_same_population"] = one_thread
+            legs[-1]["scaling_vs_one_thread"] = v / (one_thread * threads)
     return legs
 
 

@@ -677,6 +677,14 @@ static void *pool_worker(void *arg) {
     unsigned long long seen = 0, pin_seen = 0;
     pthread_mutex_lock(&g_pool.mu);
     for (;;) {
+        /* (jobs follow each other within microseconds in the event-driven renderer — one per 16-frame stretch — so a
+         * worker looks for the next one for a little while before it sleeps; the pool's threads are pinned one per core
+         * in the timing legs) */
+        if (g_pool.gen == seen) {
+            pthread_mutex_unlock(&g_pool.mu);
+            for (int spin = 0; spin < 20000 && __atomic_load_n(&g_pool.gen, __ATOMIC_ACQUIRE) == seen; spin++) __builtin_ia32_pause();
+            pthread_mutex_lock(&g_pool.mu);
+        }
         while (g_pool.gen == seen) pthread_cond_wait(&g_pool.go, &g_pool.mu);
         seen = g_pool.gen;
         if (pin_seen != g_pin_gen) {
@@ -727,6 +735,7 @@ static void pool_run(int threads, pool_fn fn, void *ctx) {
     pthread_cond_broadcast(&g_pool.go);
     pthread_mutex_unlock(&g_pool.mu);
     fn(ctx, 0, threads);
+    for (int spin = 0; spin < 20000 && __atomic_load_n(&g_pool.remaining, __ATOMIC_ACQUIRE) != 0; spin++) __builtin_ia32_pause();
     pthread_mutex_lock(&g_pool.mu);
     while (g_pool.remaining) pthread_cond_wait(&g_pool.done, &g_pool.mu);
     pthread_mutex_unlock(&g_pool.mu);
@@ -734,32 +743,38 @@ static void pool_run(int threads, pool_fn fn, void *ctx) {
 
 typedef struct { s2o_synth *s; float *pv; size_t frames, stride, col0; uint32_t sr; float *acc; } mt_job;
 
+/* thread t of n takes the 64-voice blocks b with b % n == t: voices that were started together (and are in the same,
+ * possibly dearer, envelope stages: pow(2, 0) is an early exit) sit next to each other in the pool, so contiguous
+ * ranges would hand some threads all of them */
+#define MT_BLOCK 64u
 static void mt_render(void *ctx, int t, int n) {
     mt_job *j = (mt_job *)ctx;
-    const uint32_t v0 = (uint32_t)((uint64_t)j->s->num_voices * t / n), v1 = (uint32_t)((uint64_t)j->s->num_voices * (t + 1) / n);
-    for (uint32_t v = v0; v < v1; v++)
-        render_one_voice(j->s, &j->s->voices[v], j->pv + (size_t)v * j->stride + j->col0, j->frames, j->sr);
+    const uint32_t nv = j->s->num_voices;
+    for (uint32_t b0 = (uint32_t)t * MT_BLOCK; b0 < nv; b0 += (uint32_t)n * MT_BLOCK)
+        for (uint32_t v = b0; v < b0 + MT_BLOCK && v < nv; v++)
+            render_one_voice(j->s, &j->s->voices[v], j->pv + (size_t)v * j->stride + j->col0, j->frames, j->sr);
 }
 void s2o_render_voices_mt(s2o_synth *s, float *per_voice, size_t frames, uint32_t sr, int threads) {
     mt_job j = { s, per_voice, frames, frames, 0, sr, NULL };
     pool_run(threads, mt_render, &j);
 }
 
-/* thread t's voices rendered and added (in index order) into its accumulator acc[t][frames_stride] at column col0 */
+/* thread t's voices (the same blocks) rendered and added in index order into its accumulator acc[t][frames_stride] at column col0 */
 static void mt_sample(void *ctx, int t, int n) {
     mt_job *j = (mt_job *)ctx;
-    const uint32_t v0 = (uint32_t)((uint64_t)j->s->num_voices * t / n), v1 = (uint32_t)((uint64_t)j->s->num_voices * (t + 1) / n);
+    const uint32_t nv = j->s->num_voices;
     float row[16];
     float *acc = j->acc + (size_t)t * j->stride + j->col0;
     for (size_t i = 0; i < j->frames; i++) acc[i] = 0.0f;
-    for (uint32_t v = v0; v < v1; v++) {
-        if (!j->s->voices[v].has_current) continue;
-        for (size_t d = 0; d < j->frames; d += 16) {
-            const size_t m = j->frames - d < 16 ? j->frames - d : 16;
-            render_one_voice(j->s, &j->s->voices[v], row, m, j->sr);
-            for (size_t i = 0; i < m; i++) acc[d + i] += row[i];
+    for (uint32_t b0 = (uint32_t)t * MT_BLOCK; b0 < nv; b0 += (uint32_t)n * MT_BLOCK)
+        for (uint32_t v = b0; v < b0 + MT_BLOCK && v < nv; v++) {
+            if (!j->s->voices[v].has_current) continue;
+            for (size_t d = 0; d < j->frames; d += 16) {
+                const size_t m = j->frames - d < 16 ? j->frames - d : 16;
+                render_one_voice(j->s, &j->s->voices[v], row, m, j->sr);
+                for (size_t i = 0; i < m; i++) acc[d + i] += row[i];
+            }
         }
-    }
 }
 static void sum_thread_partials(const float *acc, int threads, size_t stride, size_t frames, float *buffer) {
     for (size_t i = 0; i < frames; i++) {
