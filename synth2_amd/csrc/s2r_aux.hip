@@ -57,6 +57,17 @@ __global__ void __launch_bounds__(256) s2r_table_kernel(const S2rTabBuild b) {
     if (b.fm_plane) b.base[(size_t)b.fm_plane * b.plane + i] = dead ? 1.0f : s2r_pow2_sleef_core(mod * b.amt_osc);   // process.rs:146-147
 }
 
+// The noise table: entry x = hashnoise.rs:33-51 for the hashed word x (hash_word_x16's input `start.rotl(5) ^ word`, of
+// which only the low 16 bits reach the u16 cast): v = (x * 0x9e3779b9) & 0xffff, ((v / 65535) * 2) - 1 with the
+// two-operation quotient of s2r_div_u16_by_65535 in its f = v * 2^-16 form — the operations the render kernels ran per
+// frame before the table existed.
+__global__ void __launch_bounds__(256) s2r_noise_table_kernel(float *t) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    const float f = (float)((x * 0x79b9u) & 0xffffu) * 0x1p-16f;
+    const float q = __builtin_fmaf(f, 0x1.0001p-16f, f);
+    t[x] = __builtin_fmaf(q, 2.0f, -1.0f);
+}
+
 // ---------------------------------------------------------------------------------------
 // mix kernel: adds the workgroup partial rows in the fixed order of DESIGN.md 4.3:
 //   runs of 16 consecutive workgroups sequentially -> the run sums of a mix group sequentially
@@ -209,6 +220,11 @@ hipError_t s2r_launch_general_osc15(const S2rRenderArgs &a, uint32_t block_voice
 hipError_t s2r_launch_tables(const S2rTabBuild &b, hipStream_t stream) {
     if (b.n_entries == 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(s2r_table_kernel, dim3((b.n_entries + 255u) / 256u), dim3(256), 0, stream, b);
+    return hipGetLastError();
+}
+
+hipError_t s2r_launch_noise_table(float *table_65536, hipStream_t stream) {
+    hipLaunchKernelGGL(s2r_noise_table_kernel, dim3(65536 / 256), dim3(256), 0, stream, table_65536);
     return hipGetLastError();
 }
 

@@ -125,6 +125,8 @@ struct S2rRenderParams {
     S2rDone done;            // with direct_out: told to the host when the output is written
     float *per_voice;        // [n_voices][frames] or nullptr (mix-disabled debug/parity path)
     const float *sin_table;  // 1024 floats (tables.rs)
+    const float *noise_tab;  // 65536 floats: the x16 noise (hashnoise.rs:33-51) of hashed word x, seed and offset folded into x
+                             // (s2r_noise_table_kernel); nullptr: computed per frame
     // coefficient tables: everything of a frame that depends on the mod envelope alone, as a
     // function of the envelope's own clock — shared by every voice that plays this patch
     S2rTabRef tab;
@@ -211,6 +213,7 @@ struct S2rMixParams {
 };
 
 hipError_t s2r_launch_tables(const S2rTabBuild &b, hipStream_t stream);
+hipError_t s2r_launch_noise_table(float *table_65536, hipStream_t stream);
 hipError_t s2r_launch_render(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
 hipError_t s2r_launch_mix(const S2rMixParams &p, hipStream_t stream);
 hipError_t s2r_launch_events(const S2rVoiceArrays &v, const S2rVoiceEvent *dev_events, uint32_t n, hipStream_t stream);

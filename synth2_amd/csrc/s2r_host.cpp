@@ -164,6 +164,7 @@ struct s2r_synth {
     struct DeferredMix { bool active = false; S2rMixParams m{}; int ring_slot = -1; } dmix;
     float *os_buf = nullptr, *os_taps = nullptr; // 4x oversampling: [62 history + max_frames] mix at 4x rate, 63 taps
     float *sin_dev = nullptr;
+    float *noise_dev = nullptr;                  // the noise table (S2rRenderParams.noise_tab), 65 536 floats
     float *per_voice_dev = nullptr; size_t per_voice_cap = 0;
     // coefficient tables of the patch (S2rTabRef): rebuilt on the device when the patch or the sample
     // rate changes
@@ -454,6 +455,8 @@ S2rRenderParams make_params(s2r_synth *s, size_t frames, uint32_t sample_rate) {
     p.block_partials = s->block_partials;
     p.per_voice = nullptr;
     p.sin_table = s->sin_dev;
+    { static const bool off = [] { const char *e = std::getenv("S2R_NOISE_TAB"); return e && e[0] == '0'; }();   // (measurement aid: per-frame noise)
+      p.noise_tab = off ? nullptr : s->noise_dev; }
     p.bank = s->bank_dev;
     p.bank_size = (uint32_t)s->bank.size();
     return p;
@@ -709,6 +712,7 @@ void release_all(s2r_synth *s) {
         if (s->ring_done[k]) (void)hipEventDestroy(s->ring_done[k]);
     }
     if (s->sin_dev) (void)hipFree(s->sin_dev);
+    if (s->noise_dev) (void)hipFree(s->noise_dev);
     if (s->per_voice_dev) (void)hipFree(s->per_voice_dev);
     if (s->voice_ev_head) (void)hipFree(s->voice_ev_head);
     if (s->tev_copy) (void)hipFree(s->tev_copy);
@@ -860,6 +864,8 @@ static int create_single(const s2r_config *cfg, std::shared_ptr<S2rVoicePool> po
         }
         CREATE_HIP(hipMalloc((void **)&s->sin_dev, sizeof table));
         CREATE_HIP(hipMemcpy(s->sin_dev, table, sizeof table, hipMemcpyHostToDevice));
+        CREATE_HIP(hipMalloc((void **)&s->noise_dev, 65536 * sizeof(float)));
+        CREATE_HIP(s2r_launch_noise_table(s->noise_dev, s->stream));
     }
     CREATE_HIP(hipStreamSynchronize(s->stream));
 #undef CREATE_HIP

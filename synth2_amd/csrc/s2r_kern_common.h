@@ -24,6 +24,11 @@ constexpr int kChunk = 16;         // the reference's x16 chunk (synth.rs:158, p
 constexpr uint32_t kSuperMax = 256; // frames between two cross-wave combines: 256 (small workgroups) or 64
 constexpr uint32_t kSuperWhole = 1024; // ... or the whole fill, where a workgroup has its compute unit to itself (below)
 constexpr int kP = 4;              // frames whose closed-form work one lane carries at once (ILP)
+// Row length (floats) of a wave's [16 frames][64 voices] transpose tile.  68 = 64 + 4: a row starts on a 16-byte boundary,
+// so the lane that adds up frame f of voice group g reads its 16 values (tile[f * 68 + 16 g ...]) with four 16-byte
+// LDS reads instead of eight 8-byte pairs, and the rows' bank offset (68 mod 64 = 4 banks per row) keeps those reads
+// conflict-free: within one ds_read_b128 lane group the 16 frames land on banks 0, 4, ..., 60.
+constexpr uint32_t kTileRow = 68;
 
 // The closed-form part of kP = 4 consecutive frames is evaluated together on 4-wide vectors.
 // Measured on MI355X (tools/ubench/issue_rates.hip): a SIMD retires one DEPENDENT VALU op per
@@ -748,7 +753,7 @@ __device__ __forceinline__ void apply_arg_events(const S2rRenderArgs &a, uint32_
 // ---------------------------------------------------------------------------------------
 
 // Four frames of one quad into the wave's [16 frames][64 voices + 1] transpose tile, voice per lane: frame f of lane l
-// goes to tile[f * 65 + l].  ds_write_addtid_b32 (LDS address = M0 + offset + 4 * lane, no address register) costs a
+// goes to tile[f * kTileRow + l].  ds_write_addtid_b32 (LDS address = M0 + offset + 4 * lane, no address register) costs a
 // lone wave 8 cycles of issue where ds_write_b32 costs 16 (tools/ubench/issue_rates3.hip) — with one wave per SIMD
 // the store of every voice-frame is a sixth of the chunk otherwise.  tile_set_base() puts the tile's LDS byte address
 // (wave-uniform) into M0 once per chunk; nothing the compiler generates for these kernels touches M0 in between
@@ -763,8 +768,8 @@ __device__ __forceinline__ void tile_store4(int q, f4 v) {
 #define S2R_ST4(Q)                                                                                              \
     asm volatile("ds_write_addtid_b32 %0 offset:%c4\n\tds_write_addtid_b32 %1 offset:%c5\n\t"                     \
                  "ds_write_addtid_b32 %2 offset:%c6\n\tds_write_addtid_b32 %3 offset:%c7"                          \
-                 : : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "n"((4 * Q) * 260), "n"((4 * Q + 1) * 260),         \
-                     "n"((4 * Q + 2) * 260), "n"((4 * Q + 3) * 260) : "memory")
+                 : : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "n"((4 * Q) * (kTileRow * 4)), "n"((4 * Q + 1) * (kTileRow * 4)),         \
+                     "n"((4 * Q + 2) * (kTileRow * 4)), "n"((4 * Q + 3) * (kTileRow * 4)) : "memory")
     switch (q) { case 0: S2R_ST4(0); break; case 1: S2R_ST4(1); break; case 2: S2R_ST4(2); break; default: S2R_ST4(3); break; }
 #undef S2R_ST4
 }
@@ -841,10 +846,9 @@ __device__ __forceinline__ f4 pk_add4(f4 a, f4 b) {
 //   NZ == 2 "ALIGNED" (on top of SMALL): the chunk starts on a multiple of 16 frames and rotl(seed, 5) has a zero low
 //   nibble on every lane (the reference's seed is always 0, state.rs:18-21, and s2_bin renders 16 frames at a time,
 //   main.rs:138-143).  Then (seed ^ (o + j)) & 0xffff == B + j with B = (seed ^ o) & 0xffff for j = 0..15, and the
-//   hash's low 16 bits are (B * 0x79b9 + j * 0x79b9) mod 2^16: one product per chunk.  In float form
-//   u = H0 * 2^-16 + c_j * 2^-16 (exact: 17 bits), f = fract(u) = h_j * 2^-16 exactly, and the two-operation quotient
-//   h / 65535 = fma(h, 0x1.0001p-32, h * 2^-16) is fma(f, 0x1.0001p-16, f) — the same real number rounded once:
-//   2.5 instructions per frame instead of 4, no integer work (hashnoise.rs:33-51,57-68).
+//   hashed words of the chunk's frames are 16 consecutive integers: the noise comes from the device's noise table (below),
+//   entry x = ((v / 65535) * 2) - 1 for v = (x * 0x9e3779b9) & 0xffff, evaluated with the two-operation quotient
+//   h / 65535 = fma(h, 0x1.0001p-32, h * 2^-16) = fma(f, 0x1.0001p-16, f), f = h * 2^-16 (hashnoise.rs:33-51,57-68).
 //   AFLAT (with SMALL): every started voice of the wave sits in an amplitude stage of slope +-0 (sustain, end) for
 //   the whole run, so slope * (t - base) + y0 is (+-0) + y0 with the product's sign fixed by the slope's (t >= base
 //   inside a stage): one evaluation per chunk, at its first frame, is every frame's value bit for bit.
@@ -886,27 +890,27 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
     uint32_t o01 = pk_add_u16(o_lo | (o_lo << 16), 0x00010000u), o23 = pk_add_u16(o01, 0x00020002u);
     const uint32_t seed_pair = (r.seed_rot & 0xffffu) | (r.seed_rot << 16);
     f4 t_small = splat(t_chunk) + (f4){0.0f, 1.0f, 2.0f, 3.0f};      // exact below 2^24, as are the + 4 steps
-    // ALIGNED: H0 * 2^-16, H0 = the hash's low 16 bits at the chunk's first frame, and the next frame's
-    const float h0f = (float)(((r.seed_rot ^ o_chunk) * 0x79b9u) & 0xffffu) * 0x1p-16f;
-    constexpr float kK1 = (float)0x79b9u * 0x1p-16f, kK2 = (float)((2u * 0x79b9u) & 0xffffu) * 0x1p-16f;
-    fp2 fpair = {h0f, __builtin_amdgcn_fractf(h0f + kK1)};
+    // ALIGNED: the chunk's 16 noise values are 16 consecutive entries of the device's noise table (S2rRenderParams.
+    // noise_tab, s2r_noise_table_kernel: entry x = the noise of hashed word x, the expression above evaluated once per
+    // 16-bit x).  (seed ^ (o + j)) & 0xffff == ((seed ^ o) & 0xffff) + j for j < 16 when both low nibbles are zero, so a
+    // lane reads 64 contiguous, 64-byte-aligned bytes: four 16-byte loads from a 256 KiB table that lives in the L2 (a
+    // cohort of voices started together reads the same 64 bytes), against 40 instructions of stepping and scaling.
+    // (Asking for them one chunk AHEAD was measured too: the median wave's chunk 924 -> 816 cycles, but the 16 registers it
+    // holds across the chunk come back as spills in the moving-stage variants, the waves that set the kernel's length:
+    // the launch no shorter, 0.0446 against 0.0439 ms.)
+    f4 nzt[4];
+    if (ALIGNED) {
+        const float *np = p.noise_tab + ((r.seed_rot ^ o_chunk) & 0xffffu);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) nzt[q] = *reinterpret_cast<const f4 *>(np + 4 * q);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         f4 t;
         if (ALIGNED) {
             t = t_small;
             t_small = t_small + splat(4.0f);
-            // f_j = h_j * 2^-16 for the quad's four frames, stepped from the previous pair: h_(j+2) = h_j + 2 * 0x79b9
-            // (mod 2^16) is f_(j+2) = fract(f_j + K2) exactly (both multiples of 2^-16 below 1).  One constant instead
-            // of a table of sixteen (which the compiler rebuilt in scalar registers on every chunk).
-            f4 f;
-            f.x = fpair.x; f.y = fpair.y;
-            fpair = fpair + (fp2){kK2, kK2};
-            fpair.x = __builtin_amdgcn_fractf(fpair.x); fpair.y = __builtin_amdgcn_fractf(fpair.y);
-            f.z = fpair.x; f.w = fpair.y;
-            fpair = fpair + (fp2){kK2, kK2};
-            fpair.x = __builtin_amdgcn_fractf(fpair.x); fpair.y = __builtin_amdgcn_fractf(fpair.y);
-            nz[q] = vfma(vfma(f, splat(0x1.0001p-16f), f), splat(2.0f), splat(-1.0f));
+            nz[q] = nzt[q];
         } else if (SMALL) {
             // stepping (one inline constant, one scalar literal) instead of 4 q + k per quad (a scalar move per literal)
             t = t_small;
