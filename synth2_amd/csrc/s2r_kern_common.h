@@ -148,11 +148,12 @@ struct VoiceRegs {
 // cascade only when t reaches it.  (t only grows within a fill; thresholds never precede the
 // stage they end, so "t < thr of the stage found at an earlier t" implies the same stage now.)
 // The value produced is the reference's selected expression, operation for operation.
-struct EnvRun {
-    float slope, base, y0, thr;
-    float stage;    // 0 attack, 1 decay, 2 sustain, 3 release, 4 end (a float like its neighbours: a struct of one
-                    // type is what the optimiser keeps in registers; with an int here the pair lived in scratch)
-};
+// The record is ONE vector value — elements: .s0 slope, .s1 base, .s2 y0, .s3 thr (the stage's end threshold), .s4 stage
+// (0 attack, 1 decay, 2 sustain, 3 release, 4 end; a float like its neighbours) — not a struct: as a struct of five floats
+// the kernels' two records lived in scratch memory (the optimiser merges neighbouring field accesses of the still
+// addressable struct into overlapping vector loads and stores and can then no longer take the struct apart: DESIGN.md 2),
+// and every stage change paid trips to it.
+typedef float EnvRun __attribute__((ext_vector_type(5)));
 
 // the cascade of simdtest.rs:288-292 for one frame offset t, from scratch: the first stage whose
 // `t < threshold` test holds (0 attack, 1 decay, 2 sustain, 3 release, 4 end), returned as that
@@ -165,16 +166,16 @@ __device__ __forceinline__ EnvRun env_stage_at(const S2rEnv &e, float ro, float 
     EnvRun s;
     //  0: (1/A) * t + 0        1: ((S-1)/D) * (t-A) + 1     2: S  (0*t + S == S)
     //  3: (-S/R) * (t-ro) + S  4: 0
-    s.slope = s0 ? e.slope_att : s1 ? e.slope_dec : s3 ? e.slope_rel : 0.0f;
-    s.base  = s1 ? e.A : s3 ? ro : 0.0f;
-    s.y0    = s1 ? 1.0f : (s2 || s3) ? e.S : 0.0f;
-    s.thr   = s0 ? e.A : s1 ? e.sus_off : s2 ? ro : s3 ? end : __builtin_inff();
-    s.stage = s0 ? 0.0f : s1 ? 1.0f : s2 ? 2.0f : s3 ? 3.0f : 4.0f;
+    s.s0 = s0 ? e.slope_att : s1 ? e.slope_dec : s3 ? e.slope_rel : 0.0f;
+    s.s1  = s1 ? e.A : s3 ? ro : 0.0f;
+    s.s2    = s1 ? 1.0f : (s2 || s3) ? e.S : 0.0f;
+    s.s3   = s0 ? e.A : s1 ? e.sus_off : s2 ? ro : s3 ? end : __builtin_inff();
+    s.s4 = s0 ? 0.0f : s1 ? 1.0f : s2 ? 2.0f : s3 ? 3.0f : 4.0f;
     return s;
 }
 
 __device__ __forceinline__ float env_value(const EnvRun &s, float t) {
-    return s.slope * (t - s.base) + s.y0;       // mul then add, separately rounded (simdtest.rs:247-261)
+    return s.s0 * (t - s.s1) + s.s2;       // mul then add, separately rounded (simdtest.rs:247-261)
 }
 
 // math.rs:11-19 with feature fma: slope = rise / run; slope.mul_add(x, y0)
@@ -433,9 +434,9 @@ __device__ __forceinline__ FlatConsts flat_consts_from_tables(const S2rRenderPar
 
 template <int OSC, bool FM>
 __device__ __forceinline__ FlatCache refresh_flat(const FlatConsts &c, const EnvRun em, FlatCache fc) {
-    if (em.slope == 0.0f) {
+    if (em.s0 == 0.0f) {
         // mod = 0 * (t - base) + y0 == y0, and y0 is S or +0 (or 1.0 in a decay whose slope (S - 1) / D is zero: S)
-        const bool zero = em.y0 == 0.0f;
+        const bool zero = em.s2 == 0.0f;
         fc.xc = zero ? c.xc_0 : c.xc_s;
         if (FM) fc.k = zero ? c.k_0 : c.k_s;
     }
@@ -450,8 +451,8 @@ __device__ __forceinline__ void closed_form_x4(const S2rRenderParams &p, const V
     const u4 ou = (u4)(oi) + (u4){0u, 1u, 2u, 3u};               // offsets_x16: wrapping u32 add (process.rs:213-219)
     const f4 t = __builtin_convertvector(ou, f4);                // offsets as f32 (simdtest.rs:277-279, process.rs:348)
     // fast path first: the active stages' lines for all four frames
-    f4 amp = splat(ea.slope) * (t - splat(ea.base)) + splat(ea.y0);           // process.rs:144
-    f4 mod = splat(em.slope) * (t - splat(em.base)) + splat(em.y0);           // process.rs:145
+    f4 amp = splat(ea.s0) * (t - splat(ea.s1)) + splat(ea.s2);           // process.rs:144
+    f4 mod = splat(em.s0) * (t - splat(em.s1)) + splat(em.s2);           // process.rs:145
     bool moving = p.no_flat_shortcut != 0;
     const bool cold = !(t.w < thr_min);
     if (__builtin_expect(__ballot(cold) != 0ull, 0)) {      // wave-uniform branch: no exec juggling when nobody is cold
@@ -464,7 +465,7 @@ __device__ __forceinline__ void closed_form_x4(const S2rRenderParams &p, const V
                 if (!(tj < thr_min)) {                                                    \
                     ea = env_stage_at(p.amp, r.ro_a, r.end_a, tj);                        \
                     em = env_stage_at(p.mod, r.ro_m, r.end_m, tj);                        \
-                    thr_min = __builtin_fminf(ea.thr, em.thr);                            \
+                    thr_min = __builtin_fminf(ea.s3, em.s3);                            \
                 }                                                                         \
                 amp.C = env_value(ea, tj);                                                \
                 mod.C = env_value(em, tj);                                                \
@@ -476,7 +477,7 @@ __device__ __forceinline__ void closed_form_x4(const S2rRenderParams &p, const V
     }
     cf.amp = amp;
     cf.nz = hash_noise4(r.seed_rot, t) + splat(p.noise_level);   // process.rs:347-356 (ADD)
-    moving = moving || em.slope != 0.0f;
+    moving = moving || em.s0 != 0.0f;
     if (__ballot(moving) == 0ull) {
         // every voice of this wave has a flat mod envelope over these four frames
         cf.xc = splat(fc.xc);
@@ -881,7 +882,7 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
     // (a0 = 1 - 1 = 0): selected once per chunk instead of per quad
     // (selects, not a branch: control flow here would split the chunk's basic block)
     r.last = live ? r.last : 0.0f;
-    const float ea_slope = live ? ea.slope : 0.0f, ea_base = live ? ea.base : 0.0f, ea_y0 = live ? ea.y0 : 0.0f;
+    const float ea_slope = live ? ea.s0 : 0.0f, ea_base = live ? ea.s1 : 0.0f, ea_y0 = live ? ea.s2 : 0.0f;
     const float xc0 = live ? fc.xc : 1.0f;
     f4 amp[4], nz[4];
     const float t_chunk = (float)o_chunk;
@@ -931,7 +932,7 @@ __device__ __forceinline__ void chunk_fast(const S2rRenderParams &p, VoiceRegs &
             iq[q] = splat(1.0f) / pq[q];                         // oscillators.rs:378
         }
         if (SRC == 2) {
-            const f4 mod = splat(em.slope) * (t - splat(em.base)) + splat(em.y0);
+            const f4 mod = splat(em.s0) * (t - splat(em.s1)) + splat(em.s2);
             const f4 f_lpf = pow2_sleef_core4(mod * splat(p.amt_lpf)) * splat(p.lpf_freq);
             const f4 num = splat(-2.0f * 3.14159274101257324f) * f_lpf;
             const f4 arg = p.fast_div_sr ? div_const_nocheck4(num, p.sr, p.rcp_sr) : (num / splat(p.sr));
