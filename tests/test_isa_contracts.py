@@ -83,4 +83,27 @@ def test_hot_chunk_has_no_compare_or_select(disassembly):
     # (objdump shows no labels: a "block" here may start with the loop's preheader, which selects the run's dead-lane
     # constants once — a handful of v_cndmask — and restores spilled scalars)
     assert best <= 6, best
-    assert smallest <= 260, "the steady-state chunk grew to %d instructions (r2: ~215 for 16 frames + its loop preheader)" % smallest
+    assert smallest <= 215, "the steady-state chunk grew to %d instructions (r3: ~170 for 16 frames + its loop preheader)" % smallest
+
+
+def test_render_kernels_keep_their_state_in_registers():
+    """The render kernels the default patch runs — saw + one-pole, no mod-to-pitch, 256-voice workgroups; whole fills,
+    per-voice rows and timed events — have no private segment (scratch) and spill no vector register: the envelope stage
+    records stay in VGPRs (DESIGN.md §2 — round 2's timed-event kernel had 88 bytes per lane, 3.4 x the algorithmic HBM
+    traffic).  Scalars may spill into VGPR lanes (v_writelane / v_readlane, no memory): bounded here so that growth shows.
+    (The 1 024-voice-workgroup variants — 128 registers per lane, only on request through s2r_config.block_voices — and
+    the mod-to-pitch variants do have scratch: DESIGN.md §8.)"""
+    import synth2_amd as s2
+    s2.load_library()
+    co = _code_objects()
+    if not os.path.exists(co.READELF):
+        pytest.skip("llvm-readelf not available")
+    from synth2_amd import build as _b
+    md = co.kernel_metadata(_b.LIB)
+    onepole = {k: v for k, v in md.items() if "s2r_render_kernelILi1ELb0E" in k and "ELi256EEE" in k}
+    assert len(onepole) >= 3, sorted(md)
+    for name, v in onepole.items():
+        assert v[".private_segment_fixed_size"] == 0, (name, v)
+        assert v[".vgpr_spill_count"] == 0, (name, v)
+        assert v[".vgpr_count"] <= 256, (name, v)
+        assert v[".sgpr_spill_count"] <= 260, (name, v)

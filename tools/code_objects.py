@@ -46,6 +46,30 @@ def disassemble(lib_path):
     return texts
 
 
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+
+
+def kernel_metadata(lib_path):
+    """-> {kernel name: {".private_segment_fixed_size": n, ".sgpr_spill_count": n, ".vgpr_spill_count": n, ".vgpr_count": n,
+    ".sgpr_count": n, ".group_segment_fixed_size": n}} from the code objects' amdhsa notes"""
+    import re
+    out = {}
+    for elf in extract(lib_path):
+        with tempfile.NamedTemporaryFile(suffix=".co", delete=False) as f:
+            f.write(elf)
+            name = f.name
+        try:
+            notes = subprocess.run([READELF, "--notes", name], capture_output=True, text=True, check=True).stdout
+        finally:
+            os.unlink(name)
+        # one "- .agpr_count:" item per kernel; scalar keys are "    .key:   value" lines at the item's indent
+        for item in re.split(r"\n\s*- \.agpr_count:", notes)[1:]:
+            kv = dict(re.findall(r"\n\s{4}(\.[a-z_]+):\s+(\S+)", item))
+            if ".name" in kv:
+                out[kv[".name"]] = {k: int(v) for k, v in kv.items() if v.isdigit()}
+    return out
+
+
 if __name__ == "__main__":
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "synth2_amd", "libs2r.so")
