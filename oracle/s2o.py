@@ -57,7 +57,9 @@ def use_native_build():
     oracle/_build/.  Must be called before the library is first loaded.  Same bits: -ffp-contract=off, no fast-math."""
     global _use_native
     assert _lib is None, "the oracle library is already loaded"
-    subprocess.check_call(["make", "-C", _HERE, "_build/libs2oracle_native.so"], stdout=subprocess.DEVNULL)
+    # -B: always rebuilt — oracle/_build travels with the repo snapshot, and a -march=native object made on another
+    # host (the build container) may hold instructions this one lacks
+    subprocess.check_call(["make", "-B", "-C", _HERE, "_build/libs2oracle_native.so"], stdout=subprocess.DEVNULL)
     _use_native = True
 
 

@@ -106,6 +106,9 @@ struct EventSlot {
 
 }  // namespace
 
+// a workgroup's partial row starts on a 16-byte boundary (combine_groups stores four frames at a time)
+static inline uint32_t partials_stride(uint32_t max_frames) { return (max_frames + 3u) & ~3u; }
+
 struct s2r_synth {
     s2r_config cfg{};
     int device = 0;
@@ -450,7 +453,7 @@ S2rRenderParams make_params(s2r_synth *s, size_t frames, uint32_t sample_rate) {
     p.no_flat_shortcut = s->no_flat_shortcut ? 1 : 0;
     p.frames = (uint32_t)frames;
     p.n_voices = s->shard_voices;
-    p.frames_stride = s->cfg.max_frames;
+    p.frames_stride = partials_stride(s->cfg.max_frames);
     p.v = s->v;
     p.block_partials = s->block_partials;
     p.per_voice = nullptr;
@@ -578,7 +581,7 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
         m.n_groups = root_add ? s->mix_groups : 1u;
         m.blocks_per_group = (s->n_blocks + m.n_groups - 1) / m.n_groups;
         m.frames = (uint32_t)frames;
-        m.frames_stride = s->cfg.max_frames;
+        m.frames_stride = partials_stride(s->cfg.max_frames);
         m.root_add = root_add ? 1 : 0;
         m.stereo = stereo ? 1 : 0;
         m.out = dev_out;
@@ -825,7 +828,7 @@ static int create_single(const s2r_config *cfg, std::shared_ptr<S2rVoicePool> po
     s->v.program = base + 11 * pv;
     s->v.osc_z = (float *)(base + 12 * pv);
     CREATE_HIP(hipMalloc((void **)&s->bank_dev, S2R_MAX_BANK * sizeof(S2rBankEntry)));
-    CREATE_HIP(hipMalloc((void **)&s->block_partials, (size_t)s->n_blocks * cfg->max_frames * sizeof(float)));
+    CREATE_HIP(hipMalloc((void **)&s->block_partials, (size_t)s->n_blocks * partials_stride(cfg->max_frames) * sizeof(float)));
     CREATE_HIP(hipMalloc((void **)&s->out_dev, (size_t)2 * cfg->max_frames * sizeof(float)));
     CREATE_HIP(hipHostMalloc((void **)&s->out_host, (size_t)2 * cfg->max_frames * sizeof(float), hipHostMallocMapped));
     CREATE_HIP(hipHostGetDevicePointer((void **)&s->out_host_dev, s->out_host, 0));

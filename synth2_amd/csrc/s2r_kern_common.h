@@ -822,6 +822,43 @@ __device__ __forceinline__ f4 pk_add4(f4 a, f4 b) {
     return (f4){lo.x, lo.y, hi.x, hi.y};
 }
 
+// The workgroup's cross-wave combine: per frame the block's 16-voice group sums in group (= voice index) order
+// (synth.rs:177-195's order), from sWbuf[n_groups][super_frames] into the block's partial row (and, for a one-workgroup
+// launch, through (+0.0) + sum — accum = splat(0.0), synth.rs:176 — into the output: DESIGN.md 4.3).  A thread takes four
+// consecutive frames: one 16-byte LDS read per group, four groups' reads in flight at a time, packed adds (the same IEEE
+// additions in the same order as one frame at a time; a loop of dependent 4-byte reads cost every wave ~6 000 cycles per
+// 1 024 frames, tools/stamps.py).  n_groups is a multiple of 4 (four groups per wave), super_frames of 4; the rows'
+// entries past n_sc are read and not used.  bp: the block's row at the super-chunk's first frame, 16-byte aligned.
+__device__ __forceinline__ void combine_groups(const S2rRenderParams &p, const float *sWbuf, uint32_t n_groups, uint32_t super_frames,
+                                               uint32_t n_sc, uint32_t sc0, float *bp_sc, uint32_t tid, uint32_t n_threads) {
+    for (uint32_t f = 4u * tid; f < n_sc; f += 4u * n_threads) {
+        const float *row = sWbuf + f;
+        f4 acc;
+        {
+            const f4 v0 = *reinterpret_cast<const f4 *>(row), v1 = *reinterpret_cast<const f4 *>(row + super_frames),
+                     v2 = *reinterpret_cast<const f4 *>(row + 2u * super_frames), v3 = *reinterpret_cast<const f4 *>(row + 3u * super_frames);
+            acc = pk_add4(pk_add4(pk_add4(v0, v1), v2), v3);
+        }
+        for (uint32_t g = 4u; g < n_groups; g += 4u) {
+            const float *rg = row + (size_t)g * super_frames;
+            const f4 v0 = *reinterpret_cast<const f4 *>(rg), v1 = *reinterpret_cast<const f4 *>(rg + super_frames),
+                     v2 = *reinterpret_cast<const f4 *>(rg + 2u * super_frames), v3 = *reinterpret_cast<const f4 *>(rg + 3u * super_frames);
+            acc = pk_add4(pk_add4(pk_add4(pk_add4(acc, v0), v1), v2), v3);
+        }
+        const uint32_t n = n_sc - f < 4u ? n_sc - f : 4u;
+        if (n == 4u) *reinterpret_cast<f4 *>(bp_sc + f) = acc;
+        else for (uint32_t j = 0; j < n; ++j) bp_sc[f + j] = acc[j];
+        if (p.direct_out) {                                      // one workgroup: this IS the mix
+            for (uint32_t j = 0; j < n; ++j) {
+                const float total = 0.0f + acc[j];
+                const uint32_t fo = sc0 + f + j;
+                if (p.direct_stereo) { out_store(p.done, p.direct_out + 2u * fo, total); out_store(p.done, p.direct_out + 2u * fo + 1u, total); }
+                else out_store(p.done, p.direct_out + fo, total);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // The branch-free 16-frame chunk.  Measured (ablated builds): with the rare branches (envelope
 // stage change, fmodf slow path, coefficient-source selection) inside the per-quad loop the

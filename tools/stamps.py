@@ -59,18 +59,18 @@ for rep in range(3):
     order = np.argsort(-total)[:12]
     x = st[:, 10]
     runchunks = (x >> np.uint64(48)).astype(np.int64); t_dense = ((x >> np.uint64(24)) & np.uint64(0xffffff)).astype(np.int64); t_run = (x & np.uint64(0xffffff)).astype(np.int64)
-    print("   slowest waves, where the work went: " + "  ".join("w%d dense %d chunks %d cyc (%d/chunk), runs %d chunks %d cyc (%d/chunk), general %d |" % (
-        w, t[w, 12], t_dense[w], t_dense[w] // max(1, t[w, 12]), runchunks[w], t_run[w], t_run[w] // max(1, runchunks[w]), 0) for w in order[:5]))
     y = st[:, 13]
     t_top = (y >> np.uint64(32)).astype(np.int64); t_sel = (y & np.uint64(0xffffffff)).astype(np.int64)
-    print("   slowest waves, outside the loops: " + "  ".join("w%d events at the loop top %d cyc, choosing runs %d cyc (%d runs) |" % (w, t_top[w], t_sel[w], t[w, 14]) for w in order[:5]))
+    z = st[:, 12]
+    n_dense = (z & np.uint64(0xfffff)).astype(np.int64); t_pick1 = ((z >> np.uint64(20)) & np.uint64(0x3fffff)).astype(np.int64)
+    t_casc = ((z >> np.uint64(42)) & np.uint64(0x3fffff)).astype(np.int64)
     med = np.argsort(total)[len(total) // 2 - 2: len(total) // 2 + 2]
-    print("   median waves, outside the loops: " + "  ".join("w%d loop top %d cyc, choosing runs %d cyc (%d runs) |" % (w, t_top[w], t_sel[w], t[w, 14]) for w in med))
-    print("   median waves: " + "  ".join("w%d dense %d chunks %d cyc, runs %d chunks %d cyc (%d/chunk), general %d |" % (
-        w, t[w, 12], t_dense[w], runchunks[w], t_run[w], t_run[w] // max(1, runchunks[w]), 0) for w in med))
-    print("   slowest waves: " + "  ".join("w%d total %d work %d ev %d dense %d runs %d |" % (w, total[w], work[w], t[w, 11], t[w, 12], t[w, 14]) for w in order[:6]))
-    if ev_w.size:
-        nb = [w for w in ev_w if w + 1 < waves and t[w + 1, 11] == 0][:6]
-        print("   event wave vs its neighbour without events: " + "  ".join("w%d(ev %d dense %d runs %d) work %d vs %d (runs %d) |" % (w, t[w, 11], t[w, 12], t[w, 14], work[w], work[w + 1], t[w + 1, 14]) for w in nb))
+    print("   %6s %7s %7s %7s %7s %5s | %4s %6s %7s %6s | %7s = %6s + %6s + %6s | %6s | %5s %7s" % (
+        "wave", "total", "prolog", "work", "combine", "epil", "runs", "chunks", "in runs", "/chunk", "choose", "look", "stage", "setup", "top", "dense", "cyc"))
+    for tag, ws in (("slowest", order[:8]), ("median", med)):
+        for w in ws:
+            print("   %6d %7d %7d %7d %7d %5d | %4d %6d %7d %6d | %7d = %6d + %6d + %6d | %6d | %5d %7d  %s" % (
+                w, total[w], cols[0][w], work[w], sum(cols[2 + 2 * i][w] for i in range(n_sc)), cols[-1][w], t[w, 14], runchunks[w], t_run[w],
+                t_run[w] // max(1, runchunks[w]), t_sel[w], t_pick1[w], t_casc[w], t_sel[w] - t_pick1[w] - t_casc[w], t_top[w], n_dense[w], t_dense[w], tag))
     for n, c in zip(names, cols):
         print("   %-12s median %7d   p99 %7d   max %7d   | last-exiting wave %d: %7d" % (n, int(np.median(c)), int(np.percentile(c, 99)), int(c.max()), slow, int(c[slow])))
