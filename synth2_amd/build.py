@@ -52,6 +52,11 @@ else:
 
 
 OBJ_DIR = os.path.join(HERE, OBJ_DIR_NAME)
+# S2R_AB_LIB=<path>: development aid for A/B timing on one GPU box — loads a library kept from another build of these
+# sources (same ABI) instead of libs2r.so; never rebuilt, never the product.
+AB_LIB = os.environ.get("S2R_AB_LIB")
+if AB_LIB:
+    LIB = os.path.abspath(AB_LIB)
 
 
 def _hipcc():
@@ -62,6 +67,10 @@ def _hipcc():
 
 
 def needs_build():
+    if AB_LIB:
+        if not os.path.exists(LIB):
+            raise RuntimeError("S2R_AB_LIB=%s does not exist" % LIB)
+        return False
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)

@@ -106,4 +106,4 @@ def test_render_kernels_keep_their_state_in_registers():
         assert v[".private_segment_fixed_size"] == 0, (name, v)
         assert v[".vgpr_spill_count"] == 0, (name, v)
         assert v[".vgpr_count"] <= 256, (name, v)
-        assert v[".sgpr_spill_count"] <= 260, (name, v)
+        assert v[".sgpr_spill_count"] <= 300, (name, v)
