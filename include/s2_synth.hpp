@@ -76,6 +76,9 @@ class Synth {
     // the same in two halves for a caller with two buffers in flight (s2_bin: audio_player.rs:56-60, main.rs:135-149)
     void sample_begin(size_t len, SampleRateKhz sample_rate) { check(s2r_fill_begin(h_, len, sample_rate.v)); }
     void sample_end(float *buffer, size_t capacity) { check(s2r_fill_end(h_, buffer, capacity)); }
+    // sample() per 16 frames from the audio callback (main.rs:138-147) without a launch per call: a resident render kernel
+    // between calls, small pools only (s2r.h: s2r_set_low_latency); same samples either way
+    void set_low_latency(bool enabled) { check(s2r_set_low_latency(h_, enabled ? 1 : 0)); }
     // a batch of events, each at frame 0 or at its 16-frame boundary inside the next buffer (main.rs:138-143)
     void note_events(const s2r_note_event *events, size_t n) { check(s2r_note_events(h_, events, n)); }
 

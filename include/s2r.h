@@ -252,6 +252,17 @@ uint32_t s2r_device_count(const s2r_synth *s);                  /* 1, or the N o
  * find_active_voice, which only returns unreleased voices (synth.rs:36-38,82-90), so it can never fire — this
  * counter is the diagnostic that warning was meant to be. */
 uint64_t s2r_double_release_count(const s2r_synth *s);
+/* Low-latency fills for the reference's own call pattern — a small pool rendered 16 frames at a time from the audio
+ * callback (synth.rs:154-203 called per 16 frames, s2_bin/src/main.rs:138-147, audio_player.rs:56-60).  Enabled, a handle
+ * whose shard is ONE workgroup (at most 256 voices, block_voices permitting) with a single one-pole patch keeps a resident
+ * render kernel on the device between s2r_fill / s2r_fill_stereo calls: a fill is then a command written to mapped host
+ * memory and a completion word polled, not a kernel launch.  The kernel leaves by itself after 1 ms
+ * without a fill (the next fill starts it again) and is stopped by every other entry point that touches the device or
+ * the patch; fills it cannot take (timed events, more than 9 note events since the last fill, seed overrides) go the
+ * ordinary way.  Same bits either way.  While it runs it occupies one compute unit and the handle's stream.
+ * s2r_low_latency_active: 1 while the resident kernel is believed to be on the device. */
+int s2r_set_low_latency(s2r_synth *s, int enabled);
+int s2r_low_latency_active(const s2r_synth *s);
 /* device time of the most recent fill's render kernel in milliseconds (HIP events recorded
  * on the library's stream around the launch); < 0 if timing is off.  Enable with
  * s2r_set_timing(s, 1): adds two event records per fill. */

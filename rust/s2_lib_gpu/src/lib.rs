@@ -120,6 +120,7 @@ pub mod ffi {
         pub fn s2r_fill_device(s: *mut S2rSynth, dev_out: *mut f32, frames: usize, sample_rate_hz: u32,
                                hip_stream: *mut c_void) -> c_int;
         pub fn s2r_device_count(s: *const S2rSynth) -> u32;
+        pub fn s2r_set_low_latency(s: *mut S2rSynth, enabled: c_int) -> c_int;
         pub fn s2r_last_error(s: *const S2rSynth) -> *const c_char;
         pub fn s2r_status_string(status: c_int) -> *const c_char;
     }
@@ -287,6 +288,13 @@ pub mod synth {
             self.check(unsafe {
                 ffi::s2r_fill_oversampled(self.handle, buffer.as_mut_ptr(), buffer.len(), sample_rate.0)
             });
+        }
+
+        /// For the reference's own call pattern — `sample()` per 16 frames from the audio callback (main.rs:138-147): keeps a
+        /// resident render kernel on the device between calls, so that a fill is a command in mapped host memory, not a
+        /// launch.  Small pools only (one workgroup: at most 256 voices); same samples either way.
+        pub fn set_low_latency(&mut self, enabled: bool) {
+            self.check(unsafe { ffi::s2r_set_low_latency(self.handle, if enabled { 1 } else { 0 }) });
         }
 
         /// how many GPUs render this Synth

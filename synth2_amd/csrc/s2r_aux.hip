@@ -207,6 +207,10 @@ __global__ void s2r_events_kernel(const S2rVoiceArrays v, const S2rVoiceEvent *e
 }
 }  // namespace
 
+hipError_t s2r_launch_onepole_resident_osc0(const S2rRenderArgs &a, const S2rResident &rs, uint32_t block_voices, hipStream_t stream);
+hipError_t s2r_launch_onepole_resident_osc1(const S2rRenderArgs &a, const S2rResident &rs, uint32_t block_voices, hipStream_t stream);
+hipError_t s2r_launch_onepole_resident_osc2(const S2rRenderArgs &a, const S2rResident &rs, uint32_t block_voices, hipStream_t stream);
+hipError_t s2r_launch_onepole_resident_osc3(const S2rRenderArgs &a, const S2rResident &rs, uint32_t block_voices, hipStream_t stream);
 hipError_t s2r_launch_onepole_osc0(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
 hipError_t s2r_launch_onepole_osc1(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
 hipError_t s2r_launch_onepole_osc2(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
@@ -240,6 +244,18 @@ hipError_t s2r_launch_render(const S2rRenderArgs &a, uint32_t block_voices, hipS
     case S2R_OSC_SAW: return general ? s2r_launch_general_osc1(a, block_voices, stream) : s2r_launch_onepole_osc1(a, block_voices, stream);
     case S2R_OSC_TRIANGLE: return general ? s2r_launch_general_osc2(a, block_voices, stream) : s2r_launch_onepole_osc2(a, block_voices, stream);
     case S2R_OSC_SINE: return general ? s2r_launch_general_osc3(a, block_voices, stream) : s2r_launch_onepole_osc3(a, block_voices, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t s2r_launch_resident(const S2rRenderArgs &a, const S2rResident &rs, uint32_t block_voices, hipStream_t stream) {
+    const S2rRenderParams &p = a.p;
+    if (p.n_voices == 0 || p.frames == 0 || p.bank_size > 1 || p.lpf_kind != S2R_FILT_ONEPOLE) return hipErrorInvalidValue;
+    switch (p.osc_kind) {
+    case S2R_OSC_SQUARE: return s2r_launch_onepole_resident_osc0(a, rs, block_voices, stream);
+    case S2R_OSC_SAW: return s2r_launch_onepole_resident_osc1(a, rs, block_voices, stream);
+    case S2R_OSC_TRIANGLE: return s2r_launch_onepole_resident_osc2(a, rs, block_voices, stream);
+    case S2R_OSC_SINE: return s2r_launch_onepole_resident_osc3(a, rs, block_voices, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -184,6 +184,28 @@ struct S2rRenderArgs {
 };
 static_assert(sizeof(S2rRenderArgs) <= 4096, "kernel arguments are limited to 4 KiB");
 
+// The resident render kernel (s2r_resident_kernel; s2r_set_low_latency): ONE workgroup that stays on the device between
+// fills, polls a command in mapped host memory, renders the fill it describes (the one-pole kernel's fill, state in HBM
+// between fills as ever) straight into mapped host memory and reports through the fill's completion word — a 16-frame
+// fill then costs two trips over the host link and a few microseconds of kernel, not a launch.
+//   command: 32 words in two 64-byte lines, read by one wave with one load per lane.  The host writes the payload, then
+//   word 31, then word 0 (x86 stores become visible in program order): a reader that finds word 0 == word 31 == a new
+//   sequence number has the whole command.
+#define S2R_RES_CMD_WORDS 32u
+#define S2R_RES_MAX_EVENTS 9u          // 4 header words + 9 * 3 + the closing sequence word
+#define S2R_RES_FLAG_EXIT 1u
+struct S2rResident {
+    const uint32_t *cmd;         // [32], device address of the mapped host command:
+                                 //   [0] seq  [1] frames | flags << 16  [2] n_events  [3] the completion word's value
+                                 //   [4 .. 30] events (voice, flags, pitch bits)  [31] seq
+    uint32_t *exited;            // mapped host word: the kernel stores `launch_id` there as its last act
+    uint32_t launch_id;
+    uint32_t first_seq;          // the first command's sequence number (everything before it is stale)
+    uint32_t idle_ticks;         // leaves after this many 100 MHz ticks without a command ...
+    uint32_t max_polls;          // ... or this many polls, whichever comes first: the grid always drains
+    uint32_t *done_flag, *done_counter;   // the fills' completion word (S2rDone; the command carries the value)
+};
+
 // what s2r_table_kernel needs: the patch resolved for a sample rate and where the planes go
 struct S2rTabBuild {
     S2rEnv mod;
@@ -214,6 +236,8 @@ struct S2rMixParams {
 
 hipError_t s2r_launch_tables(const S2rTabBuild &b, hipStream_t stream);
 hipError_t s2r_launch_noise_table(float *table_65536, hipStream_t stream);
+// one-pole single-patch handles of one workgroup only (a.p.direct_out set, a.p.frames = the longest fill): false otherwise
+hipError_t s2r_launch_resident(const S2rRenderArgs &a, const S2rResident &rs, uint32_t block_voices, hipStream_t stream);
 hipError_t s2r_launch_render(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
 hipError_t s2r_launch_mix(const S2rMixParams &p, hipStream_t stream);
 hipError_t s2r_launch_events(const S2rVoiceArrays &v, const S2rVoiceEvent *dev_events, uint32_t n, hipStream_t stream);

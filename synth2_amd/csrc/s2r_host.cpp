@@ -178,6 +178,15 @@ struct s2r_synth {
     unsigned long long *stamps_dev = nullptr;            // diagnostic builds (-DS2R_STAMPS): per-wave phase stamps of the last fill
     unsigned long long *timeline_dev = nullptr; uint32_t timeline_n = 0, timeline_cap = 0;   // ... and the launches' timeline
     bool use_tab = true, use_arg_events = true;
+    // s2r_set_low_latency: the resident kernel (S2rResident, s2r_device.h) — running on `stream` between fills while
+    // res_running; every entry point that touches the device or what the kernel's arguments were built from stops it first
+    bool low_latency = false, res_running = false, res_stereo = false;
+    uint32_t res_rate = 0, res_seq = 0, res_launch_id = 0;
+    uint32_t *res_host = nullptr, *res_dev = nullptr;    // mapped host memory: [32] the kernel's "exited" word, and, where the CPU cannot
+                                                         // write device memory, [0 .. 31] the command
+    uint32_t *res_cmd = nullptr;                         // the command as the CPU writes it: res_host, or 32 words of fine-grained
+    uint32_t *res_cmd_dev = nullptr;                     // DEVICE memory (large BAR) that the kernel polls without crossing the link
+    bool res_cmd_vram = false;
     float pitch_table[256];
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool timing = false, timed = false, no_flat_shortcut = false;
@@ -196,6 +205,10 @@ int set_err(s2r_synth *s, int code, const char *fmt, ...) {
     }
     return code;
 }
+
+// every entry point that touches the device, or anything a running resident kernel's arguments were built from, first
+#define S2R_QUIESCE(s) do { const int rc_q_ = resident_stop(s); if (rc_q_ != S2R_OK) return rc_q_; } while (0)
+int resident_stop(s2r_synth *s);
 
 #define S2R_HIP(s, call)                                                                              \
     do {                                                                                              \
@@ -667,12 +680,124 @@ int enqueue_root(s2r_synth *s, size_t frames, uint32_t sample_rate, float *dev_o
     return enqueue_fill(s, frames, sample_rate, s->stream, dev_out, true, stereo, nullptr, defer_ring_slot, done);
 }
 
+// ---- the resident kernel (s2r_set_low_latency) ----
+
+void resident_post(s2r_synth *s, uint32_t seq) {                // payload first, then word 31, then word 0 (S2rResident)
+    volatile uint32_t *c = s->res_cmd;
+    // (device memory behind the BAR is write-combining: the fences are what orders the three stages on the link)
+    if (s->res_cmd_vram) __builtin_ia32_sfence();
+    __atomic_store_n(&c[31], seq, __ATOMIC_RELEASE);
+    if (s->res_cmd_vram) __builtin_ia32_sfence();
+    __atomic_store_n(&c[0], seq, __ATOMIC_RELEASE);
+    if (s->res_cmd_vram) __builtin_ia32_sfence();
+}
+
+bool resident_exited(const s2r_synth *s) { return __atomic_load_n(&s->res_host[32], __ATOMIC_ACQUIRE) == s->res_launch_id; }
+
+// Ends the resident kernel, if there is one, and waits for it: the stream is the caller's again.
+int resident_stop(s2r_synth *s) {
+    if (!s || !s->res_running) return S2R_OK;
+    volatile uint32_t *c = s->res_cmd;
+    c[1] = S2R_RES_FLAG_EXIT << 16; c[2] = 0; c[3] = 0;
+    resident_post(s, ++s->res_seq);
+    s->res_running = false;
+    S2R_HIP(s, hipSetDevice(s->device));
+    S2R_HIP(s, hipStreamSynchronize(s->stream));
+    return S2R_OK;
+}
+
+// A fill the resident kernel can take: one workgroup of the one-pole kernel, a handful of untimed events, nothing else
+// in flight on the stream.
+bool resident_eligible(const s2r_synth *s, size_t frames) {
+    if (!s->low_latency || s->parent || !s->kids.empty() || s->n_blocks != 1 || s->block_voices > 256u) return false;
+    if (s->bank.size() != 1 || s->bank[0].osc_kind > S2R_OSC_SINE || s->bank[0].lpf_kind != S2R_FILT_ONEPOLE) return false;
+    if (!s->use_arg_events || !s->tpending.empty() || s->fill_time != 0 || s->pending.size() > S2R_RES_MAX_EVENTS) return false;
+    if (s->timing || s->dmix.active || s->ring_count != 0 || s->timeline_dev || frames > 0xffffu) return false;
+    for (const S2rVoiceEvent &e : s->pending) if (e.seed != 0u) return false;
+    return true;
+}
+
+int resident_launch(s2r_synth *s, uint32_t sample_rate, bool stereo) {
+    S2R_HIP(s, hipSetDevice(s->device));
+    static thread_local S2rRenderArgs a;
+    S2rRenderParams &p = a.p;
+    p = make_params(s, s->cfg.max_frames, sample_rate);          // (p.frames: the longest fill, sizes the staging)
+    { int rc = ensure_tables(s, p, sample_rate, s->stream); if (rc != S2R_OK) return rc; }
+    if (tables_wanted(s)) p.tab = s->tab;
+    p.voice_ev_head = s->voice_ev_head;
+    p.direct_out = s->out_host_dev; p.direct_stereo = stereo ? 1 : 0;
+    p.stamps = s->stamps_dev;                                    // (diagnostic builds: tools/stamps_small.py)
+    a.n_events = 0;
+    S2rResident rs{};
+    rs.cmd = s->res_cmd_dev; rs.exited = s->res_dev + 32;
+    rs.launch_id = ++s->res_launch_id;
+    rs.first_seq = s->res_seq + 1u;
+    rs.idle_ticks = 100000u;                                     // 1 ms without a command (real-time callers come every 0.33 ms)
+    rs.max_polls = 1u << 20;
+    rs.done_flag = s->done_dev + 2; rs.done_counter = s->done_counter + 2;
+    S2R_HIP(s, s2r_launch_resident(a, rs, s->block_voices, s->stream));
+    s->res_running = true; s->res_rate = sample_rate; s->res_stereo = stereo;
+    return S2R_OK;
+}
+
+int resident_fill(s2r_synth *s, float *out, size_t frames, uint32_t sample_rate, bool stereo) {
+    if (s->res_running && (s->res_rate != sample_rate || s->res_stereo != stereo || resident_exited(s))) {
+        int rc = resident_stop(s);
+        if (rc != S2R_OK) return rc;
+    }
+    if (!s->res_running) { int rc = resident_launch(s, sample_rate, stereo); if (rc != S2R_OK) return rc; }
+    volatile uint32_t *c = s->res_cmd;
+    const uint32_t n = (uint32_t)s->pending.size();
+    const uint32_t done_value = ++s->done_seq;
+    c[1] = (uint32_t)frames; c[2] = n; c[3] = done_value;
+    for (uint32_t i = 0; i < n; i++) {
+        const S2rVoiceEvent &e = s->pending[i];
+        c[4u + 3u * i] = e.voice; c[5u + 3u * i] = e.flags; c[6u + 3u * i] = s2r_f2u(e.pitch);
+    }
+    for (const S2rVoiceEvent &e : s->pending) s->pending_slot[e.voice] = -1;
+    s->pending.clear();
+    resident_post(s, ++s->res_seq);
+    s->pool->advance(frames);
+    // the completion word; a kernel that left (idle for too long) just before the command reached it is started again
+    volatile uint32_t *f = s->done_host + 2;
+    bool done = false;
+    for (int attempt = 0; attempt < 3 && !done; attempt++) {
+        for (int round = 0; round < 4000 && !done; round++) {
+            for (int i = 0; i < 1000; i++) {
+                if ((int32_t)(*f - done_value) >= 0) { done = true; break; }
+                __builtin_ia32_pause();
+            }
+            if (!done && resident_exited(s)) break;
+        }
+        if (done || (int32_t)(*f - done_value) >= 0) { done = true; break; }
+        if (!resident_exited(s)) break;                          // neither finished nor gone: the stream decides below
+        s->res_running = false;
+        S2R_HIP(s, hipSetDevice(s->device));
+        S2R_HIP(s, hipStreamSynchronize(s->stream));
+        if ((int32_t)(*f - done_value) >= 0) { done = true; break; }
+        int rc = resident_launch(s, sample_rate, stereo);        // (first_seq = the command's successor: post it again)
+        if (rc != S2R_OK) return rc;
+        resident_post(s, ++s->res_seq);
+    }
+    if (!done) {
+        (void)resident_stop(s);
+        if ((int32_t)(*f - done_value) < 0) return set_err(s, S2R_ERR_HIP, "the resident kernel did not report the fill");
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    std::memcpy(out, s->out_host, frames * (stereo ? 2 : 1) * sizeof(float));
+    return S2R_OK;
+}
+
 int fill_host(s2r_synth *s, float *out, size_t frames, uint32_t sample_rate, bool stereo) {
     int rc = check_fill(s, frames, sample_rate);
     if (rc != S2R_OK) return rc;
     if (frames == 0) return S2R_OK;
     if (!out) return set_err(s, S2R_ERR_INVALID, "null output buffer");
+    // (the resident kernel's fills make no HIP call while it runs)
+    if (resident_eligible(s, frames)) return resident_fill(s, out, frames, sample_rate, stereo);
     S2R_HIP(s, hipSetDevice(s->device));
+    rc = resident_stop(s);
+    if (rc != S2R_OK) return rc;
     // the last kernel of the fill writes the few KiB of output straight into mapped host memory: no copy
     // command between the launch and the wait
     const S2rDone done{s->done_dev + 2, ++s->done_seq, s->done_counter + 2};
@@ -687,6 +812,7 @@ int fill_host(s2r_synth *s, float *out, size_t frames, uint32_t sample_rate, boo
 
 void release_all(s2r_synth *s) {
     if (!s) return;
+    (void)resident_stop(s);
     for (s2r_synth *kid : s->kids) release_all(kid);
     s->kids.clear();
     (void)hipSetDevice(s->device);
@@ -716,6 +842,8 @@ void release_all(s2r_synth *s) {
     }
     if (s->sin_dev) (void)hipFree(s->sin_dev);
     if (s->noise_dev) (void)hipFree(s->noise_dev);
+    if (s->res_cmd_vram && s->res_cmd) (void)hipFree(s->res_cmd);
+    if (s->res_host) (void)hipHostFree(s->res_host);
     if (s->per_voice_dev) (void)hipFree(s->per_voice_dev);
     if (s->voice_ev_head) (void)hipFree(s->voice_ev_head);
     if (s->tev_copy) (void)hipFree(s->tev_copy);
@@ -979,6 +1107,7 @@ int s2r_set_patch(s2r_synth *s, const s2r_patch *patch) {
     std::string err;
     int rc = s2r_validate_patch(patch, &err);
     if (rc != S2R_OK) return set_err(s, rc, "%s", err.c_str());
+    S2R_QUIESCE(s);
     s->bank[0] = *patch;
     s->bank_dirty = true; s->tab_dirty = true;
     for (s2r_synth *kid : s->kids) { kid->bank[0] = *patch; kid->bank_dirty = true; kid->tab_dirty = true; }
@@ -993,6 +1122,7 @@ int s2r_set_patch_bank(s2r_synth *s, const s2r_patch *patches, uint32_t n) {
         int rc = s2r_validate_patch(&patches[k], &err);
         if (rc != S2R_OK) return set_err(s, rc, "patch %u: %s", k, err.c_str());
     }
+    S2R_QUIESCE(s);
     s->bank.assign(patches, patches + n);
     if (s->program >= n) s->program = 0;
     s->bank_dirty = true; s->tab_dirty = true;
@@ -1005,6 +1135,7 @@ uint32_t s2r_patch_bank_size(const s2r_synth *s) { return s ? (uint32_t)s->bank.
 int s2r_program_change(s2r_synth *s, uint32_t program) {
     if (!s) return S2R_ERR_INVALID;
     if (program >= s->bank.size()) return set_err(s, S2R_ERR_INVALID, "program %u: the bank holds %zu patches", program, s->bank.size());
+    S2R_QUIESCE(s);
     s->program = program;
     return S2R_OK;
 }
@@ -1021,6 +1152,7 @@ int s2r_load_patch(s2r_synth *s, const char *text, size_t len) {
     std::string err;
     int rc = s2r_parse_patch(text ? text : "", len, &p, nullptr, &err);
     if (rc != S2R_OK) return set_err(s, rc, "%s", err.c_str());
+    S2R_QUIESCE(s);
     s->bank[0] = p;
     s->bank_dirty = true; s->tab_dirty = true;
     for (s2r_synth *kid : s->kids) { kid->bank[0] = p; kid->bank_dirty = true; kid->tab_dirty = true; }
@@ -1136,6 +1268,7 @@ int s2r_fill_begin(s2r_synth *s, size_t frames, uint32_t sample_rate_hz) {
     int rc = check_fill(s, frames, sample_rate_hz);
     if (rc != S2R_OK) return rc;
     if (s->ring_count >= 2) return set_err(s, S2R_ERR_INVALID, "two fills are already in flight: s2r_fill_end first");
+    S2R_QUIESCE(s);
     S2R_HIP(s, hipSetDevice(s->device));
     const uint32_t slot = (s->ring_head + s->ring_count) & 1u;
     if (frames) {
@@ -1182,6 +1315,7 @@ int s2r_fill_stereo(s2r_synth *s, float *interleaved_lr_out, size_t frames, uint
 int s2r_fill_oversampled(s2r_synth *s, float *mono_out, size_t frames, uint32_t sample_rate_hz) {
     if (!s) return S2R_ERR_INVALID;
     if (sample_rate_hz > 0xffffffffu / S2R_OVERSAMPLE) return set_err(s, S2R_ERR_INVALID, "sample rate too high to oversample");
+    S2R_QUIESCE(s);
     const size_t os_frames = frames * S2R_OVERSAMPLE;
     int rc = check_fill(s, os_frames, sample_rate_hz * S2R_OVERSAMPLE);
     if (rc != S2R_OK) return rc;
@@ -1220,6 +1354,7 @@ int s2r_fill_device(s2r_synth *s, float *dev_partial_out, size_t frames, uint32_
     if (frames == 0) return S2R_OK;
     if (!dev_partial_out) return set_err(s, S2R_ERR_INVALID, "null device output buffer");
     if (!s->kids.empty()) return set_err(s, S2R_ERR_INVALID, "s2r_fill_device is the per-shard building block: a device-list handle combines its shards itself (s2r_fill)");
+    S2R_QUIESCE(s);
     S2R_HIP(s, hipSetDevice(s->device));
     return enqueue_fill(s, frames, sample_rate_hz, (hipStream_t)hip_stream, dev_partial_out, false, false, nullptr);
 }
@@ -1230,6 +1365,7 @@ int s2r_fill_device_root(s2r_synth *s, float *dev_out, size_t frames, uint32_t s
     if (frames == 0) return S2R_OK;
     if (!dev_out) return set_err(s, S2R_ERR_INVALID, "null device output buffer");
     if (!s->kids.empty()) return set_err(s, S2R_ERR_INVALID, "s2r_fill_device_root takes a single-device handle");
+    S2R_QUIESCE(s);
     S2R_HIP(s, hipSetDevice(s->device));
     return enqueue_fill(s, frames, sample_rate_hz, (hipStream_t)hip_stream, dev_out, true, false, nullptr);
 }
@@ -1245,6 +1381,7 @@ int s2r_render_voices(s2r_synth *s, float *per_voice_out, size_t frames, uint32_
     if (frames == 0) return S2R_OK;
     if (!per_voice_out) return set_err(s, S2R_ERR_INVALID, "null output buffer");
     if (!s->tpending.empty()) return set_err(s, S2R_ERR_INVALID, "s2r_render_voices does not take timed events; use s2r_fill");
+    S2R_QUIESCE(s);
     if (!s->kids.empty()) {                       // every shard's rows, put back into pool order
         for (s2r_synth *kid : s->kids) if (!kid->tpending.empty()) return set_err(s, S2R_ERR_INVALID, "s2r_render_voices does not take timed events; use s2r_fill");
         rc = enqueue_multi(s, frames, sample_rate_hz, nullptr, false, per_voice_out);
@@ -1276,6 +1413,7 @@ int s2r_render_voices(s2r_synth *s, float *per_voice_out, size_t frames, uint32_
 
 int s2r_export_state(s2r_synth *s, s2r_voice_state *voices) {
     if (!s || !voices) return S2R_ERR_INVALID;
+    S2R_QUIESCE(s);
     if (!s->kids.empty()) {                       // pool order: every shard's voices put back where the pool has them
         std::vector<s2r_voice_state> tmp;
         for (s2r_synth *kid : s->kids) {
@@ -1320,6 +1458,7 @@ int s2r_export_state(s2r_synth *s, s2r_voice_state *voices) {
 
 int s2r_import_state(s2r_synth *s, const s2r_voice_state *voices) {
     if (!s || !voices) return S2R_ERR_INVALID;
+    S2R_QUIESCE(s);
     if (!s->kids.empty()) {
         std::vector<s2r_voice_state> tmp;
         for (s2r_synth *kid : s->kids) {
@@ -1362,6 +1501,7 @@ int s2r_import_state(s2r_synth *s, const s2r_voice_state *voices) {
 int s2r_set_noise_seed(s2r_synth *s, uint32_t voice_index, uint32_t seed) {
     if (!s || s->parent || voice_index >= s->pool->size()) return S2R_ERR_INVALID;
     s->seed_override[voice_index] = seed;
+    S2R_QUIESCE(s);
     uint32_t local = 0;
     s2r_synth *sh = shard_of(s, voice_index, &local);
     if (sh) {
@@ -1383,6 +1523,7 @@ uint64_t s2r_double_release_count(const s2r_synth *s) { return s ? s->double_rel
 
 int s2r_set_flat_shortcut(s2r_synth *s, int enabled) {
     if (!s) return S2R_ERR_INVALID;
+    S2R_QUIESCE(s);
     s->no_flat_shortcut = enabled == 0;
     for (s2r_synth *kid : s->kids) kid->no_flat_shortcut = s->no_flat_shortcut;
     return S2R_OK;
@@ -1390,6 +1531,7 @@ int s2r_set_flat_shortcut(s2r_synth *s, int enabled) {
 
 int s2r_set_coeff_stream(s2r_synth *s, int enabled) {
     if (!s) return S2R_ERR_INVALID;
+    S2R_QUIESCE(s);
     s->use_tab = enabled != 0;                    // 0: coefficients in-lane; else from the patch's tables
     s->use_arg_events = enabled != 2 && enabled != 4;   // 2, 4: note events through their own launch, never in the kernel arguments
     s->bank_dirty = true;                         // (a resolved bank carries the choice in its entries' tab_valid)
@@ -1397,8 +1539,41 @@ int s2r_set_coeff_stream(s2r_synth *s, int enabled) {
     return S2R_OK;
 }
 
+int s2r_set_low_latency(s2r_synth *s, int enabled) {
+    if (!s) return S2R_ERR_INVALID;
+    if (s->parent || !s->kids.empty()) return set_err(s, S2R_ERR_INVALID, "s2r_set_low_latency takes a single-device handle");
+    S2R_QUIESCE(s);
+    if (enabled && !s->res_host) {
+        S2R_HIP(s, hipSetDevice(s->device));
+        S2R_HIP(s, hipHostMalloc((void **)&s->res_host, 64 * sizeof(uint32_t), hipHostMallocMapped));
+        std::memset(s->res_host, 0, 64 * sizeof(uint32_t));
+        S2R_HIP(s, hipHostGetDevicePointer((void **)&s->res_dev, s->res_host, 0));
+        s->res_cmd = s->res_host; s->res_cmd_dev = s->res_dev; s->res_cmd_vram = false;
+        // Where the whole of device memory is visible to the CPU (large BAR: hipDeviceAttributeIsLargeBar), the command lives
+        // in fine-grained device memory: the CPU's stores cross the link once, posted, and the kernel's polls stay on the
+        // device (a poll of host memory is a round trip over the link, and the command is seen a trip later).
+        // S2R_RES_CMD_HOST=1 keeps it in host memory (measurement aid).
+        int large_bar = 0;
+        const char *force_host = std::getenv("S2R_RES_CMD_HOST");
+        if (!(force_host && force_host[0] == '1') &&
+            hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, s->device) == hipSuccess && large_bar) {
+            uint32_t *v = nullptr;
+            if (hipExtMallocWithFlags((void **)&v, 64 * sizeof(uint32_t), hipDeviceMallocFinegrained) == hipSuccess && v) {
+                S2R_HIP(s, hipMemset(v, 0, 64 * sizeof(uint32_t)));
+                S2R_HIP(s, hipDeviceSynchronize());
+                s->res_cmd = v; s->res_cmd_dev = v; s->res_cmd_vram = true;
+            } else (void)hipGetLastError();
+        }
+    }
+    s->low_latency = enabled != 0;
+    return S2R_OK;
+}
+
+int s2r_low_latency_active(const s2r_synth *s) { return (s && s->res_running) ? 1 : 0; }
+
 int s2r_set_timing(s2r_synth *s, int enabled) {
     if (!s) return S2R_ERR_INVALID;
+    S2R_QUIESCE(s);
     s->timing = enabled != 0;
     s->timed = false;
     for (s2r_synth *kid : s->kids) { kid->timing = s->timing; kid->timed = false; }
@@ -1406,6 +1581,7 @@ int s2r_set_timing(s2r_synth *s, int enabled) {
 }
 
 float s2r_last_render_ms(s2r_synth *s) {
+    if (s) (void)resident_stop(s);
     if (s && !s->kids.empty()) {                  // the longest of the shards' render kernels
         float worst = -1.0f;
         for (s2r_synth *kid : s->kids) { const float ms = s2r_last_render_ms(kid); if (ms < 0.0f) return -1.0f; if (ms > worst) worst = ms; }
@@ -1425,6 +1601,7 @@ const char *s2r_last_error(const s2r_synth *s) { return s ? s->err.c_str() : "nu
 extern "C" uint32_t s2r_debug_read_stamps(s2r_synth *s, unsigned long long *out, uint32_t max_waves) {
 #if defined(S2R_STAMPS)
     if (!s) return 0;
+    (void)resident_stop(s);
     const uint32_t waves = s->padded_voices / 64u;
     if (hipSetDevice(s->device) != hipSuccess) return 0;
     if (!s->stamps_dev) {
@@ -1449,6 +1626,7 @@ extern "C" uint32_t s2r_debug_read_stamps(s2r_synth *s, unsigned long long *out,
 extern "C" uint32_t s2r_debug_timeline(s2r_synth *s, unsigned long long *out, uint32_t max_launches) {
 #if defined(S2R_STAMPS)
     if (!s) return 0;
+    (void)resident_stop(s);
     if (hipSetDevice(s->device) != hipSuccess) return 0;
     if (!out) {
         if (s->timeline_dev) { (void)hipFree(s->timeline_dev); s->timeline_dev = nullptr; }

@@ -641,6 +641,10 @@ __device__ __forceinline__ void signal_done(const S2rDone &d, uint32_t n_workgro
     if (d.flag == nullptr) return;                               // (uniform over the launch)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's output stores are acknowledged
     __syncthreads();
+    if (n_workgroups == 1u) {                                    // nobody to count: the flag alone (an atomic's round trip less)
+        if (threadIdx.x == 0) __hip_atomic_store(d.flag, d.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     if (threadIdx.x == 0) {
         const uint32_t arrived = __hip_atomic_fetch_add(d.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (arrived + 1u == n_workgroups) {
@@ -702,6 +706,15 @@ inline uint32_t s2r_pick_super_frames(uint32_t n_groups, uint32_t grid, uint32_t
 // group-sum buffers the launch needs: two (a super-chunk's combine overlaps the next one's chunks) unless the fill is one
 __host__ __device__ inline uint32_t s2r_sw_buffers(uint32_t frames, uint32_t super_frames) { return frames > super_frames ? 2u : 1u; }
 
+// What changes from one fill of a handle to the next, as the render kernels' fill loop sees it: the kernel arguments' own
+// values when every fill is a launch; the posted command's when a resident kernel renders fill after fill (s2r_resident_kernel).
+struct FillCtl {
+    uint32_t frames;         // this fill's length (<= the launch's p.frames, which sizes the staging)
+    uint32_t n_events;       // untimed note events applied before the state is loaded (apply_arg_events)
+    const uint32_t *ev;      // [3 * n_events]: voice, flags, pitch bits
+    S2rDone done;            // the fill's completion word
+};
+
 // ---------------------------------------------------------------------------------------
 // The fill's note events when they ride in the kernel arguments (S2rRenderArgs): every wave looks at 64 records per
 // step, one per lane; the few that hit one of its 64 voices are handed to their lane, which rewrites its voice's
@@ -709,17 +722,16 @@ __host__ __device__ inline uint32_t s2r_sw_buffers(uint32_t frames, uint32_t sup
 // (synth.rs:74-75) — before the kernel loads its state.  The host folds a fill's events to at most one record per
 // voice (s2r_host.cpp push_event), so no two lanes of the grid write the same voice.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void apply_arg_events(const S2rRenderArgs &a, uint32_t vi, uint32_t lane) {
-    const S2rRenderParams &p = a.p;
-    if (a.n_events == 0u) return;
+__device__ __forceinline__ void apply_arg_events(const S2rRenderParams &p, uint32_t n_events, const uint32_t *ev, uint32_t vi, uint32_t lane) {
+    if (n_events == 0u) return;
     const uint32_t group = __builtin_amdgcn_readfirstlane(vi >> 6);
     uint32_t my_flags = 0u, my_pitch = 0u;
-    for (uint32_t k0 = 0; k0 < a.n_events; k0 += 64u) {          // wave-uniform
+    for (uint32_t k0 = 0; k0 < n_events; k0 += 64u) {          // wave-uniform
         const uint32_t i = k0 + lane;
-        const bool have = i < a.n_events;
-        const uint32_t ev_voice = have ? a.ev[3u * i] : 0xffffffffu;
-        const uint32_t ev_flags = have ? a.ev[3u * i + 1u] : 0u;
-        const uint32_t ev_pitch = have ? a.ev[3u * i + 2u] : 0u;
+        const bool have = i < n_events;
+        const uint32_t ev_voice = have ? ev[3u * i] : 0xffffffffu;
+        const uint32_t ev_flags = have ? ev[3u * i + 1u] : 0u;
+        const uint32_t ev_pitch = have ? ev[3u * i + 2u] : 0u;
         uint64_t hits = __ballot(ev_voice != 0xffffffffu && (ev_voice >> 6) == group);
         while (hits) {                                           // wave-uniform
             const int src = __builtin_ctzll(hits);
@@ -829,7 +841,7 @@ __device__ __forceinline__ f4 pk_add4(f4 a, f4 b) {
 // additions in the same order as one frame at a time; a loop of dependent 4-byte reads cost every wave ~6 000 cycles per
 // 1 024 frames, tools/stamps.py).  n_groups is a multiple of 4 (four groups per wave), super_frames of 4; the rows'
 // entries past n_sc are read and not used.  bp: the block's row at the super-chunk's first frame, 16-byte aligned.
-__device__ __forceinline__ void combine_groups(const S2rRenderParams &p, const float *sWbuf, uint32_t n_groups, uint32_t super_frames,
+__device__ __forceinline__ void combine_groups(const S2rRenderParams &p, const S2rDone &done, const float *sWbuf, uint32_t n_groups, uint32_t super_frames,
                                                uint32_t n_sc, uint32_t sc0, float *bp_sc, uint32_t tid, uint32_t n_threads) {
     for (uint32_t f = 4u * tid; f < n_sc; f += 4u * n_threads) {
         const float *row = sWbuf + f;
@@ -852,8 +864,8 @@ __device__ __forceinline__ void combine_groups(const S2rRenderParams &p, const f
             for (uint32_t j = 0; j < n; ++j) {
                 const float total = 0.0f + acc[j];
                 const uint32_t fo = sc0 + f + j;
-                if (p.direct_stereo) { out_store(p.done, p.direct_out + 2u * fo, total); out_store(p.done, p.direct_out + 2u * fo + 1u, total); }
-                else out_store(p.done, p.direct_out + fo, total);
+                if (p.direct_stereo) { out_store(done, p.direct_out + 2u * fo, total); out_store(done, p.direct_out + 2u * fo + 1u, total); }
+                else out_store(done, p.direct_out + fo, total);
             }
         }
     }

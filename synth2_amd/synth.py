@@ -162,6 +162,8 @@ def load_library():
         "s2r_device_count": (C.c_uint32, [H]),
         "s2r_double_release_count": (C.c_uint64, [H]),
         "s2r_set_timing": (C.c_int, [H, C.c_int]),
+        "s2r_set_low_latency": (C.c_int, [H, C.c_int]),
+        "s2r_low_latency_active": (C.c_int, [H]),
         "s2r_set_flat_shortcut": (C.c_int, [H, C.c_int]),
         "s2r_set_coeff_stream": (C.c_int, [H, C.c_int]),
         "s2r_last_render_ms": (C.c_float, [H]),
@@ -412,6 +414,15 @@ class Synth:
         events ride in the render kernel's arguments; 2: tables, events always through their own launch; 3 / 4: synonyms
         of 1 / 2"""
         self._check(self.L.s2r_set_coeff_stream(self.h, int(enabled)))
+
+    def set_low_latency(self, enabled=True):
+        """a resident render kernel between sample() calls (small pools, s2r.h: s2r_set_low_latency): the reference's own
+        16-frames-per-call pattern without a launch per call"""
+        self._check(self.L.s2r_set_low_latency(self.h, 1 if enabled else 0))
+
+    @property
+    def low_latency_active(self):
+        return bool(self.L.s2r_low_latency_active(self.h))
 
     def set_timing(self, enabled=True):
         self._check(self.L.s2r_set_timing(self.h, 1 if enabled else 0))
