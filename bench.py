@@ -237,6 +237,31 @@ def cpu_baseline_legs(budget_s):
     return legs
 
 
+def small_fill_leg():
+    """compiles tools/ubench/small_fill.cpp against the in-tree library (g++, two seconds) and runs it as a child process: median and
+    p99 wall time of s2r_fill(16 frames) for 8 voices over 20 000 calls with note events in between, both ways"""
+    import shutil
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    src = os.path.join(here, "tools", "ubench", "small_fill.cpp")
+    exe = os.path.join(here, "tools", "ubench", "_build", "small_fill")
+    gxx = shutil.which("g++")
+    if not gxx or not os.path.exists(src):
+        return {"error": "no g++ or no source"}
+    try:
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        libdir = os.path.join(here, "synth2_amd")
+        subprocess.run([gxx, "-O2", "-std=c++17", "-I", os.path.join(here, "include"), src, "-o", exe, "-L", libdir, "-ls2r", "-Wl,-rpath," + libdir],
+                       check=True, capture_output=True, timeout=120)
+        r = subprocess.run([exe, "--json"], check=True, capture_output=True, timeout=120, text=True)
+        leg = json.loads(r.stdout.strip().splitlines()[-1])
+        leg["caller"] = "C++ over the C ABI (tools/ubench/small_fill.cpp), median of the calls' wall times"
+        leg["real_time_budget_us"] = round(16 / SR * 1e6, 1)
+        return leg
+    except Exception as e:                                        # (a measurement leg: never the bench's failure)
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+
+
 def run_config_leg(name, voices, patch_text, steps, warmup, oversampled=False, bytes_per_voice=BYTES_PER_VOICE_FILL):
     """One more configuration of BASELINE.json timed the way the headline is (N = 1, after it, so that it cannot perturb
     it): the C3 event schedule on `voices` voices of `patch_text`, aged for two periods, `warmup` + `steps` buffers through
@@ -596,6 +621,12 @@ def main():
                                  oversampled=True, bytes_per_voice=40 + 24)
         config_legs.append(leg); del _s
 
+    # ---- the reference's own call pattern (BASELINE configs[0]: 8 voices, Synth::sample per 16 frames, main.rs:138-147): wall time of
+    #      one s2r_fill from a C++ caller over the C ABI, a launch per call and through the resident kernel (s2r_set_low_latency) ----
+    small_fill = None
+    if world == 1 and rank == 0 and not args.no_config_legs:
+        small_fill = small_fill_leg()
+
     if rank == 0:
         value = total * FRAMES * args.steps / dt_max
         kernel_s = kernel_ms * 1e-3
@@ -671,6 +702,8 @@ def main():
         }
         if config_legs is not None:
             out["config_legs"] = config_legs
+        if small_fill is not None:
+            out["small_fill"] = small_fill
         if world > 1:
             out["multi_gpu_note"] = ("this path has not been run on two or more GPUs by its authors (no such box was available to them): "
                                      "tests cover it with N ranks under gloo and with one rank through RCCL")

@@ -55,6 +55,11 @@ def test_fuzz(seed):
     what = "seed %d: %d voices, block %d, groups %d, %d patches (osc/filter %s), sr %d" % (
         seed, voices, block, groups, len(bank), " ".join("%d/%d" % (q.osc_kind, q.lpf_kind) for q in bank), sr)
     rng_age = np.random.RandomState(int(os.environ.get("S2R_FUZZ_BASE", "1000")) * 31 + 7 + seed)   # its own stream: the cases above stay what they were
+    # (round 3) half of the cases ask for the resident kernel (s2r_set_low_latency; its own stream again): it takes the fills of the
+    # pools of one workgroup with a single one-pole patch and stands aside for everything else
+    if np.random.RandomState(int(os.environ.get("S2R_FUZZ_BASE", "1000")) * 17 + 3 + seed).rand() < 0.5:
+        pr.gpu.set_low_latency(True)
+        what += ", low latency"
     for b in range(7):
         if b and rng.rand() < 0.15:                      # checkpoint round trip between two buffers
             pr.gpu.import_state(pr.gpu.export_state())
@@ -203,3 +208,66 @@ def test_fuzz_shards(seed):
 
 
 SR = 48000
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("S2R_FUZZ_SEEDS", "40")) * 3 // 4)))
+def test_fuzz_low_latency(seed):
+    """the resident kernel (s2r_set_low_latency) under the reference's call pattern: pools of one workgroup, a random
+    one-pole patch, many short fills with note events in between — some more than a command holds — and, now and then,
+    everything that makes the kernel stand aside: checkpoints, a new patch, per-voice rows, stereo, another sample
+    rate, a pause longer than its idle limit"""
+    import time
+    rng = np.random.RandomState(int(os.environ.get("S2R_FUZZ_BASE", "1000")) * 13 + 5 + seed)
+    voices = int(rng.choice([8, 8, 64, 100, 256]))
+    block = int(rng.choice([0, 0, 256, 128, 64]))
+    while block and block < voices:
+        block *= 2
+    max_frames = int(rng.choice([1024, 2048, 64]))
+
+    def onepole_patch():
+        q = random_patch(rng)
+        q.lpf_kind = 0
+        q.osc_kind = int(rng.randint(0, 4))
+        return q
+    patch = onepole_patch()
+    seeds = rng.randint(0, 2 ** 31, voices).astype(np.uint64) if rng.rand() < 0.1 else None
+    pr = Pair(voices, patch, max_frames=max_frames, block_voices=block, seeds=seeds)
+    pr.gpu.set_low_latency(True)
+    sr = int(rng.choice([48000, 48000, 44100, 96000]))
+    held = []
+    what = "seed %d: %d voices, block %d, osc %d, sr %d" % (seed, voices, block, patch.osc_kind, sr)
+    resident_fills = 0
+    for b in range(80):
+        r = rng.rand()
+        if r < 0.04:
+            pr.gpu.import_state(pr.gpu.export_state())
+        elif r < 0.07:
+            patch = onepole_patch()
+            pr.gpu.set_patch(patch); pr.cpu.config = oracle_cfg_from_patch(patch)
+        elif r < 0.09:
+            sr = int(rng.choice([48000, 44100, 22050]))
+        elif r < 0.11:
+            t = time.perf_counter()
+            while time.perf_counter() - t < 0.0015:
+                pass
+        n_ev = int(rng.choice([0, 0, 0, 1, 1, 2, 3, 12])) if b else int(rng.randint(1, voices + 3))
+        for _ in range(n_ev):
+            if (not held) or rng.rand() < 0.6:
+                note = int(rng.randint(20, 110)); held.append(note); pr.note_on(note)
+            else:
+                pr.note_off(held.pop(int(rng.randint(len(held)))))
+        frames = min(max_frames, int(rng.choice([16, 16, 16, 16, 32, 48, 100, 1, 17, max_frames])))
+        with np.errstate(all="ignore"):
+            kind = rng.rand()
+            if kind < 0.05:
+                g, o = pr.render_voices(frames, sr)
+            elif kind < 0.15:
+                gs = pr.gpu.sample_stereo(frames, sr)
+                o = s2o.mix_tree(pr.cpu.render_voices(frames, sr), pr.block_voices, pr.groups)
+                assert_bits_equal(gs[:, 1], o, what + ", fill %d (%d frames, stereo, right)" % (b, frames))
+                g = gs[:, 0]
+            else:
+                g, o, _pv = pr.sample(frames, sr)
+        assert_bits_equal(g, o, what + ", fill %d (%d frames)" % (b, frames))
+        resident_fills += int(pr.gpu.low_latency_active)
+    assert resident_fills >= 20, (what, resident_fills)

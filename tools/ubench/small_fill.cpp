@@ -12,7 +12,10 @@
 
 static void die(s2r_synth *s, const char *what, int rc) { std::fprintf(stderr, "%s: %d %s\n", what, rc, s ? s2r_last_error(s) : ""); std::exit(1); }
 
-int main() {
+int main(int argc, char **argv) {
+    const bool json = argc > 1 && std::strcmp(argv[1], "--json") == 0;       // bench.py's small_fill leg: one line for 8 voices
+    double med[2][2] = {{0, 0}, {0, 0}}, p99[2][2] = {{0, 0}, {0, 0}};
+    int vi = 0;
     for (uint32_t voices : {8u, 256u}) {
         for (int lowlat = 0; lowlat < 2; lowlat++) {
             s2r_config cfg;
@@ -34,10 +37,14 @@ int main() {
             }
             std::sort(us.begin(), us.end());
             double sum = 0; for (double v : us) sum += v;
-            std::printf("%4u voices, 16-frame s2r_fill from C++, %-16s mean %5.2f us, median %5.2f, p10 %5.2f, p99 %5.2f, max %6.1f   (last sample %g)\n", voices,
+            med[vi][lowlat] = us[us.size() / 2]; p99[vi][lowlat] = us[us.size() * 99 / 100];
+            if (!json) std::printf("%4u voices, 16-frame s2r_fill from C++, %-16s mean %5.2f us, median %5.2f, p10 %5.2f, p99 %5.2f, max %6.1f   (last sample %g)\n", voices,
                         lowlat ? "resident kernel:" : "launch per call:", sum / us.size(), us[us.size() / 2], us[us.size() / 10], us[us.size() * 99 / 100], us.back(), buf[15]);
             s2r_destroy(s);
         }
+        vi++;
     }
+    if (json) std::printf("{\"voices\": 8, \"frames\": 16, \"calls\": 20000, \"launch_per_call_us\": %.2f, \"launch_per_call_p99_us\": %.2f, \"resident_kernel_us\": %.2f, "
+                          "\"resident_kernel_p99_us\": %.2f, \"voices_256_resident_kernel_us\": %.2f}\n", med[0][0], p99[0][0], med[0][1], p99[0][1], med[1][1]);
     return 0;
 }
