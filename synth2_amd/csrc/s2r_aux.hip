@@ -78,6 +78,11 @@ __global__ void __launch_bounds__(256) s2r_noise_table_kernel(float *t) {
 constexpr uint32_t kMixRun = 16;
 
 __device__ __forceinline__ void mix_body(const S2rMixParams &m, uint32_t block, float *s_run) {
+    const bool ov = m.ov_render_counter != nullptr;              // two streams: the rows' render kernel runs beside this launch
+    if (ov) {
+        if (threadIdx.x == 0 && !ov_wait(m.ov_render_counter, m.ov_render_target)) ov_raise(m.ov_fail);
+        __syncthreads();
+    }
     const uint32_t f_local = threadIdx.x & 15u, slot = threadIdx.x >> 4;
     const uint32_t f = block * 16u + f_local;
     const uint32_t runs_per_group = (m.blocks_per_group + kMixRun - 1) / kMixRun;
@@ -90,7 +95,10 @@ __device__ __forceinline__ void mix_body(const S2rMixParams &m, uint32_t block, 
             const uint32_t b0 = gb0 + rg * kMixRun;
             float v[kMixRun];
 #pragma unroll
-            for (uint32_t j = 0; j < kMixRun; ++j) v[j] = (b0 + j < gb1) ? m.block_partials[(size_t)(b0 + j) * m.frames_stride + f] : 0.0f;
+            for (uint32_t j = 0; j < kMixRun; ++j) {
+                const float *src = m.block_partials + (size_t)(b0 + j) * m.frames_stride + f;
+                v[j] = (b0 + j < gb1) ? (ov ? ov_load(src) : *src) : 0.0f;
+            }
             float acc = v[0];
 #pragma unroll
             for (uint32_t j = 1; j < kMixRun; ++j) if (b0 + j < gb1) acc += v[j];
@@ -157,15 +165,25 @@ __global__ void s2r_decimate4_history_kernel(float *x, uint32_t n_out) {
 // the render kernel follow per-voice chains through them, and a PCIe round trip per hop is what they cannot afford
 // (It touches no voice state — a chain's first record that sits at frame 0, the fill's folded untimed events, is applied
 // by the render kernel's prologue — so the host may run it beside the previous fill's render kernel.)
-__device__ __forceinline__ void heads_body(int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n, uint32_t i) {
+// (`ov`: two streams — the copy and the heads are handed to a render kernel that may already be running: write-through stores)
+__device__ __forceinline__ void heads_body(int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n, uint32_t i, bool ov) {
     if (i >= n) return;
     const S2rTimedEvent e = tev[i];
-    tev_copy[i] = e;
-    if (e.flags & S2R_TEV_FIRST) heads[e.voice] = (int32_t)i;
+    if (ov) {
+        static_assert(sizeof(S2rTimedEvent) == 32, "two 16-byte stores");
+        float *dst = reinterpret_cast<float *>(tev_copy + i);
+        ov_store4(dst, (f4){s2r_u2f(e.voice), s2r_u2f(e.frame), s2r_u2f(e.flags), e.pitch});
+        ov_store4(dst + 4, (f4){s2r_u2f(e.seed), s2r_u2f((uint32_t)e.next), s2r_u2f(e.program), 0.0f});
+        if (e.flags & S2R_TEV_FIRST) ov_store(heads + e.voice, (int32_t)i);
+    } else {
+        tev_copy[i] = e;
+        if (e.flags & S2R_TEV_FIRST) heads[e.voice] = (int32_t)i;
+    }
 }
 
-__global__ void s2r_tev_heads_kernel(int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n) {
-    heads_body(heads, tev, tev_copy, n, blockIdx.x * blockDim.x + threadIdx.x);
+__global__ void s2r_tev_heads_kernel(int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n, uint32_t *ov_heads_counter) {
+    heads_body(heads, tev, tev_copy, n, blockIdx.x * blockDim.x + threadIdx.x, ov_heads_counter != nullptr);
+    if (ov_heads_counter != nullptr) ov_signal(ov_heads_counter);
 }
 
 // Between two render kernels of a caller with several fills in flight: the PREVIOUS fill's mix (its first `mix_blocks`
@@ -176,7 +194,10 @@ __global__ void __launch_bounds__(256) s2r_mix_and_heads_kernel(const S2rMixPara
     extern __shared__ float s_run[];
     tl_mark(m.timeline, m.tl_slot, 0);
     if (blockIdx.x < mix_blocks) mix_body(m, blockIdx.x, s_run);
-    else heads_body(heads, tev, tev_copy, n, (blockIdx.x - mix_blocks) * blockDim.x + threadIdx.x);
+    else {
+        heads_body(heads, tev, tev_copy, n, (blockIdx.x - mix_blocks) * blockDim.x + threadIdx.x, m.ov_heads_counter != nullptr);
+        if (m.ov_heads_counter != nullptr) ov_signal(m.ov_heads_counter);
+    }
     tl_mark(m.timeline, m.tl_slot, 1);
 }
 
@@ -271,7 +292,7 @@ hipError_t s2r_launch_mix(const S2rMixParams &m, hipStream_t stream) {
 
 hipError_t s2r_launch_mix_and_heads(const S2rMixParams &m, int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n,
                                     hipStream_t stream) {
-    if (m.frames == 0) return s2r_launch_tev_heads(heads, tev, tev_copy, n, stream);
+    if (m.frames == 0) return s2r_launch_tev_heads(heads, tev, tev_copy, n, stream, m.ov_heads_counter);
     if (n == 0) return s2r_launch_mix(m, stream);
     const uint32_t runs_per_group = (m.blocks_per_group + kMixRun - 1) / kMixRun;
     const size_t lds = (size_t)runs_per_group * m.n_groups * 16u * sizeof(float);
@@ -287,9 +308,10 @@ hipError_t s2r_launch_events(const S2rVoiceArrays &v, const S2rVoiceEvent *dev_e
     return hipGetLastError();
 }
 
-hipError_t s2r_launch_tev_heads(int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n, hipStream_t stream) {
+hipError_t s2r_launch_tev_heads(int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n, hipStream_t stream,
+                                uint32_t *ov_heads_counter) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(s2r_tev_heads_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, heads, tev, tev_copy, n);
+    hipLaunchKernelGGL(s2r_tev_heads_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, heads, tev, tev_copy, n, ov_heads_counter);
     return hipGetLastError();
 }
 

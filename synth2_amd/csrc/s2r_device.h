@@ -141,6 +141,12 @@ struct S2rRenderParams {
     // patch bank (bank_size > 1: s2r_render_general_kernel<ANY, true>; the fields above then hold patch 0)
     const S2rBankEntry *bank;
     uint32_t bank_size;
+    // Fills in flight on two streams (S2rOverlap below; the one-pole kernel): this launch waits for its chain heads, built
+    // by a kernel on the other stream, and counts its workgroups in for the mix that waits there.  nullptr: not used.
+    const uint32_t *ov_heads_counter;
+    uint32_t ov_heads_target;
+    uint32_t *ov_render_counter;
+    uint32_t *ov_fail;
 };
 
 // Coalesced note events, one record per touched voice per fill (host folds the event
@@ -219,6 +225,17 @@ struct S2rTabBuild {
     uint32_t fm_plane;
 };
 
+// Two fills in flight on TWO streams (s2r_fill_begin / s2r_fill_end).  Between the render kernels of
+// consecutive fills the stream used to run the previous fill's mix and this fill's chain heads (3 us and two kernel
+// boundaries per step).  Both now run on a second stream, beside the render kernels, and what orders them is in device
+// memory: a counter of workgroups per buffer parity that have finished the chain heads (the render kernel of that fill
+// waits for it before it looks at its voices' chains) and one of render workgroups that have written their partial row
+// (the mix waits for it).  Counters only grow; the host hands every waiter the value to wait for.  Every wait is
+// bounded (50 ms of the device clock): a waiter that gives up raises `fail` (mapped host memory) and goes on, and the
+// host reports the fill as failed — nothing spins for ever.  Heads, event copies and partial rows are double-buffered by
+// the fill's parity (at most two fills are in flight).
+struct S2rOverlapWords { uint32_t render_done[2], heads_done[2]; };
+
 struct S2rMixParams {
     const float *block_partials;  // [n_blocks][frames_stride]
     uint32_t n_blocks;
@@ -230,6 +247,10 @@ struct S2rMixParams {
     int32_t stereo;               // 1: write interleaved L,R (audio_player.rs:224-228)
     float *out;
     S2rDone done;                 // told to the host when `out` (mapped host memory) is complete
+    const uint32_t *ov_render_counter;   // S2rOverlap: wait until *counter reaches ov_render_target before reading the rows
+    uint32_t ov_render_target;
+    uint32_t *ov_heads_counter;   // ... and (s2r_mix_and_heads_kernel) every chain-heads workgroup counts itself in here
+    uint32_t *ov_fail;
     unsigned long long *timeline; // diagnostic builds only: as S2rRenderParams.timeline
     uint32_t tl_slot;
 };
@@ -243,7 +264,8 @@ hipError_t s2r_launch_mix(const S2rMixParams &p, hipStream_t stream);
 hipError_t s2r_launch_events(const S2rVoiceArrays &v, const S2rVoiceEvent *dev_events, uint32_t n, hipStream_t stream);
 hipError_t s2r_launch_mix_and_heads(const S2rMixParams &m, int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n,
                                     hipStream_t stream);
-hipError_t s2r_launch_tev_heads(int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n, hipStream_t stream);
+hipError_t s2r_launch_tev_heads(int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n, hipStream_t stream,
+                                uint32_t *ov_heads_counter = nullptr);
 // build-defined 4x decimator: x = 62 samples of history + 4 * n_out new ones, h = 63 taps (device), and the
 // last 62 inputs copied to the front of x afterwards (second launch) for the next call
 hipError_t s2r_launch_decimate4(float *x_with_history, const float *taps, uint32_t n_out, float *out, hipStream_t stream);

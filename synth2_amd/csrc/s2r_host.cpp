@@ -164,7 +164,18 @@ struct s2r_synth {
     uint32_t ring_head = 0, ring_count = 0;
     // s2r_fill_begin leaves its fill's mix to the NEXT s2r_fill_begin, which launches it together with its own chain
     // heads (s2r_mix_and_heads_kernel: one launch boundary less per buffer), or to s2r_fill_end, whichever comes first
-    struct DeferredMix { bool active = false; S2rMixParams m{}; int ring_slot = -1; } dmix;
+    struct DeferredMix { bool active = false; bool overlap = false; S2rMixParams m{}; int ring_slot = -1; } dmix;
+    // Two streams for the fills of s2r_fill_begin (S2rOverlapWords, s2r_device.h): the mixes and the chain heads run on
+    // stream_b beside the render kernels on `stream`; [1] of each pair is the second buffer (by the fill's parity)
+    hipStream_t stream_b = nullptr;
+    bool ov_enabled = false;                     // stream_b and the second buffers exist (S2R_OVERLAP=0 leaves them out)
+    bool ov_busy = false;                        // kernels of an overlapped fill may still be running on stream_b
+    float *partials2[2] = {nullptr, nullptr};
+    int32_t *heads2[2] = {nullptr, nullptr};
+    S2rTimedEvent *tevcopy2[2] = {nullptr, nullptr};
+    S2rOverlapWords *ov_words = nullptr;         // device memory
+    uint32_t ov_render_target[2] = {0, 0}, ov_heads_target[2] = {0, 0};
+    uint32_t ov_fill = 0;                        // overlapped fills begun so far: the next one's parity is its low bit
     float *os_buf = nullptr, *os_taps = nullptr; // 4x oversampling: [62 history + max_frames] mix at 4x rate, 63 taps
     float *sin_dev = nullptr;
     float *noise_dev = nullptr;                  // the noise table (S2rRenderParams.noise_tab), 65 536 floats
@@ -270,7 +281,19 @@ void push_event(s2r_synth *top, uint32_t pool_index, uint32_t flags, float pitch
 int launch_deferred_mix(s2r_synth *s, hipStream_t stream) {
     if (!s->dmix.active) return S2R_OK;
     s->dmix.active = false;
-    S2R_HIP(s, s2r_launch_mix(s->dmix.m, stream));
+    // (an overlapped fill's mix waits in the kernel for its rows: it goes to the second stream wherever it is launched from)
+    S2R_HIP(s, s2r_launch_mix(s->dmix.m, s->dmix.overlap ? s->stream_b : stream));
+    return S2R_OK;
+}
+
+// Leaves the two-stream mode: the last overlapped fill's mix is launched and both streams are waited for, so that whatever
+// follows on `stream` alone finds the partial rows, the chain heads and the event copies free.
+int overlap_drain(s2r_synth *s) {
+    if (!s->ov_busy) return S2R_OK;
+    if (s->dmix.active && s->dmix.overlap) { int rc = launch_deferred_mix(s, s->stream); if (rc != S2R_OK) return rc; }
+    S2R_HIP(s, hipStreamSynchronize(s->stream));
+    S2R_HIP(s, hipStreamSynchronize(s->stream_b));
+    s->ov_busy = false;
     return S2R_OK;
 }
 
@@ -283,13 +306,17 @@ int slot_release(s2r_synth *s, EventSlot &sl) {
         int rc = launch_deferred_mix(s, s->stream);
         if (rc != S2R_OK) return rc;
         S2R_HIP(s, hipStreamSynchronize(s->stream));
+        if (s->ov_busy) S2R_HIP(s, hipStreamSynchronize(s->stream_b));
     }
     sl.state = 0;
     return S2R_OK;
 }
 
 // `done`: the completion word of the fill these events belong to (nullptr: none; the slot is then guarded by an event)
-int flush_events(s2r_synth *s, hipStream_t stream, EventSlot **timed_slot, const S2rTimedEvent **tev_dev, const S2rDone *done = nullptr) {
+// `ov_parity` >= 0: the fill is an overlapped one (two streams): its chain heads and event copy go to that parity's buffers,
+// built on stream_b, and count themselves in for the render kernel that waits for them
+int flush_events(s2r_synth *s, hipStream_t stream, EventSlot **timed_slot, const S2rTimedEvent **tev_dev, const S2rDone *done = nullptr,
+                 int ov_parity = -1) {
     *timed_slot = nullptr; *tev_dev = nullptr;
     if (s->pending.empty() && s->tpending.empty()) return S2R_OK;
     EventSlot &sl = s->slots[s->next_slot];
@@ -328,6 +355,7 @@ int flush_events(s2r_synth *s, hipStream_t stream, EventSlot **timed_slot, const
         // old buffers is waited for first)
         S2R_HIP(s, hipStreamSynchronize(stream));
         S2R_HIP(s, hipStreamSynchronize(s->stream));
+        if (s->stream_b) S2R_HIP(s, hipStreamSynchronize(s->stream_b));
         uint32_t cap = s->tev_capacity;
         while (cap < nt) cap *= 2u;
         for (EventSlot &e : s->slots) {
@@ -338,17 +366,37 @@ int flush_events(s2r_synth *s, hipStream_t stream, EventSlot **timed_slot, const
         }
         S2R_HIP(s, hipFree(s->tev_copy)); s->tev_copy = nullptr;
         S2R_HIP(s, hipMalloc((void **)&s->tev_copy, (size_t)cap * sizeof(S2rTimedEvent)));
+        s->tevcopy2[0] = s->tev_copy;
+        if (s->ov_enabled) {
+            S2R_HIP(s, hipFree(s->tevcopy2[1])); s->tevcopy2[1] = nullptr;
+            S2R_HIP(s, hipMalloc((void **)&s->tevcopy2[1], (size_t)cap * sizeof(S2rTimedEvent)));
+        }
         s->tev_capacity = cap;
     }
     if (nt) {
         std::memcpy(sl.thost, s->tpending.data(), nt * sizeof(S2rTimedEvent));
-        if (s->dmix.active && stream == s->stream) {           // the previous fill's mix rides with this fill's chain heads
+        if (ov_parity >= 0) {
+            // two streams: the chain heads (and, with them, the previous overlapped fill's mix, which waits for its rows in
+            // the kernel) on stream_b, beside whatever render kernel is running
+            uint32_t *hc = &s->ov_words->heads_done[ov_parity];
+            s->ov_heads_target[ov_parity] += (nt + 255u) / 256u;
+            if (s->dmix.active && s->dmix.overlap) {
+                s->dmix.active = false;
+                S2rMixParams m = s->dmix.m;
+                m.ov_heads_counter = hc;
+                S2R_HIP(s, s2r_launch_mix_and_heads(m, s->heads2[ov_parity], sl.tdev, s->tevcopy2[ov_parity], nt, s->stream_b));
+            } else {
+                S2R_HIP(s, s2r_launch_tev_heads(s->heads2[ov_parity], sl.tdev, s->tevcopy2[ov_parity], nt, s->stream_b, hc));
+            }
+            *timed_slot = &sl; *tev_dev = s->tevcopy2[ov_parity];
+        } else if (s->dmix.active && stream == s->stream) {    // the previous fill's mix rides with this fill's chain heads
             s->dmix.active = false;
             S2R_HIP(s, s2r_launch_mix_and_heads(s->dmix.m, s->voice_ev_head, sl.tdev, s->tev_copy, nt, stream));
+            *timed_slot = &sl; *tev_dev = s->tev_copy;         // the kernels read the HBM copy
         } else {
             S2R_HIP(s, s2r_launch_tev_heads(s->voice_ev_head, sl.tdev, s->tev_copy, nt, stream));
+            *timed_slot = &sl; *tev_dev = s->tev_copy;
         }
-        *timed_slot = &sl; *tev_dev = s->tev_copy;         // the kernels read the HBM copy
         for (const S2rTimedEvent &e : s->tpending) s->tlast[e.voice] = -1;
         s->tpending.clear();
     } else if (done) {
@@ -489,6 +537,14 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
         if (rc != S2R_OK) return rc;
         S2R_HIP(s, hipStreamSynchronize(s->stream));
     }
+    // Two streams (S2rOverlapWords): the fills of s2r_fill_begin on our own stream, rendered by the one-pole kernel into
+    // partial rows that a mix will add up.  Anything else first waits for the overlapped fills before it.
+    const bool onepole_kernel = s->bank.size() == 1 && s->bank[0].osc_kind <= S2R_OSC_SINE && s->bank[0].lpf_kind == S2R_FILT_ONEPOLE;
+    const bool overlap = s->ov_enabled && defer_ring_slot >= 0 && stream == s->stream && dev_out != nullptr && root_add && s->n_blocks > 1 &&
+                         per_voice_dev == nullptr && onepole_kernel && done != nullptr;
+    const int ov_parity = overlap ? (int)(s->ov_fill & 1u) : -1;
+    if (!overlap) { int rc = overlap_drain(s); if (rc != S2R_OK) return rc; }
+    else if (s->dmix.active && !s->dmix.overlap) { int rc = launch_deferred_mix(s, stream); if (rc != S2R_OK) return rc; }
     // The common case — a handful of untimed events without seed overrides — needs no launch for them: they ride in
     // the render kernel's arguments and every wave applies the ones that hit its voices before it loads its state.
     bool arg_events = s->use_arg_events && s->tpending.empty() && s->pending.size() <= S2R_ARG_MAX_EVENTS;
@@ -497,7 +553,7 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
     EventSlot *timed_slot = nullptr;
     const S2rTimedEvent *tev_dev = nullptr;
     if (!arg_events) {
-        int rc = flush_events(s, stream, &timed_slot, &tev_dev, done);
+        int rc = flush_events(s, stream, &timed_slot, &tev_dev, done, ov_parity);
         if (rc != S2R_OK) return rc;
     }
     {   // (no chain heads in this fill to take the previous fill's mix along: it goes alone, before the render kernel
@@ -567,6 +623,14 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
     p.per_voice = per_voice_dev;
     p.tev = tev_dev;
     p.voice_ev_head = s->voice_ev_head;
+    if (overlap) {
+        p.block_partials = s->partials2[ov_parity];
+        p.voice_ev_head = s->heads2[ov_parity];
+        if (tev_dev) { p.ov_heads_counter = &s->ov_words->heads_done[ov_parity]; p.ov_heads_target = s->ov_heads_target[ov_parity]; }
+        p.ov_render_counter = &s->ov_words->render_done[ov_parity];
+        p.ov_fail = s->done_dev + 3;
+        s->ov_render_target[ov_parity] += s->n_blocks;
+    }
     a.n_events = 0;
     if (arg_events) {
         a.n_events = (uint32_t)s->pending.size();
@@ -600,7 +664,15 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
         m.out = dev_out;
         if (done) m.done = *done;
         if (s->timeline_dev && s->timeline_n < s->timeline_cap) { m.timeline = s->timeline_dev; m.tl_slot = s->timeline_n++; }
-        if (defer_ring_slot >= 0 && stream == s->stream) { s->dmix.active = true; s->dmix.m = m; s->dmix.ring_slot = defer_ring_slot; }
+        if (overlap) {
+            m.block_partials = s->partials2[ov_parity];
+            m.ov_render_counter = &s->ov_words->render_done[ov_parity];
+            m.ov_render_target = s->ov_render_target[ov_parity];
+            m.ov_fail = s->done_dev + 3;
+            s->ov_fill++;
+            s->ov_busy = true;
+        }
+        if (defer_ring_slot >= 0 && stream == s->stream) { s->dmix.active = true; s->dmix.overlap = overlap; s->dmix.m = m; s->dmix.ring_slot = defer_ring_slot; }
         else S2R_HIP(s, s2r_launch_mix(m, stream));
     }
     if (!s->parent) {                             // (a device-list handle moves the shared clock once, after its shards)
@@ -669,8 +741,16 @@ int wait_done(s2r_synth *s, uint32_t idx, uint32_t seq) {
         }
     }
     S2R_HIP(s, hipStreamSynchronize(s->stream));
+    if (s->stream_b) S2R_HIP(s, hipStreamSynchronize(s->stream_b));
     if ((int32_t)(*f - seq) < 0) return set_err(s, S2R_ERR_HIP, "the fill's last kernel finished without signalling completion");
     return S2R_OK;
+}
+
+// (two streams) a kernel that gave up waiting for the other stream's work says so in done_host[3]
+int overlap_check(s2r_synth *s) {
+    if (*(volatile uint32_t *)(s->done_host + 3) == 0u) return S2R_OK;
+    s->done_host[3] = 0u;
+    return set_err(s, S2R_ERR_HIP, "a kernel of a fill gave up waiting for the other stream's (S2rOverlapWords): the fill's output is not valid");
 }
 
 // the fill of any handle on ITS stream: the final mix (root-added) lands in `dev_out`
@@ -817,6 +897,7 @@ void release_all(s2r_synth *s) {
     s->kids.clear();
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->stream_b) (void)hipStreamSynchronize(s->stream_b);
     for (int b = 0; b < 2; b++) {
         if (s->rows_dev[b]) (void)hipFree(s->rows_dev[b]);
         for (hipEvent_t e : s->kid_done[b]) if (e) (void)hipEventDestroy(e);
@@ -847,6 +928,11 @@ void release_all(s2r_synth *s) {
     if (s->per_voice_dev) (void)hipFree(s->per_voice_dev);
     if (s->voice_ev_head) (void)hipFree(s->voice_ev_head);
     if (s->tev_copy) (void)hipFree(s->tev_copy);
+    if (s->partials2[1]) (void)hipFree(s->partials2[1]);
+    if (s->heads2[1]) (void)hipFree(s->heads2[1]);
+    if (s->tevcopy2[1]) (void)hipFree(s->tevcopy2[1]);
+    if (s->ov_words) (void)hipFree(s->ov_words);
+    if (s->stream_b) (void)hipStreamDestroy(s->stream_b);
     if (s->tab_dev) (void)hipFree(s->tab_dev);
     if (s->stamps_dev) (void)hipFree(s->stamps_dev);
     if (s->timeline_dev) (void)hipFree(s->timeline_dev);
@@ -983,6 +1069,20 @@ static int create_single(const s2r_config *cfg, std::shared_ptr<S2rVoicePool> po
     CREATE_HIP(hipMalloc((void **)&s->voice_ev_head, pv * sizeof(int32_t)));
     CREATE_HIP(hipMalloc((void **)&s->tev_copy, (size_t)s->tev_capacity * sizeof(S2rTimedEvent)));
     CREATE_HIP(hipMemsetAsync(s->voice_ev_head, 0xff, pv * sizeof(int32_t), s->stream));
+    s->partials2[0] = s->block_partials; s->heads2[0] = s->voice_ev_head; s->tevcopy2[0] = s->tev_copy;
+    {   // two streams for the fills of s2r_fill_begin (S2rOverlapWords): shards of more than one workgroup; S2R_OVERLAP=0: off
+        const char *e = std::getenv("S2R_OVERLAP");
+        if (s->n_blocks > 1 && !(e && e[0] == '0')) {
+            CREATE_HIP(hipStreamCreateWithFlags(&s->stream_b, hipStreamNonBlocking));
+            CREATE_HIP(hipMalloc((void **)&s->partials2[1], (size_t)s->n_blocks * partials_stride(cfg->max_frames) * sizeof(float)));
+            CREATE_HIP(hipMalloc((void **)&s->heads2[1], pv * sizeof(int32_t)));
+            CREATE_HIP(hipMemsetAsync(s->heads2[1], 0xff, pv * sizeof(int32_t), s->stream));
+            CREATE_HIP(hipMalloc((void **)&s->tevcopy2[1], (size_t)s->tev_capacity * sizeof(S2rTimedEvent)));
+            CREATE_HIP(hipMalloc((void **)&s->ov_words, sizeof(S2rOverlapWords)));
+            CREATE_HIP(hipMemsetAsync(s->ov_words, 0, sizeof(S2rOverlapWords), s->stream));
+            s->ov_enabled = true;
+        }
+    }
     CREATE_HIP(hipEventCreate(&s->t0));
     CREATE_HIP(hipEventCreate(&s->t1));
     {
@@ -1302,6 +1402,7 @@ int s2r_fill_end(s2r_synth *s, float *mono_out, size_t capacity) {
     }
     if (s->ring_seq[slot]) { int rc = wait_done(s, slot, s->ring_seq[slot]); if (rc != S2R_OK) return rc; }
     else S2R_HIP(s, hipEventSynchronize(s->ring_done[slot]));
+    { int rc = overlap_check(s); if (rc != S2R_OK) return rc; }
     if (s->ring_frames[slot]) std::memcpy(mono_out, s->ring_host[slot], s->ring_frames[slot] * sizeof(float));
     s->ring_head ^= 1u;
     s->ring_count--;

@@ -654,6 +654,41 @@ __device__ __forceinline__ void signal_done(const S2rDone &d, uint32_t n_workgro
     }
 }
 
+// Two streams (S2rOverlapWords, s2r_device.h): data handed from the workgroups of one kernel to those of another that runs
+// beside it, possibly on another XCD, whose L2 is not coherent with this one's.  The form used is the write-through one of
+// MI355X_MICROARCH.md ("Valid forms", first row of its table; measured on gfx950, cheaper by microseconds per workgroup
+// than an agent-scope release fence, which writes back the XCD's whole L2):
+//   producer  EVERY handed-off byte is stored `sc1` (ov_store / ov_store4: write-through, the line leaves this L2); every
+//             storing wave waits for its stores (`s_waitcnt vmcnt(0)`); a workgroup barrier; ONE lane adds to the counter
+//             (agent-scope atomic) — ov_signal, called by every thread of the workgroup;
+//   consumer  ONE lane polls the counter with relaxed `sc1` loads (ov_wait; a few polls per microsecond per workgroup: the
+//             pollers must not eat the fabric) until it has reached the value the host computed — counters only grow, the
+//             comparison survives their wrap; a workgroup barrier (the caller's); then EVERY load of the handed-off bytes
+//             is an `sc1` load (ov_load), never a plain one.
+// Every wait is bounded: 50 ms of the device's 100 MHz clock, then the waiter raises the fill's `fail` word and goes on.
+__device__ __forceinline__ bool ov_wait(const uint32_t *counter, uint32_t target) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int32_t)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 5000000ull) return false;
+        __builtin_amdgcn_s_sleep(100);
+    }
+    return true;
+}
+__device__ __forceinline__ void ov_signal(uint32_t *counter) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ov_raise(uint32_t *fail) {
+    if (fail) __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+template <typename T> __device__ __forceinline__ T ov_load(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T> __device__ __forceinline__ void ov_store(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// sixteen bytes with one write-through store (a dword store of this kind is one fabric write each: six times the time per byte)
+__device__ __forceinline__ void ov_store4(float *p, f4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+
 // minimum of a value over the wavefront, in a scalar register: four DPP row shifts, two row broadcasts (the classic
 // GFX9 reduction; ~35 cycles of issue for a lone wave where a ballot round trip costs ~50 and answers less)
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
@@ -858,7 +893,10 @@ __device__ __forceinline__ void combine_groups(const S2rRenderParams &p, const S
             acc = pk_add4(pk_add4(pk_add4(pk_add4(acc, v0), v1), v2), v3);
         }
         const uint32_t n = n_sc - f < 4u ? n_sc - f : 4u;
-        if (n == 4u) *reinterpret_cast<f4 *>(bp_sc + f) = acc;
+        if (p.ov_render_counter != nullptr) {                    // two streams: the row is handed to a mix that runs beside this kernel
+            if (n == 4u) ov_store4(bp_sc + f, acc);
+            else for (uint32_t j = 0; j < n; ++j) ov_store(bp_sc + f + j, acc[j]);
+        } else if (n == 4u) *reinterpret_cast<f4 *>(bp_sc + f) = acc;
         else for (uint32_t j = 0; j < n; ++j) bp_sc[f + j] = acc[j];
         if (p.direct_out) {                                      // one workgroup: this IS the mix
             for (uint32_t j = 0; j < n; ++j) {

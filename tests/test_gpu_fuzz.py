@@ -271,3 +271,88 @@ def test_fuzz_low_latency(seed):
         assert_bits_equal(g, o, what + ", fill %d (%d frames)" % (b, frames))
         resident_fills += int(pr.gpu.low_latency_active)
     assert resident_fills >= 20, (what, resident_fills)
+
+
+def _oracle_buffer(pr, ev, frames, sr):
+    """the oracle's buffer for a fill with the (possibly timed) events `ev`: events applied between 16-frame sample() calls"""
+    pv = np.zeros((pr.cpu.num_voices, frames), dtype=np.float32)
+    k = 0
+    for c in range(0, frames, 16):
+        while k < len(ev) and ev["frame"][k] == c:
+            if ev["kind"][k] == 1:
+                pr.cpu.note_on(int(ev["note"][k]))
+            else:
+                pr.cpu.note_off(int(ev["note"][k]))
+            k += 1
+        n = min(16, frames - c)
+        with np.errstate(all="ignore"):
+            pv[:, c:c + n] = pr.cpu.render_voices(n, sr)
+    assert k == len(ev)
+    return s2o.mix_tree(pv, pr.block_voices, pr.groups)
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("S2R_FUZZ_SEEDS", "40")) // 2)))
+def test_fuzz_two_buffers_in_flight(seed):
+    """s2r_fill_begin / s2r_fill_end with up to two buffers in flight — for the one-pole kernel on two streams (the mixes and
+    the chain heads beside the render kernels), for the other kernels on one — against the oracle, buffer by
+    buffer: timed and untimed events, fills of any length, and now and then what makes the two-stream mode stand aside (a
+    synchronous fill, per-voice rows, a checkpoint, a new patch)."""
+    rng = np.random.RandomState(int(os.environ.get("S2R_FUZZ_BASE", "1000")) * 19 + 11 + seed)
+    voices = int(rng.choice([300, 1000, 2048]))
+    block = int(rng.choice([0, 64, 128, 256]))
+    groups = int(rng.choice([0, 0, 2]))
+    max_frames = int(rng.choice([1024, 2048]))
+    patch = random_patch(rng)
+    if rng.rand() < 0.7:
+        patch.lpf_kind = 0; patch.osc_kind = int(rng.randint(0, 4))       # the one-pole kernel: two streams
+    pr = Pair(voices, patch, max_frames=max_frames, block_voices=block, mix_groups=groups)
+    sr = int(rng.choice([48000, 48000, 44100]))
+    what = "seed %d: %d voices, block %d, groups %d, osc/filter %d/%d, sr %d" % (seed, voices, block, groups, patch.osc_kind, patch.lpf_kind, sr)
+    held = []
+    queue = []                                                   # (index, frames, the oracle's buffer) of the fills in flight
+
+    def end_one():
+        k, frames, want = queue.pop(0)
+        got = pr.gpu.sample_end(np.empty(frames, dtype=np.float32))
+        assert_bits_equal(got, want, what + ", buffer %d (%d frames)" % (k, frames))
+
+    for b in range(24):
+        r = rng.rand()
+        if b and r < 0.12:
+            while queue:
+                end_one()
+            kind = rng.rand()
+            if kind < 0.3:
+                g, o, _pv = pr.sample(int(rng.choice([16, 100, 1024])), sr)
+                assert_bits_equal(g, o, what + ", synchronous fill before buffer %d" % b)
+            elif kind < 0.5:
+                g, o = pr.render_voices(64, sr)
+                assert_bits_equal(g, o, what + ", per-voice rows before buffer %d" % b)
+            elif kind < 0.75:
+                pr.gpu.import_state(pr.gpu.export_state())
+            else:
+                patch = random_patch(rng)
+                if rng.rand() < 0.7:
+                    patch.lpf_kind = 0; patch.osc_kind = int(rng.randint(0, 4))
+                pr.gpu.set_patch(patch); pr.cpu.config = oracle_cfg_from_patch(patch)
+                what += " -> %d/%d at buffer %d" % (patch.osc_kind, patch.lpf_kind, b)
+        frames = min(max_frames, int(rng.choice([1024, 1024, 1024, 512, 256, 100, 48, 16])))
+        n_ev = int(rng.randint(0, 40)) if b else int(rng.randint(voices // 2, voices + 5))
+        timed = rng.rand() < 0.6 and frames >= 32
+        times = np.sort(rng.randint(0, frames // 16, n_ev)) * 16 if timed else np.zeros(n_ev, dtype=np.int64)
+        rows = []
+        for t in times:
+            on = (not held) or rng.rand() < 0.6
+            if on:
+                note = int(rng.randint(20, 110)); held.append(note)
+            else:
+                note = held.pop(int(rng.randint(len(held))))
+            rows.append((1 if on else 0, note, int(t), 1.0))
+        ev = np.array(rows, dtype=s2.NOTE_EVENT_DTYPE) if rows else np.zeros(0, dtype=s2.NOTE_EVENT_DTYPE)
+        pr.gpu.note_events(ev)
+        pr.gpu.sample_begin(frames, sr)
+        queue.append((b, frames, _oracle_buffer(pr, ev, frames, sr)))
+        while len(queue) > (1 if rng.rand() < 0.8 else 0):       # usually keep one in flight while the next is prepared
+            end_one()
+    while queue:
+        end_one()
