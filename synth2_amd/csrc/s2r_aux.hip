@@ -80,7 +80,7 @@ constexpr uint32_t kMixRun = 16;
 __device__ __forceinline__ void mix_body(const S2rMixParams &m, uint32_t block, float *s_run) {
     const bool ov = m.ov_render_counter != nullptr;              // two streams: the rows' render kernel runs beside this launch
     if (ov) {
-        if (threadIdx.x == 0 && !ov_wait(m.ov_render_counter, m.ov_render_target)) ov_raise(m.ov_fail);
+        if (threadIdx.x == 0 && !ov_wait(m.ov_render_counter, m.ov_render_target)) ov_raise(m.ov_fail, 2u);
         __syncthreads();
     }
     const uint32_t f_local = threadIdx.x & 15u, slot = threadIdx.x >> 4;

@@ -748,9 +748,11 @@ int wait_done(s2r_synth *s, uint32_t idx, uint32_t seq) {
 
 // (two streams) a kernel that gave up waiting for the other stream's work says so in done_host[3]
 int overlap_check(s2r_synth *s) {
-    if (*(volatile uint32_t *)(s->done_host + 3) == 0u) return S2R_OK;
+    const uint32_t who = *(volatile uint32_t *)(s->done_host + 3);
+    if (who == 0u) return S2R_OK;
     s->done_host[3] = 0u;
-    return set_err(s, S2R_ERR_HIP, "a kernel of a fill gave up waiting for the other stream's (S2rOverlapWords): the fill's output is not valid");
+    return set_err(s, S2R_ERR_HIP, "%s gave up waiting for the other stream's kernel (S2rOverlapWords): the fill's output is not valid",
+                   who == 1u ? "a render kernel (for its chain heads)" : "a mix (for its partial rows)");
 }
 
 // the fill of any handle on ITS stream: the final mix (root-added) lands in `dev_out`
@@ -1071,8 +1073,15 @@ static int create_single(const s2r_config *cfg, std::shared_ptr<S2rVoicePool> po
     CREATE_HIP(hipMemsetAsync(s->voice_ev_head, 0xff, pv * sizeof(int32_t), s->stream));
     s->partials2[0] = s->block_partials; s->heads2[0] = s->voice_ev_head; s->tevcopy2[0] = s->tev_copy;
     {   // two streams for the fills of s2r_fill_begin (S2rOverlapWords): shards of more than one workgroup; S2R_OVERLAP=0: off
+        // Only where the kernels that wait for each other can always be resident TOGETHER: a render grid of at most one
+        // workgroup of at most 256 threads per compute unit takes at most half of every SIMD's registers and of the LDS, so the
+        // chain-heads workgroups it waits for always find room beside it.  (A grid of two workgroups per CU holds every
+        // register: its waiting workgroups would keep out the ones they wait for — seen at 131 072 voices, as the bounded
+        // wait's error.)
         const char *e = std::getenv("S2R_OVERLAP");
-        if (s->n_blocks > 1 && !(e && e[0] == '0')) {
+        int n_cu = 0;
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 0;
+        if (s->n_blocks > 1 && (int)s->n_blocks <= n_cu && s->block_voices <= 256u && !(e && e[0] == '0')) {
             CREATE_HIP(hipStreamCreateWithFlags(&s->stream_b, hipStreamNonBlocking));
             CREATE_HIP(hipMalloc((void **)&s->partials2[1], (size_t)s->n_blocks * partials_stride(cfg->max_frames) * sizeof(float)));
             CREATE_HIP(hipMalloc((void **)&s->heads2[1], pv * sizeof(int32_t)));

@@ -679,8 +679,8 @@ __device__ __forceinline__ void ov_signal(uint32_t *counter) {
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void ov_raise(uint32_t *fail) {
-    if (fail) __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+__device__ __forceinline__ void ov_raise(uint32_t *fail, uint32_t who) {      // who: 1 a render kernel (its chain heads), 2 a mix (its rows)
+    if (fail) __hip_atomic_store(fail, who, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 template <typename T> __device__ __forceinline__ T ov_load(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <typename T> __device__ __forceinline__ void ov_store(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -190,3 +190,26 @@ def test_config3_1048576_voices_as_8_shards_on_one_device():
             acc = acc + part
         assert_bits_equal(out.cpu().numpy(), acc, "rank-ordered sum of the 8 partial rows, buffer %d" % b)
         assert_bits_equal(one.sample(np.empty(F, dtype=np.float32)), acc, "one handle over a device list of 8, buffer %d" % b)
+
+
+def test_two_buffers_in_flight_where_two_workgroups_share_a_compute_unit():
+    """131 072 voices are two render workgroups per compute unit — every register taken: the fills of s2r_fill_begin then
+    stay on ONE stream (on two, the render kernel's waiting workgroups would keep out the chain-heads workgroups they wait
+    for: DESIGN.md 4.2b).  The buffers of s2r_fill_begin / s2r_fill_end with timed events equal those of the same events
+    through s2r_fill, and the smaller pool next to it (one workgroup per unit: two streams) says the same."""
+    import bench
+    for voices in (131072, 65536):
+        cyc = bench.make_c3_events(voices, bench.PERIOD)
+        a = s2.Synth(voices, max_frames=bench.FRAMES)
+        b = s2.Synth(voices, max_frames=bench.FRAMES)
+        pending = []
+        for k in range(10):
+            ev = cyc[k % bench.PERIOD]
+            a.note_events(ev); a.sample_begin(bench.FRAMES, SR)
+            b.note_events(ev)
+            pending.append((k, b.sample(np.empty(bench.FRAMES, dtype=np.float32), SR).copy()))
+            if len(pending) == 2:
+                kk, want = pending.pop(0)
+                assert_bits_equal(a.sample_end(np.empty(bench.FRAMES, dtype=np.float32)), want, "%d voices, buffer %d" % (voices, kk))
+        kk, want = pending.pop(0)
+        assert_bits_equal(a.sample_end(np.empty(bench.FRAMES, dtype=np.float32)), want, "%d voices, buffer %d" % (voices, kk))
