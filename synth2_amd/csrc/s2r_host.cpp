@@ -537,11 +537,10 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
         if (rc != S2R_OK) return rc;
         S2R_HIP(s, hipStreamSynchronize(s->stream));
     }
-    // Two streams (S2rOverlapWords): the fills of s2r_fill_begin on our own stream, rendered by the one-pole kernel into
-    // partial rows that a mix will add up.  Anything else first waits for the overlapped fills before it.
-    const bool onepole_kernel = s->bank.size() == 1 && s->bank[0].osc_kind <= S2R_OSC_SINE && s->bank[0].lpf_kind == S2R_FILT_ONEPOLE;
+    // Two streams (S2rOverlapWords): the fills of s2r_fill_begin on our own stream, rendered into partial rows that a mix
+    // will add up.  Anything else first waits for the overlapped fills before it.
     const bool overlap = s->ov_enabled && defer_ring_slot >= 0 && stream == s->stream && dev_out != nullptr && root_add && s->n_blocks > 1 &&
-                         per_voice_dev == nullptr && onepole_kernel && done != nullptr;
+                         per_voice_dev == nullptr && done != nullptr;
     const int ov_parity = overlap ? (int)(s->ov_fill & 1u) : -1;
     if (!overlap) { int rc = overlap_drain(s); if (rc != S2R_OK) return rc; }
     else if (s->dmix.active && !s->dmix.overlap) { int rc = launch_deferred_mix(s, stream); if (rc != S2R_OK) return rc; }

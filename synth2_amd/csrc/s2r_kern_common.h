@@ -689,6 +689,17 @@ __device__ __forceinline__ void ov_store4(float *p, f4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
 }
 
+// a record of the fill's event copy: plainly, or (two streams: the copy comes from a kernel on the other one) `sc1`
+__device__ __forceinline__ S2rTimedEvent tev_load(const S2rRenderParams &p, bool ovh, int32_t i) {
+    if (!ovh) return p.tev[i];
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(p.tev + i);
+    S2rTimedEvent e;
+    e.voice = 0u; e._pad = 0u;
+    e.frame = ov_load(w + 1); e.flags = ov_load(w + 2); e.pitch = s2r_u2f(ov_load(w + 3));
+    e.seed = ov_load(w + 4); e.next = (int32_t)ov_load(w + 5); e.program = ov_load(w + 6);
+    return e;
+}
+
 // minimum of a value over the wavefront, in a scalar register: four DPP row shifts, two row broadcasts (the classic
 // GFX9 reduction; ~35 cycles of issue for a lone wave where a ballot round trip costs ~50 and answers less)
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
