@@ -8,7 +8,8 @@ A *step* is one 1024-frame buffer of the whole voice pool: the buffer's note eve
 the 4 KiB mix is copied to (pinned) host memory — every buffer, inside the timed region, like the events' H2D.  The steps
 run through the host-buffer API with TWO buffers in flight (`s2r_fill_begin` / `s2r_fill_end`: buffer k is queued, then
 buffer k - 1 is waited for and copied into the caller's memory — the arrangement s2_bin itself uses between its synth and
-audio threads, audio_player.rs:56-60), one fence before and one after the K steps as the bench contract prescribes; the
+audio threads, audio_player.rs:56-60; the library then runs the previous buffer's mix and the next buffer's event preparation on a
+second stream beside the render kernels), one fence before and one after the K steps as the bench contract prescribes; the
 strictly one-at-a-time form (`s2r_fill`: the caller waits for every buffer before it hands over the next events) is timed
 on the same workload and printed as `value_host_api_sync`.
 

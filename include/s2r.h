@@ -29,6 +29,8 @@
 extern "C" {
 #endif
 
+/* Changes when a struct layout or an existing signature changes.  Entry points added since 4.0 without touching either:
+ * s2r_set_low_latency, s2r_low_latency_active. */
 #define S2R_ABI_VERSION 4
 
 typedef enum {
