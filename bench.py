@@ -521,7 +521,7 @@ def main():
     # side 1.5-2x slower (s2r_note_events 19 -> 30 us, s2r_fill_begin 12 -> 30 us) and the step becomes host-bound.
     # 5 ms of busy waiting between the fence and the timer bring the core back; the timed region is still exactly K
     # steps with a fence on either side.
-    t_spin = time.perf_counter() + 0.005
+    t_spin = time.perf_counter() + float(os.environ.get("S2R_BENCH_PREWAIT_MS", "5")) * 1e-3      # (the variable: measurement aid)
     while time.perf_counter() < t_spin:
         pass
     t0 = time.perf_counter()
