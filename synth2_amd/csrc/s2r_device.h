@@ -200,6 +200,7 @@ static_assert(sizeof(S2rRenderArgs) <= 4096, "kernel arguments are limited to 4 
 #define S2R_RES_CMD_WORDS 32u
 #define S2R_RES_MAX_EVENTS 9u          // 4 header words + 9 * 3 + the closing sequence word
 #define S2R_RES_FLAG_EXIT 1u
+#define S2R_RES_GRANULE_FRAMES 64u     // fills up to this length come back as granules (FillCtl, s2r_kern_common.h)
 struct S2rResident {
     const uint32_t *cmd;         // [32], device address of the mapped host command:
                                  //   [0] seq  [1] frames | flags << 16  [2] n_events  [3] the completion word's value
@@ -210,6 +211,7 @@ struct S2rResident {
     uint32_t idle_ticks;         // leaves after this many 100 MHz ticks without a command ...
     uint32_t max_polls;          // ... or this many polls, whichever comes first: the grid always drains
     uint32_t *done_flag, *done_counter;   // the fills' completion word (S2rDone; the command carries the value)
+    unsigned long long *granules;         // [S2R_RES_GRANULE_FRAMES] mapped host memory: short fills' output (tag = the command's completion value)
 };
 
 // what s2r_table_kernel needs: the patch resolved for a sample rate and where the planes go

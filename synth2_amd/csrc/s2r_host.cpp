@@ -195,6 +195,7 @@ struct s2r_synth {
     uint32_t res_rate = 0, res_seq = 0, res_launch_id = 0;
     uint32_t *res_host = nullptr, *res_dev = nullptr;    // mapped host memory: [32] the kernel's "exited" word, and, where the CPU cannot
                                                          // write device memory, [0 .. 31] the command
+    unsigned long long *res_gran = nullptr, *res_gran_dev = nullptr;   // mapped: the granules of fills of up to S2R_RES_GRANULE_FRAMES frames
     uint32_t *res_cmd = nullptr;                         // the command as the CPU writes it: res_host, or 32 words of fine-grained
     uint32_t *res_cmd_dev = nullptr;                     // DEVICE memory (large BAR) that the kernel polls without crossing the link
     bool res_cmd_vram = false;
@@ -816,6 +817,7 @@ int resident_launch(s2r_synth *s, uint32_t sample_rate, bool stereo) {
     rs.idle_ticks = 100000u;                                     // 1 ms without a command (real-time callers come every 0.33 ms)
     rs.max_polls = 1u << 20;
     rs.done_flag = s->done_dev + 2; rs.done_counter = s->done_counter + 2;
+    rs.granules = s->res_gran_dev;
     S2R_HIP(s, s2r_launch_resident(a, rs, s->block_voices, s->stream));
     s->res_running = true; s->res_rate = sample_rate; s->res_stereo = stereo;
     return S2R_OK;
@@ -839,30 +841,46 @@ int resident_fill(s2r_synth *s, float *out, size_t frames, uint32_t sample_rate,
     s->pending.clear();
     resident_post(s, ++s->res_seq);
     s->pool->advance(frames);
-    // the completion word; a kernel that left (idle for too long) just before the command reached it is started again
+    // The fill's end: the completion word — or, for a short fill, the tags of its granules (every frame's 8-byte word
+    // carries the fill's value above the sample).  A kernel that left (idle for too long) just before the command reached
+    // it is started again.
     volatile uint32_t *f = s->done_host + 2;
+    const bool gran = frames <= S2R_RES_GRANULE_FRAMES && s->res_gran != nullptr;
+    volatile unsigned long long *g = s->res_gran;
+    auto arrived = [&]() -> bool {
+        if (!gran) return (int32_t)(*f - done_value) >= 0;
+        for (size_t i = frames; i-- > 0;) if ((uint32_t)(g[i] >> 32) != done_value) return false;     // (the last frame is the last to come)
+        return true;
+    };
     bool done = false;
     for (int attempt = 0; attempt < 3 && !done; attempt++) {
         for (int round = 0; round < 4000 && !done; round++) {
             for (int i = 0; i < 1000; i++) {
-                if ((int32_t)(*f - done_value) >= 0) { done = true; break; }
+                if (arrived()) { done = true; break; }
                 __builtin_ia32_pause();
             }
             if (!done && resident_exited(s)) break;
         }
-        if (done || (int32_t)(*f - done_value) >= 0) { done = true; break; }
+        if (done || arrived()) { done = true; break; }
         if (!resident_exited(s)) break;                          // neither finished nor gone: the stream decides below
         s->res_running = false;
         S2R_HIP(s, hipSetDevice(s->device));
         S2R_HIP(s, hipStreamSynchronize(s->stream));
-        if ((int32_t)(*f - done_value) >= 0) { done = true; break; }
+        if (arrived()) { done = true; break; }
         int rc = resident_launch(s, sample_rate, stereo);        // (first_seq = the command's successor: post it again)
         if (rc != S2R_OK) return rc;
         resident_post(s, ++s->res_seq);
     }
     if (!done) {
         (void)resident_stop(s);
-        if ((int32_t)(*f - done_value) < 0) return set_err(s, S2R_ERR_HIP, "the resident kernel did not report the fill");
+        if (!arrived()) return set_err(s, S2R_ERR_HIP, "the resident kernel did not report the fill");
+    }
+    if (gran) {
+        for (size_t i = 0; i < frames; i++) {
+            const float v = s2r_u2f((uint32_t)g[i]);
+            if (stereo) { out[2 * i] = v; out[2 * i + 1] = v; } else out[i] = v;
+        }
+        return S2R_OK;
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     std::memcpy(out, s->out_host, frames * (stereo ? 2 : 1) * sizeof(float));
@@ -926,6 +944,7 @@ void release_all(s2r_synth *s) {
     if (s->noise_dev) (void)hipFree(s->noise_dev);
     if (s->res_cmd_vram && s->res_cmd) (void)hipFree(s->res_cmd);
     if (s->res_host) (void)hipHostFree(s->res_host);
+    if (s->res_gran) (void)hipHostFree(s->res_gran);
     if (s->per_voice_dev) (void)hipFree(s->per_voice_dev);
     if (s->voice_ev_head) (void)hipFree(s->voice_ev_head);
     if (s->tev_copy) (void)hipFree(s->tev_copy);
@@ -1658,6 +1677,9 @@ int s2r_set_low_latency(s2r_synth *s, int enabled) {
         std::memset(s->res_host, 0, 64 * sizeof(uint32_t));
         S2R_HIP(s, hipHostGetDevicePointer((void **)&s->res_dev, s->res_host, 0));
         s->res_cmd = s->res_host; s->res_cmd_dev = s->res_dev; s->res_cmd_vram = false;
+        S2R_HIP(s, hipHostMalloc((void **)&s->res_gran, S2R_RES_GRANULE_FRAMES * sizeof(unsigned long long), hipHostMallocMapped));
+        std::memset(s->res_gran, 0, S2R_RES_GRANULE_FRAMES * sizeof(unsigned long long));
+        S2R_HIP(s, hipHostGetDevicePointer((void **)&s->res_gran_dev, s->res_gran, 0));
         // Where the whole of device memory is visible to the CPU (large BAR: hipDeviceAttributeIsLargeBar), the command lives
         // in fine-grained device memory: the CPU's stores cross the link once, posted, and the kernel's polls stay on the
         // device (a poll of host memory is a round trip over the link, and the command is seen a trip later).

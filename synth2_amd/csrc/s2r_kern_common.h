@@ -759,6 +759,12 @@ struct FillCtl {
     uint32_t n_events;       // untimed note events applied before the state is loaded (apply_arg_events)
     const uint32_t *ev;      // [3 * n_events]: voice, flags, pitch bits
     S2rDone done;            // the fill's completion word
+    // Short fills of the resident kernel: the output as GRANULES in mapped host memory — one naturally aligned 8-byte word
+    // per frame, the sample's bits below and the fill's tag above, each written by ONE 8-byte system-scope store and read by
+    // the host with one 8-byte load: a frame is there when its tag is, so the fill needs no completion word and nobody
+    // waits for a store to be acknowledged across the link (MI355X_MICROARCH.md's R2 granule).  nullptr: not used.
+    unsigned long long *granules;
+    uint32_t granule_tag;
 };
 
 // ---------------------------------------------------------------------------------------
@@ -888,7 +894,8 @@ __device__ __forceinline__ f4 pk_add4(f4 a, f4 b) {
 // 1 024 frames, tools/stamps.py).  n_groups is a multiple of 4 (four groups per wave), super_frames of 4; the rows'
 // entries past n_sc are read and not used.  bp: the block's row at the super-chunk's first frame, 16-byte aligned.
 __device__ __forceinline__ void combine_groups(const S2rRenderParams &p, const S2rDone &done, const float *sWbuf, uint32_t n_groups, uint32_t super_frames,
-                                               uint32_t n_sc, uint32_t sc0, float *bp_sc, uint32_t tid, uint32_t n_threads) {
+                                               uint32_t n_sc, uint32_t sc0, float *bp_sc, uint32_t tid, uint32_t n_threads,
+                                               unsigned long long *granules = nullptr, uint32_t granule_tag = 0u) {
     for (uint32_t f = 4u * tid; f < n_sc; f += 4u * n_threads) {
         const float *row = sWbuf + f;
         f4 acc;
@@ -913,6 +920,11 @@ __device__ __forceinline__ void combine_groups(const S2rRenderParams &p, const S
             for (uint32_t j = 0; j < n; ++j) {
                 const float total = 0.0f + acc[j];
                 const uint32_t fo = sc0 + f + j;
+                if (granules != nullptr) {                       // (mono: the host doubles the frame for a stereo caller)
+                    __hip_atomic_store(granules + fo, ((unsigned long long)granule_tag << 32) | (unsigned long long)s2r_f2u(total),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    continue;
+                }
                 if (p.direct_stereo) { out_store(done, p.direct_out + 2u * fo, total); out_store(done, p.direct_out + 2u * fo + 1u, total); }
                 else out_store(done, p.direct_out + fo, total);
             }
