@@ -258,7 +258,8 @@ uint64_t s2r_double_release_count(const s2r_synth *s);
  * callback (synth.rs:154-203 called per 16 frames, s2_bin/src/main.rs:138-147, audio_player.rs:56-60).  Enabled, a handle
  * whose shard is ONE workgroup (at most 256 voices, block_voices permitting) with a single one-pole patch keeps a resident
  * render kernel on the device between s2r_fill / s2r_fill_stereo calls: a fill is then a command written to mapped host
- * memory and a completion word polled, not a kernel launch.  The kernel leaves by itself after 1 ms
+ * memory and a completion word (for fills of up to 64 frames: the tags of the frames themselves) polled, not a kernel
+ * launch.  The kernel leaves by itself after 1 ms
  * without a fill (the next fill starts it again) and is stopped by every other entry point that touches the device or
  * the patch; fills it cannot take (timed events, more than 9 note events since the last fill, seed overrides) go the
  * ordinary way.  Same bits either way.  While it runs it occupies one compute unit and the handle's stream.
