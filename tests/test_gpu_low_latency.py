@@ -190,3 +190,24 @@ def test_resident_kernel_refused_or_ignored_where_it_does_not_apply():
     g, o, _ = seeded.sample(16); assert_bits_equal(g, o, "seed overrides ride with the note-on: a launch")
     g, o, _ = seeded.sample(16); assert_bits_equal(g, o, "no events: resident")
     assert seeded.gpu.low_latency_active
+
+
+@pytest.mark.parametrize("block", [0, 64, 128])
+def test_resident_kernel_granules_and_completion_word_side_by_side(block):
+    """fills of up to 64 frames come back as tagged 8-byte granules, longer ones through the completion word: lengths on both
+    sides of the limit in turn, mono and stereo, in workgroups of 64, 128 and 256 voices"""
+    pr = _lowlat_pair(60, block_voices=block, max_frames=256)
+    for n in (50, 57, 62, 69, 74):
+        pr.note_on(n)
+    for k, frames in enumerate([64, 65, 63, 1, 256, 16, 64, 128, 2, 64, 65, 16]):
+        if k == 5:
+            pr.note_off(57); pr.note_on(81)
+        if k % 3 == 2:
+            gs = pr.gpu.sample_stereo(frames)
+            _, o = pr_cpu_sample(pr, frames)
+            assert_bits_equal(gs[:, 0], o, "block %d, %d frames, stereo left" % (block, frames))
+            assert_bits_equal(gs[:, 1], o, "block %d, %d frames, stereo right" % (block, frames))
+        else:
+            g, o, _ = pr.sample(frames)
+            assert_bits_equal(g, o, "block %d, %d frames" % (block, frames))
+        assert pr.gpu.low_latency_active
