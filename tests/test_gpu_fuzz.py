@@ -33,7 +33,7 @@ def random_patch(rng):
 
 
 # S2R_FUZZ_SEEDS=N widens the sweep, S2R_FUZZ_BASE moves it.  History: seed 293 found idle voices' rows coming
-# out as -0.0 after a general-path chunk (fixed); some 60 000 cases over two dozen bases have run; later finds (stale oscillator constants after a timed restart on the streamed path, an -O3 miscompile) were fixed before they were committed; with voices aged across 2^24 frames (below): 7500 more at bases 500000, 600000 and 700000
+# out as -0.0 after a general-path chunk (fixed); some 60 000 cases over two dozen bases have run; later finds (stale oscillator constants after a timed restart on the streamed path, an -O3 miscompile) were fixed before they were committed; with voices aged across 2^24 frames (below): 7500 more at bases 500000, 600000 and 700000; round 3 (the resident kernel, two streams, the combine, the run selection): some 16 000 cases of the four tests below at bases 930000 ... 1040000
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("S2R_FUZZ_SEEDS", "40")))))
 def test_fuzz(seed):
     rng = np.random.RandomState(int(os.environ.get("S2R_FUZZ_BASE", "1000")) + seed)
