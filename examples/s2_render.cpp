@@ -3,11 +3,13 @@
 // MIDI that is due, call Synth::sample.  Instead of cpal and a MIDI port it reads a note script
 // and writes raw little-endian f32 frames, so its output can be compared with anything else.
 //
-//   s2_render <script.txt> <out.f32> [--buffer N] [--voices N] [--rate HZ] [--patch file.synth2] [--batched]
+//   s2_render <script.txt> <out.f32> [--buffer N] [--voices N] [--rate HZ] [--patch file.synth2] [--batched] [--launch-per-call]
 //
 // script lines:  <frame> on <note> [velocity 0..127]   |   <frame> off <note>       (# comments)
 //
-// default mode: the reference's loop — 16-frame chunks, MIDI applied before each (main.rs:138-147).
+// default mode: the reference's loop — 16-frame chunks, MIDI applied before each (main.rs:138-147) — with the library's
+//               resident render kernel between the calls (Synth::set_low_latency: a command and a polled word per call
+//               instead of a kernel launch); --launch-per-call: without it.  Same samples.
 // --batched:    one Synth::sample per device buffer; the MIDI of the buffer goes ahead in one
 //               s2r_note_events call, stamped with the 16-frame boundary it belongs to.  Same samples.
 #include <algorithm>
@@ -48,7 +50,7 @@ static void apply(s2::Synth &synth, const Msg &m) {
 
 int main(int argc, char **argv) {
     if (argc < 3) { std::fprintf(stderr, "usage: s2_render <script> <out.f32> [--buffer N] [--voices N] [--rate HZ] [--patch f] [--batched] [--frames N]\n"); return 2; }
-    size_t buffer_frames = 2048; uint32_t voices = 8, rate = 48000; bool batched = false; uint64_t total_frames = 0;
+    size_t buffer_frames = 2048; uint32_t voices = 8, rate = 48000; bool batched = false, low_latency = true; uint64_t total_frames = 0;
     std::string patch_path;
     for (int i = 3; i < argc; i++) {
         const std::string a = argv[i];
@@ -59,6 +61,7 @@ int main(int argc, char **argv) {
         else if (a == "--frames") total_frames = std::strtoull(next(), nullptr, 10);
         else if (a == "--patch") patch_path = next();
         else if (a == "--batched") batched = true;
+        else if (a == "--launch-per-call") low_latency = false;
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     const std::vector<Msg> script = read_script(argv[1]);
@@ -70,6 +73,7 @@ int main(int argc, char **argv) {
             std::stringstream ss; ss << pf.rdbuf();
             synth.load_patch(ss.str());
         }
+        if (!batched && low_latency) synth.set_low_latency(true);        // (pools of one workgroup; bigger ones render the ordinary way)
         const s2::SampleRateKhz sample_rate{rate};
         std::FILE *out = std::fopen(argv[2], "wb");
         if (!out) { std::fprintf(stderr, "cannot write %s\n", argv[2]); return 2; }

@@ -60,7 +60,7 @@ def _oracle(script, total, buffer_frames, patch_cfg=None):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["reference_loop", "batched"])
+@pytest.mark.parametrize("mode", ["reference_loop", "reference_loop_launch_per_call", "batched"])
 @pytest.mark.parametrize("buffer_frames", [2048, 1000])
 def test_cpp_caller_matches_the_oracle(tmp_path, mode, buffer_frames):
     exe = _exe()
@@ -71,6 +71,8 @@ def test_cpp_caller_matches_the_oracle(tmp_path, mode, buffer_frames):
     cmd = [exe, str(script), str(out), "--buffer", str(buffer_frames), "--frames", str(total)]
     if mode == "batched":
         cmd.append("--batched")
+    elif mode == "reference_loop_launch_per_call":       # (the default loop keeps the resident kernel between its 16-frame calls)
+        cmd.append("--launch-per-call")
     subprocess.check_call(cmd)
     got = np.fromfile(out, dtype=np.float32)
     want = _oracle(SCRIPT, total, buffer_frames)
