@@ -213,3 +213,62 @@ def test_two_buffers_in_flight_where_two_workgroups_share_a_compute_unit():
                 assert_bits_equal(a.sample_end(np.empty(bench.FRAMES, dtype=np.float32)), want, "%d voices, buffer %d" % (voices, kk))
         kk, want = pending.pop(0)
         assert_bits_equal(a.sample_end(np.empty(bench.FRAMES, dtype=np.float32)), want, "%d voices, buffer %d" % (voices, kk))
+
+
+def test_config4_262144_voices_as_8_shards_4x_oversampled_dpw_svf():
+    """BASELINE config [4] at its full pool: 262 144 voices, alias-suppressed (DPW) saw + SVF, rendered at 4 x 48 kHz and
+    decimated, dealt out to 8 shards in runs of 64 — all eight on this one device.  (a) windows of every shard's per-voice
+    rows at the 4x rate bit for bit against the oracle; (b) every shard's partial row equals the oracle's tree over that
+    shard's rows; (c) the rank-ordered sum of the eight partial rows is what ONE handle over a device list of eight returns
+    at the 4x rate; (d) that handle's s2r_fill_oversampled output is the oracle's decimator applied to the same mix."""
+    import torch
+    from helpers import oracle_cfg_from_patch
+    V, N, G, frames_out = 262144, 8, 64, 64
+    F4 = 4 * frames_out
+    per = V // N
+    patch = make_patch(osc_kind=s2.OSC_DPW_SAW, lpf_kind=s2.FILT_SVF_LP, lpf_freq=4000.0, lpf_q=1.2, mod_env_to_lpf_freq=2.0)
+    def mk(**kw):
+        s = s2.Synth(V, max_frames=F4, shard_interleave=G, **kw)
+        s.set_patch(patch)
+        return s
+    shards = [mk(shard_index=k, shard_count=N) for k in range(N)]
+    twins = [mk(shard_index=k, shard_count=N) for k in range(N)]
+    one = mk(devices=[0] * N)
+    one_os = mk(devices=[0] * N)
+    ev = np.zeros(V, dtype=s2.NOTE_EVENT_DTYPE)
+    ev["kind"] = 1; ev["note"] = (np.arange(V) * 13) % 90 + 24; ev["velocity"] = 1.0
+    for s in shards + twins + [one, one_os]:
+        s.note_events(ev)                                    # (an empty pool hands out its voices in index order: voice i plays ev[i])
+    win = np.concatenate([np.arange(0, 512), np.arange(V - 512, V)])
+    slot_of = {int(p): i for i, p in enumerate(win)}
+    ora = s2o.OracleSynth(win.size)
+    ora.config = oracle_cfg_from_patch(patch)
+    for p in win:
+        ora.note_on(int(ev["note"][p]))
+    rows = torch.zeros((N, F4), dtype=torch.float32, device="cuda")
+    out = torch.zeros(F4, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    hist = np.zeros(62, dtype=np.float32)
+    for b in range(2):
+        want = ora.render_voices(F4, 4 * SR, threads=_threads())
+        for k, s in enumerate(shards):
+            s.fill_device(rows[k].data_ptr(), F4, 4 * SR, stream)
+        s2.sum_partials_device(rows.data_ptr(), N, F4, out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        rows_h = rows.cpu().numpy()
+        acc = np.zeros(F4, dtype=np.float32)
+        for k in range(N):
+            pv = twins[k].render_voices(F4, 4 * SR)
+            pool_idx = s2.synth.shard_pool_indices(V, k, N, G)
+            sel = np.nonzero(np.isin(pool_idx, win))[0]
+            assert sel.size == win.size // N
+            assert_bits_equal(pv[sel], want[[slot_of[int(p)] for p in pool_idx[sel]]], "shard %d, window rows at 192 kHz, buffer %d" % (k, b))
+            part = s2o.mix_tree_partial(pv, shards[k].block_voices)
+            assert_bits_equal(rows_h[k], part, "shard %d partial row, buffer %d" % (k, b))
+            acc = acc + part
+            del pv
+        assert_bits_equal(out.cpu().numpy(), acc, "rank-ordered sum of the 8 partial rows, buffer %d" % b)
+        assert_bits_equal(one.sample(np.empty(F4, dtype=np.float32), 4 * SR), acc, "one handle over a device list of 8 at the 4x rate, buffer %d" % b)
+        x = np.concatenate([hist, acc])
+        assert_bits_equal(one_os.sample_oversampled(frames_out, SR), s2o.decimate4(x, frames_out), "decimated output of the device-list handle, buffer %d" % b)
+        hist = x[-62:]
