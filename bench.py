@@ -350,14 +350,10 @@ def executed_roofline(prof, voices, kernel_ms):
 
 
 def kernel_source_hash():
-    """identifies the build a committed profile belongs to (the GPU box has no .git)"""
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "synth2_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h", ".inc", ".cpp")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
-    return h.hexdigest()[:16]
+    """identifies the build a committed profile belongs to (the GPU box has no .git): synth2_amd/build.py's source_hash, the
+    first half of what s2r_build_id() of a library built from these sources returns"""
+    from synth2_amd import build as _b
+    return _b.source_hash()
 
 
 def committed_profile():

@@ -246,6 +246,11 @@ int s2r_set_noise_seed(s2r_synth *s, uint32_t voice_index, uint32_t seed);
 
 /* Introspection */
 uint32_t s2r_abi_version(void);
+/* Which sources this binary was built from: "<sha256 over synth2_amd/csrc, 16 hex>-<include/s2r.h + compiler flags, 8 hex>",
+ * compiled in by synth2_amd/build.py.  A loader that has the sources at hand (synth2_amd.load_library, bench.py) compares it
+ * with their hash and refuses — or rebuilds — a binary that does not match, whatever the files' times say; bench.py prints it
+ * beside the profile's source hash.  (No counterpart in the reference: cargo rebuilds s2_lib from source.) */
+const char *s2r_build_id(void);
 uint32_t s2r_shard_voices(const s2r_synth *s);
 uint32_t s2r_block_voices(const s2r_synth *s);
 uint32_t s2r_device_count(const s2r_synth *s);                  /* 1, or the N of a device list */

@@ -3,7 +3,9 @@
 hipcc cross-compiles gfx950 without a GPU, so this runs in the build container as well as on
 the GPU box.  -ffp-contract=off is mandatory (bit-exact arithmetic, see csrc/s2r_math.h).
 """
+import hashlib
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -66,24 +68,59 @@ def _hipcc():
     raise RuntimeError("hipcc not found: libs2r cannot be built (there is no CPU fallback)")
 
 
-def needs_build():
+def source_hash(csrc=None):
+    """identifies the sources a library was built from: sha256 over the names and bytes of csrc/'s sources (bench.py's
+    kernel_source_hash is this function; the committed rocprofv3 summaries under profiles/ carry it)"""
+    csrc = csrc or CSRC
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h", ".inc", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def build_id(csrc=None):
+    """what s2r_build_id() of a library built NOW would return: <source hash>-<hash of include/s2r.h and the flags>"""
+    h = hashlib.sha256()
+    h.update(open(os.path.join(ROOT, "include", "s2r.h"), "rb").read())
+    h.update(repr(FLAGS).encode())
+    return source_hash(csrc) + "-" + h.hexdigest()[:8]
+
+
+_ID_MARK = b"S2R_BUILD_ID="
+
+
+def embedded_build_id(lib=None):
+    """the build id compiled into a libs2r.so (s2r_build_id(), read from the file without loading it), or None"""
+    try:
+        data = open(lib or LIB, "rb").read()
+    except OSError:
+        return None
+    m = re.search(re.escape(_ID_MARK) + rb"([0-9a-f]{16}-[0-9a-f]{8})", data)
+    return m.group(1).decode() if m else None
+
+
+def needs_build(csrc=None):
+    """The library is bound to its sources by CONTENT: it carries the hash of the sources it was built from
+    (s2r_build_id), and anything else on disk — whatever the files' times say — is a stale binary."""
     if AB_LIB:
         if not os.path.exists(LIB):
             raise RuntimeError("S2R_AB_LIB=%s does not exist" % LIB)
         return False
     if not os.path.exists(LIB):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(ROOT, "include", "s2r.h"), __file__]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return embedded_build_id() != build_id(csrc)
 
 
 def _compile_one(args):
-    cc, src, obj, verbose = args
-    cmd = [cc] + FLAGS + ["-x", "hip", "-c", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", obj, src]
+    cc, src, obj, verbose, extra, stamp = args
+    cmd = [cc] + FLAGS + extra + ["-x", "hip", "-c", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", obj, src]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    with open(obj + ".id", "w") as f:
+        f.write(stamp)
     return obj
 
 
@@ -93,14 +130,27 @@ def build(force=False, verbose=False, jobs=None):
     from concurrent.futures import ThreadPoolExecutor
     cc = _hipcc()
     os.makedirs(OBJ_DIR, exist_ok=True)
-    lib_deps = [os.path.join(CSRC, f) for f in HEADERS] + [os.path.join(ROOT, "include", "s2r.h"), __file__]
-    newest_dep = max(os.path.getmtime(d) for d in lib_deps)
+    bid = build_id()
+    # an object is as good as the bytes it was compiled from: its own source, every header, the flags (content, not times)
+    hh = hashlib.sha256()
+    for f in HEADERS:
+        hh.update(open(os.path.join(CSRC, f), "rb").read())
+    hh.update(open(os.path.join(ROOT, "include", "s2r.h"), "rb").read())
+    hh.update(repr(FLAGS).encode())
     todo, objs = [], []
     for f in SOURCES:
         src, obj = os.path.join(CSRC, f), os.path.join(OBJ_DIR, os.path.splitext(f)[0] + ".o")
         objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(newest_dep, os.path.getmtime(src)):
-            todo.append((cc, src, obj, verbose))
+        # (s2r_host.cpp carries the build id: S2R_BUILD_ID, the marker embedded_build_id() looks for)
+        extra = ['-DS2R_BUILD_ID="%s"' % bid] if f == "s2r_host.cpp" else []
+        h = hh.copy(); h.update(open(src, "rb").read()); h.update(repr(extra).encode())
+        stamp = h.hexdigest()
+        try:
+            have = open(obj + ".id").read()
+        except OSError:
+            have = None
+        if force or not os.path.exists(obj) or have != stamp:
+            todo.append((cc, src, obj, verbose, extra, stamp))
     jobs = jobs or max(1, min(len(todo), os.cpu_count() or 1, 8))
     if todo:
         with ThreadPoolExecutor(max_workers=jobs) as ex:
@@ -109,6 +159,8 @@ def build(force=False, verbose=False, jobs=None):
     if verbose:
         print(" ".join(link), file=sys.stderr)
     subprocess.check_call(link)
+    if embedded_build_id() != bid:
+        raise RuntimeError("the linked library does not carry the build id %s" % bid)
     return LIB
 
 

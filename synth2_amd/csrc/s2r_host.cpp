@@ -969,6 +969,14 @@ extern "C" {
 
 uint32_t s2r_abi_version(void) { return S2R_ABI_VERSION; }
 
+// synth2_amd/build.py passes -DS2R_BUILD_ID="<hash of the sources>"; the marker in front is what lets a loader read the id
+// out of the file without mapping it (build.py embedded_build_id)
+#ifndef S2R_BUILD_ID
+#define S2R_BUILD_ID "0000000000000000-00000000"
+#endif
+static const char kBuildIdMarked[] = "S2R_BUILD_ID=" S2R_BUILD_ID;
+const char *s2r_build_id(void) { return kBuildIdMarked + 13; }
+
 const char *s2r_status_string(int status) {
     switch (status) {
     case S2R_OK: return "ok";

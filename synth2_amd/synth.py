@@ -112,22 +112,29 @@ def lib_path():
 
 
 def load_library():
-    """dlopen libs2r.so; builds it first when hipcc is present and the sources are newer."""
+    """dlopen libs2r.so; builds it first when it was not built from the sources on disk (s2r_build_id: content, not times)."""
     global _lib
     if _lib is not None:
         return _lib
     path = _build.LIB
     if _build.needs_build():
-        # sources newer than the library (or no library): rebuild, and fail loudly if that is impossible — a stale
+        # no library, or one built from other sources: rebuild, and fail loudly if that is impossible — a stale
         # libs2r.so would let tests and the bench pass against old code
         try:
             path = _build.build()
         except Exception as e:
-            raise RuntimeError("libs2r.so is missing or older than its sources and could not be rebuilt: %s" % (e,)) from e
+            raise RuntimeError("libs2r.so is missing or was not built from these sources (build id %s, sources %s) and could not be rebuilt: %s" % (
+                _build.embedded_build_id(), _build.build_id(), e)) from e
     L = C.CDLL(path)
+    if not _build.AB_LIB:
+        L.s2r_build_id.restype = C.c_char_p
+        have = L.s2r_build_id().decode()
+        if have != _build.build_id():
+            raise RuntimeError("libs2r.so says it was built from %s; the sources on disk are %s" % (have, _build.build_id()))
     H = C.c_void_p
     sig = {
         "s2r_abi_version": (C.c_uint32, []),
+        "s2r_build_id": (C.c_char_p, []),
         "s2r_status_string": (C.c_char_p, [C.c_int]),
         "s2r_create": (C.c_int, [C.POINTER(Config), C.POINTER(H)]),
         "s2r_destroy": (None, [H]),

@@ -67,6 +67,87 @@ def test_bench_c3_path_at_65536_voices_against_the_oracle():
     assert np.array_equal(st["release_frame_offset"][rel], vo["rfo"][rel])
 
 
+def _leg_patch(text):
+    """a bench.py config leg's patch text -> (synth2_amd.Patch, oracle LayerCfg)"""
+    patch = s2.parse_patch(text)
+    return patch, oracle_cfg_from_patch(patch)
+
+
+def _whole_pool_on(voices):
+    ev = np.zeros(voices, dtype=s2.NOTE_EVENT_DTYPE)
+    ev["kind"] = 1; ev["note"] = 36 + np.arange(voices) % 61; ev["velocity"] = 1.0
+    return ev
+
+
+def test_bench_config2_leg_at_65536_voices_against_the_oracle():
+    """What `bench.py`'s config_legs[0] times, as it times it: BASELINE config [2] as written — 65 536
+    voices, saw + ADSR + SVF, the leg's own patch text — on `bench.make_c3_events(65536)` through s2r_note_events +
+    s2r_fill_begin / s2r_fill_end with two buffers in flight (the general render kernel in MODE 2 on two streams, timed
+    note-offs, frame-0 events merged into the chains).  The pool is filled first (one buffer), so that every note-on of the
+    schedule steals the oldest voice as it does in the aged population the leg is timed on; then 22 buffers of the schedule.
+    EVERY buffer is compared bit for bit with the oracle driven as the reference's caller drives Synth — MIDI applied
+    between 16-frame sample() calls (s2_bin/src/main.rs:138-147), process.rs:306-379 with the filter call swapped — and
+    mixed through the documented tree; no window, no self-comparison."""
+    import bench
+    V = 65536
+    text = "synth c2 { lpf.kind = svf_lp; lpf.q = 1.4 }"           # bench.py main(): config_legs[0]
+    assert text in open(bench.__file__).read()
+    patch, cfg = _leg_patch(text)
+    cyc = bench.make_c3_events(V, bench.PERIOD)
+    gpu = s2.Synth(V, max_frames=bench.FRAMES)
+    gpu.load_patch(text)
+    ora = s2o.OracleSynth(V)
+    ora.config = cfg
+    threads = _threads()
+    queue = []
+    batches = [_whole_pool_on(V)] + [cyc[k % bench.PERIOD] for k in range(22)]
+    n_timed = 0
+    for k, ev in enumerate(batches):
+        n_timed += int(np.count_nonzero(ev["frame"]))
+        gpu.note_events(ev)
+        gpu.sample_begin(bench.FRAMES, SR)
+        pv = ora.render_events(ev, bench.FRAMES, SR, threads=threads)
+        queue.append((k, s2o.mix_tree(pv, gpu.block_voices, 1)))
+        del pv
+        if len(queue) == 2:
+            kk, want = queue.pop(0)
+            assert_bits_equal(gpu.sample_end(np.empty(bench.FRAMES, dtype=np.float32)), want, "config [2] leg, buffer %d" % kk)
+    kk, want = queue.pop(0)
+    assert_bits_equal(gpu.sample_end(np.empty(bench.FRAMES, dtype=np.float32)), want, "config [2] leg, buffer %d" % kk)
+    assert n_timed > 20000 and not ora.panicked
+
+
+def test_bench_config4_leg_at_32768_voices_against_the_oracle():
+    """What `bench.py`'s config_legs[1] times, as it times it: config [4]'s per-GPU share — 32 768 voices, DPW saw + SVF,
+    4x oversampled — on `bench.make_c3_events(32768, PERIOD, 4096)` (note-offs on the internal rate's 16-frame boundaries)
+    through s2r_note_events + s2r_fill_oversampled, one buffer at a time: the whole pool started, then five buffers of the
+    schedule, each compared bit for bit with the oracle's 4 096 internal frames at 192 kHz (events between 16-frame calls),
+    its tree and its decimator with the history carried from buffer to buffer."""
+    import bench
+    V, F4 = 32768, 4 * bench.FRAMES
+    text = "synth c4 { osc.kind = dpw_saw; lpf.kind = svf_lp; lpf.q = 1.4 }"     # bench.py main(): config_legs[1]
+    assert text in open(bench.__file__).read()
+    patch, cfg = _leg_patch(text)
+    cyc = bench.make_c3_events(V, bench.PERIOD, F4)
+    gpu = s2.Synth(V, max_frames=F4)
+    gpu.load_patch(text)
+    ora = s2o.OracleSynth(V)
+    ora.config = cfg
+    threads = _threads()
+    hist = np.zeros(62, dtype=np.float32)
+    n_timed = 0
+    for k, ev in enumerate([_whole_pool_on(V)] + [cyc[k % bench.PERIOD] for k in range(5)]):
+        n_timed += int(np.count_nonzero(ev["frame"]))
+        gpu.note_events(ev)
+        got = gpu.sample_oversampled(bench.FRAMES, SR)
+        pv = ora.render_events(ev, F4, 4 * SR, threads=threads)
+        x = np.concatenate([hist, s2o.mix_tree(pv, gpu.block_voices, 1)])
+        del pv
+        assert_bits_equal(got, s2o.decimate4(x, bench.FRAMES), "config [4] leg, buffer %d" % k)
+        hist = x[-62:]
+    assert n_timed > 2000 and not ora.panicked
+
+
 def test_config2_svf_at_65536_voices():
     """BASELINE config [2] as written — 65 536 voices, saw + ADSR + SVF (the build-defined state-variable filter at the
     modulated cutoff): a 2 048-voice window of per-voice rows bit for bit against the oracle, and the mix equal to the

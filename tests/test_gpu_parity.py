@@ -715,7 +715,7 @@ def test_dsp_filters_with_timed_events(kind):
 
 
 def test_dsp_filters_full_size_linearity_free_properties():
-    """65536 voices under LP2: the oracle is too slow for the whole pool, so check (a) a 2048-voice
+    """65536 voices under LP2, the quick form (whole pools against the oracle: tests/test_gpu_full_size.py): (a) a 2048-voice
     window of per-voice rows bit-exactly and (b) that the mix equals the documented tree over the
     GPU's own per-voice rows (the summation order is size-independent)."""
     voices = 65536
@@ -1191,7 +1191,8 @@ def test_dpw_with_timed_events_and_checkpoint():
 
 def test_config4_share_32768_voices_4x_oversampled_dpw_svf():
     """BASELINE config [4]'s per-GPU share at full size: 262 144 voices / 8 GPUs = 32 768 voices, alias-suppressed
-    oscillator + SVF, 4x oversampled (rendered at 192 kHz, decimated to 48 kHz).  The oracle is too slow for the pool, so:
+    oscillator + SVF, 4x oversampled (rendered at 192 kHz, decimated to 48 kHz).  The quick form (the whole pool against the oracle,
+    timed events and all: test_bench_config4_leg_at_32768_voices_against_the_oracle):
     (a) a 1 024-voice window of per-voice rows at the 4x rate bit for bit against the oracle, (b) the 4x-rate mix equals
     the documented tree over the GPU's own rows, (c) the decimated output equals the oracle's decimator applied to that
     mix (the summation order and the decimator are size-independent)."""

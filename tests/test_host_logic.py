@@ -246,3 +246,29 @@ def test_rust_shim_and_integration_excerpt_follow_the_header():
         line = line.strip()
         if line.startswith("pub fn "):
             assert line in rs_lines, "INTEGRATION.md prints a line that is not in lib.rs: " + line
+
+
+def test_the_library_is_bound_to_its_sources_by_content(tmp_path):
+    """libs2r.so carries the hash of the sources it was built from (s2r_build_id, put there by
+    synth2_amd/build.py) and the loader compares THAT with the sources on disk — not file times.  A source edited without
+    its time moving (or with a time older than the library's) makes the library stale; the untouched tree does not."""
+    import shutil
+    from synth2_amd import build as b
+    L = s2.load_library()
+    have = L.s2r_build_id().decode()
+    assert have == b.build_id() == b.embedded_build_id()
+    assert have.split("-")[0] == b.source_hash()
+    import bench
+    assert bench.kernel_source_hash() == b.source_hash()      # the hash the committed profiles are keyed by
+    assert not b.needs_build()
+    # the same sources somewhere else, one kernel source edited, every file OLDER than the library
+    csrc = tmp_path / "csrc"
+    shutil.copytree(b.CSRC, csrc)
+    assert not b.needs_build(str(csrc))
+    f = csrc / "s2r_aux.hip"
+    f.write_bytes(f.read_bytes() + b"\n// edited\n")
+    old = os.path.getmtime(b.LIB) - 3600.0
+    for g in csrc.iterdir():
+        os.utime(g, (old, old))
+    assert b.source_hash(str(csrc)) != b.source_hash()
+    assert b.needs_build(str(csrc)), "a library built from other sources must be refused or rebuilt, whatever the times say"
