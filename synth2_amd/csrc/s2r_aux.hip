@@ -75,51 +75,13 @@ __global__ void __launch_bounds__(256) s2r_noise_table_kernel(float *t) {
 // One workgroup handles 16 frames: thread (slot, f) adds whole runs (16 independent loads in
 // flight each), the run sums meet in LDS, 16 threads finish.  Runs never straddle a mix group.
 // ---------------------------------------------------------------------------------------
-constexpr uint32_t kMixRun = 16;
-
 __device__ __forceinline__ void mix_body(const S2rMixParams &m, uint32_t block, float *s_run) {
     const bool ov = m.ov_render_counter != nullptr;              // two streams: the rows' render kernel runs beside this launch
     if (ov) {
         if (threadIdx.x == 0 && !ov_wait(m.ov_render_counter, m.ov_render_target)) ov_raise(m.ov_fail, 2u);
         __syncthreads();
     }
-    const uint32_t f_local = threadIdx.x & 15u, slot = threadIdx.x >> 4;
-    const uint32_t f = block * 16u + f_local;
-    const uint32_t runs_per_group = (m.blocks_per_group + kMixRun - 1) / kMixRun;
-    const uint32_t total_runs = runs_per_group * m.n_groups;
-    if (f < m.frames) {
-        for (uint32_t run = slot; run < total_runs; run += 16u) {
-            const uint32_t g = run / runs_per_group, rg = run % runs_per_group;
-            const uint32_t gb0 = g * m.blocks_per_group;
-            uint32_t gb1 = gb0 + m.blocks_per_group; if (gb1 > m.n_blocks) gb1 = m.n_blocks;
-            const uint32_t b0 = gb0 + rg * kMixRun;
-            float v[kMixRun];
-#pragma unroll
-            for (uint32_t j = 0; j < kMixRun; ++j) {
-                const float *src = m.block_partials + (size_t)(b0 + j) * m.frames_stride + f;
-                v[j] = (b0 + j < gb1) ? (ov ? ov_load(src) : *src) : 0.0f;
-            }
-            float acc = v[0];
-#pragma unroll
-            for (uint32_t j = 1; j < kMixRun; ++j) if (b0 + j < gb1) acc += v[j];
-            s_run[run * 16u + f_local] = (b0 < gb1) ? acc : 0.0f;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 16u && f < m.frames) {
-        float total = 0.0f;                                      // accum = splat(0.0), synth.rs:176
-        for (uint32_t g = 0; g < m.n_groups; ++g) {
-            const uint32_t gb0 = g * m.blocks_per_group;
-            uint32_t gb1 = gb0 + m.blocks_per_group; if (gb1 > m.n_blocks) gb1 = m.n_blocks;
-            if (gb0 >= gb1) continue;
-            const uint32_t n_runs = (gb1 - gb0 + kMixRun - 1) / kMixRun;
-            float acc = s_run[(g * runs_per_group) * 16u + f_local];
-            for (uint32_t r = 1; r < n_runs; ++r) acc += s_run[(g * runs_per_group + r) * 16u + f_local];
-            total = (m.root_add || g > 0) ? total + acc : acc;
-        }
-        if (m.stereo) { out_store(m.done, m.out + 2 * f, total); out_store(m.done, m.out + 2 * f + 1, total); }
-        else out_store(m.done, m.out + f, total);
-    }
+    mix_block(m, block, s_run, ov, m.done.flag != nullptr);
     signal_done(m.done, (m.frames + 15u) / 16u);
 }
 
@@ -232,6 +194,10 @@ hipError_t s2r_launch_onepole_resident_osc0(const S2rRenderArgs &a, const S2rRes
 hipError_t s2r_launch_onepole_resident_osc1(const S2rRenderArgs &a, const S2rResident &rs, uint32_t block_voices, hipStream_t stream);
 hipError_t s2r_launch_onepole_resident_osc2(const S2rRenderArgs &a, const S2rResident &rs, uint32_t block_voices, hipStream_t stream);
 hipError_t s2r_launch_onepole_resident_osc3(const S2rRenderArgs &a, const S2rResident &rs, uint32_t block_voices, hipStream_t stream);
+hipError_t s2r_launch_onepole_pool_osc0(const S2rRenderArgs &a, const S2rPool &pl, uint32_t block_voices, hipStream_t stream);
+hipError_t s2r_launch_onepole_pool_osc1(const S2rRenderArgs &a, const S2rPool &pl, uint32_t block_voices, hipStream_t stream);
+hipError_t s2r_launch_onepole_pool_osc2(const S2rRenderArgs &a, const S2rPool &pl, uint32_t block_voices, hipStream_t stream);
+hipError_t s2r_launch_onepole_pool_osc3(const S2rRenderArgs &a, const S2rPool &pl, uint32_t block_voices, hipStream_t stream);
 hipError_t s2r_launch_onepole_osc0(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
 hipError_t s2r_launch_onepole_osc1(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
 hipError_t s2r_launch_onepole_osc2(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
@@ -277,6 +243,18 @@ hipError_t s2r_launch_resident(const S2rRenderArgs &a, const S2rResident &rs, ui
     case S2R_OSC_SAW: return s2r_launch_onepole_resident_osc1(a, rs, block_voices, stream);
     case S2R_OSC_TRIANGLE: return s2r_launch_onepole_resident_osc2(a, rs, block_voices, stream);
     case S2R_OSC_SINE: return s2r_launch_onepole_resident_osc3(a, rs, block_voices, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t s2r_launch_pool(const S2rRenderArgs &a, const S2rPool &pl, uint32_t block_voices, hipStream_t stream) {
+    const S2rRenderParams &p = a.p;
+    if (p.n_voices == 0 || p.frames == 0 || p.bank_size > 1 || p.lpf_kind != S2R_FILT_ONEPOLE) return hipErrorInvalidValue;
+    switch (p.osc_kind) {
+    case S2R_OSC_SQUARE: return s2r_launch_onepole_pool_osc0(a, pl, block_voices, stream);
+    case S2R_OSC_SAW: return s2r_launch_onepole_pool_osc1(a, pl, block_voices, stream);
+    case S2R_OSC_TRIANGLE: return s2r_launch_onepole_pool_osc2(a, pl, block_voices, stream);
+    case S2R_OSC_SINE: return s2r_launch_onepole_pool_osc3(a, pl, block_voices, stream);
     default: return hipErrorInvalidValue;
     }
 }

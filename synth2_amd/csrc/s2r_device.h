@@ -97,6 +97,33 @@ struct S2rTabRef {
 #define S2R_TAB_PAD 16u          // entries a 16-frame chunk may read past a region's last used one
 #define S2R_TAB_MAX_ENTRIES (1u << 22)
 
+// ONE launch per fill.  The render kernel does the two small jobs that used to be launches of their own:
+//   * chain heads: the host hands over the fill's timed-event records GROUPED BY WORKGROUP (mapped host memory) with the
+//     groups' bounds; every workgroup copies its own slice into HBM and publishes its own voices' chain heads before it
+//     loads its state — nobody waits for anybody;
+//   * the mix ("ticket mix"): a workgroup that has written its partial row counts itself in on `arrive`; the LAST
+//     `n_mixers` to arrive wait for the very last one (bounded: they are the fill's slowest workgroups, and every workgroup
+//     they wait for is already running) and add the rows up in the documented order, 16-frame blocks dealt
+//     out among them; the last mixer to finish ends the fill: the completion word, or — a shard of a device list / of a
+//     group of processes — one more count on `rows_done` in the root's memory: the shard that counts in LAST adds the
+//     shards' rows in shard order from +0.0 (synth.rs:176,195) and ends the fill.  No wait anywhere in that.
+struct S2rMixTail {
+    uint32_t n_mixers;            // 0: no in-kernel mix (the rows are left for s2r_mix_kernel)
+    uint32_t n_blocks, blocks_per_group, n_groups;
+    int32_t root_add, stereo;
+    float *out;                   // the fill's output (root_add) or this shard's partial row
+    S2rDone done;                 // counter: the mixers' own arrival; flag/value: the completion word (no exchange)
+    // exchange of partial rows between shards (device list, one process per GPU): nullptr = none
+    uint32_t *rows_done;          // counter in the root's memory (system scope)
+    uint32_t rows_target;         // value it has when every shard has counted in for this fill
+    int32_t reserved;
+    uint32_t n_rows, row_stride;
+    const float *rows;            // [n_rows][row_stride], the root's
+    float *final_out;
+    S2rDone final_done;
+    int32_t final_stereo;
+};
+
 struct S2rRenderParams {
     // patch (static_config.rs:4-44), shared by every voice
     int32_t osc_kind;
@@ -147,6 +174,13 @@ struct S2rRenderParams {
     uint32_t ov_heads_target;
     uint32_t *ov_render_counter;
     uint32_t *ov_fail;
+    // One launch per fill (S2rMixTail above): arrive != nullptr
+    const S2rTimedEvent *tev_src;    // the fill's records, grouped by workgroup (mapped host memory, device view)
+    S2rTimedEvent *tev_copy;         // ... and where the workgroups put them in HBM (== tev)
+    const uint32_t *slices;          // workgroup b's records are [slices[b], slices[b + 1]); nullptr: S2rRenderArgs.ev holds the bounds
+    uint32_t *arrive;                // rows counter of this fill's parity (device memory; only grows)
+    uint32_t arrive_target;          // its value when every workgroup has written its row
+    S2rMixTail mt;
 };
 
 // Coalesced note events, one record per touched voice per fill (host folds the event
@@ -214,6 +248,45 @@ struct S2rResident {
     unsigned long long *granules;         // [S2R_RES_GRANULE_FRAMES] mapped host memory: short fills' output (tag = the command's completion value)
 };
 
+// The POOL-RESIDENT render kernel (s2r_pool_kernel; s2r_set_resident): the whole grid of a shard — at most one workgroup
+// per compute unit — stays on the device between fills.  The host posts a fill as a COMMAND (one 64-byte line in a ring of
+// S2R_POOL_CMD_SLOTS, in fine-grained device memory behind the BAR or in mapped host memory), the fill's records grouped by
+// workgroup and the groups' bounds; every workgroup renders the fill with the code a launch per fill runs (one launch per
+// fill's form: S2rMixTail), then looks for the next command — a workgroup that is done early starts the next fill while
+// the slowest ones still finish this one, so a fill lasts as long as the AVERAGE workgroup, not the slowest, once two are in
+// flight.  No launch, no kernel boundary, no launch latency per fill.
+//   command words: [0] seq  [1] frames | flags << 16  [2] records in this fill  [3] the completion word's value
+//                  [4] output: 0, 1 the ring slots, 2 the synchronous buffer; | 256: stereo  [5] event slot (tev_src index)
+//                  [6] parity  [7] arrive_target  [8] n_mixers  [9] rows_target  [10] rows slot  [15] seq
+//   Whether command `s` runs is decided ONCE for the whole grid, by whoever gets there first: word `decided` in device
+//   memory holds 2 * seq + bail of the last command decided; a workgroup that sees command s = last + 1 complete moves it
+//   2 * last -> 2 * s (run) and one whose patience has run out moves it -> 2 * s + 1 (everybody leaves: the host finds
+//   `exited` == launch_id, waits for the stream and starts the kernel again in front of the commands that were not run).
+//   Every wait is bounded in ticks and in polls: the grid always drains.
+#define S2R_POOL_CMD_SLOTS 4u
+#define S2R_POOL_CMD_WORDS 16u
+#define S2R_POOL_FLAG_EXIT 1u
+struct S2rPool {
+    const uint32_t *cmd;              // [S2R_POOL_CMD_SLOTS][16]
+    const uint32_t *slices;           // [S2R_POOL_CMD_SLOTS][n_blocks + 1], mapped host memory
+    uint32_t slices_stride;
+    const S2rTimedEvent *tev_src[4];  // the event slots' records (mapped host memory, device view)
+    S2rTimedEvent *tev_copy[2];       // by parity
+    int32_t *heads[2];
+    float *partials[2];
+    uint32_t *arrive;                 // [2] by parity
+    float *out[3];                    // ring slot 0, ring slot 1, the synchronous buffer (mapped host memory) — or this shard's rows
+    uint32_t *done_flag, *done_counter;   // [3] each, as `out`
+    uint32_t *decided;                // device memory
+    uint32_t *exited;                 // mapped host memory
+    uint32_t *fail;
+    uint32_t launch_id, first_seq, idle_ticks, max_polls;
+    S2rMixTail mt;                    // what does not change from fill to fill (n_blocks, groups, exchange geometry)
+    float *rows[2], *rows_mine[2];    // exchange: the root's rows by rows slot, and this shard's row among them; the ROOT's outputs:
+    float *final_out[3];
+    uint32_t *final_flag, *final_counter;
+};
+
 // what s2r_table_kernel needs: the patch resolved for a sample rate and where the planes go
 struct S2rTabBuild {
     S2rEnv mod;
@@ -262,6 +335,8 @@ hipError_t s2r_launch_noise_table(float *table_65536, hipStream_t stream);
 // one-pole single-patch handles of one workgroup only (a.p.direct_out set, a.p.frames = the longest fill): false otherwise
 hipError_t s2r_launch_resident(const S2rRenderArgs &a, const S2rResident &rs, uint32_t block_voices, hipStream_t stream);
 hipError_t s2r_launch_render(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
+// the pool-resident kernel of a one-pole single-patch shard (a.p.frames = the longest fill)
+hipError_t s2r_launch_pool(const S2rRenderArgs &a, const S2rPool &pl, uint32_t block_voices, hipStream_t stream);
 hipError_t s2r_launch_mix(const S2rMixParams &p, hipStream_t stream);
 hipError_t s2r_launch_events(const S2rVoiceArrays &v, const S2rVoiceEvent *dev_events, uint32_t n, hipStream_t stream);
 hipError_t s2r_launch_mix_and_heads(const S2rMixParams &m, int32_t *heads, const S2rTimedEvent *tev, S2rTimedEvent *tev_copy, uint32_t n,

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <atomic>
 #include <memory>
 #include <new>
@@ -68,6 +69,24 @@ float ms_as_samples(float ms, uint32_t sample_rate) {
     return sr * seconds;
 }
 
+// one turn of a spin loop
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::atomic_signal_fence(std::memory_order_seq_cst);
+#endif
+}
+inline void store_fence() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_sfence();
+#else
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+#endif
+}
+
 S2rEnv resolve_env(const s2r_adsr &a, uint32_t sample_rate) {
     S2rEnv e;
     e.A = ms_as_samples(a.attack_ms, sample_rate);
@@ -101,8 +120,13 @@ struct EventSlot {
     // record none.
     hipEvent_t done = nullptr;
     int state = 0;
-    uint32_t idx = 0, seq = 0;
+    volatile uint32_t *word = nullptr;   // state 2: the completion word (host view) ...
+    uint32_t seq = 0;                    // ... and the value it shows once the fill is done
 };
+
+// mapped host memory the host polls, or reads behind a flag the device sets: coherent (fine-grained) whatever the
+// runtime's default or HIP_HOST_COHERENT say, and visible to every device of a device list
+constexpr unsigned kHostPolled = hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable;
 
 }  // namespace
 
@@ -176,6 +200,28 @@ struct s2r_synth {
     S2rOverlapWords *ov_words = nullptr;         // device memory
     uint32_t ov_render_target[2] = {0, 0}, ov_heads_target[2] = {0, 0};
     uint32_t ov_fill = 0;                        // overlapped fills begun so far: the next one's parity is its low bit
+    // One launch per fill (S2rMixTail, s2r_device.h): the render kernel builds its own chain heads from the fill's records grouped
+    // by workgroup and the last workgroups to finish add the rows up.  S2R_FUSED=0: the three-launch form (heads, render, mix)
+    int fused_mode = 1;                          // 0 never; 1 everything but the two-stream fills of s2r_fill_begin; 2 those too
+    uint32_t *fz_arrive = nullptr;               // device memory [2]: rows written, by parity (launches per fill use [0])
+    uint32_t fz_target[2] = {0, 0};
+    FastDiv div_block;                           // local voice -> workgroup
+    std::vector<S2rTimedEvent> tsorted;          // the fill's records grouped by workgroup ...
+    std::vector<uint32_t> tperm, tbounds;        // ... arrival index -> grouped index; workgroup b's records are [tbounds[b], tbounds[b + 1])
+    // exchange of partial rows between the shards of a device list: a counter per rows slot in the parent's device memory
+    uint32_t *rows_done = nullptr;
+    uint32_t rows_target[2] = {0, 0};
+    bool force_stage = false, force_peer = false;   // S2R_FORCE_STAGE / S2R_FORCE_PEER: the multi-device branches on one device (tests)
+    // The pool-resident render kernel (S2rPool, s2r_device.h; s2r_set_resident): running on `stream` between fills while
+    // pool_running; stopped by every entry point that touches the device or what the kernel's arguments were built from
+    bool resident = false, pool_running = false;
+    uint32_t pool_seq = 0, pool_launch_id = 0, pool_rate = 0, pool_fills = 0;
+    uint32_t *pool_cmd = nullptr, *pool_cmd_dev = nullptr; bool pool_cmd_vram = false;
+    uint32_t *pool_slices = nullptr, *pool_slices_dev = nullptr;   // mapped host memory [S2R_POOL_CMD_SLOTS][n_blocks + 1]
+    uint32_t *pool_host = nullptr, *pool_host_dev = nullptr;       // mapped host memory: [0] the kernel's "exited" word
+    uint32_t *pool_decided = nullptr;                              // device memory
+    uint32_t pool_idle_ticks = 200000u;                            // 2 ms without a command
+    int n_cu = 0;
     float *os_buf = nullptr, *os_taps = nullptr; // 4x oversampling: [62 history + max_frames] mix at 4x rate, 63 taps
     float *sin_dev = nullptr;
     float *noise_dev = nullptr;                  // the noise table (S2rRenderParams.noise_tab), 65 536 floats
@@ -219,8 +265,10 @@ int set_err(s2r_synth *s, int code, const char *fmt, ...) {
 }
 
 // every entry point that touches the device, or anything a running resident kernel's arguments were built from, first
-#define S2R_QUIESCE(s) do { const int rc_q_ = resident_stop(s); if (rc_q_ != S2R_OK) return rc_q_; } while (0)
+#define S2R_QUIESCE(s) do { const int rc_q_ = quiesce(s); if (rc_q_ != S2R_OK) return rc_q_; } while (0)
 int resident_stop(s2r_synth *s);
+int pool_stop(s2r_synth *s);
+int quiesce(s2r_synth *s) { int rc = resident_stop(s); return rc != S2R_OK ? rc : pool_stop(s); }
 
 #define S2R_HIP(s, call)                                                                              \
     do {                                                                                              \
@@ -301,7 +349,7 @@ int overlap_drain(s2r_synth *s) {
 // waits until nothing on the device reads the slot's pinned records any more
 int slot_release(s2r_synth *s, EventSlot &sl) {
     if (sl.state == 1) S2R_HIP(s, hipEventSynchronize(sl.done));
-    else if (sl.state == 2 && (int32_t)(*(volatile uint32_t *)(s->done_host + sl.idx) - sl.seq) < 0) {
+    else if (sl.state == 2 && (int32_t)(*sl.word - sl.seq) < 0) {
         // (four slots rotate and at most two fills are in flight, so this is the rare path: the fill's last kernel — its
         // mix, possibly still deferred — has not reported yet)
         int rc = launch_deferred_mix(s, s->stream);
@@ -362,7 +410,7 @@ int flush_events(s2r_synth *s, hipStream_t stream, EventSlot **timed_slot, const
         for (EventSlot &e : s->slots) {
             e.state = 0;                                       // (both streams were just waited for)
             S2R_HIP(s, hipHostFree(e.thost)); e.thost = nullptr; e.tdev = nullptr;
-            S2R_HIP(s, hipHostMalloc((void **)&e.thost, (size_t)cap * sizeof(S2rTimedEvent), hipHostMallocMapped));
+            S2R_HIP(s, hipHostMalloc((void **)&e.thost, (size_t)cap * sizeof(S2rTimedEvent), kHostPolled));
             S2R_HIP(s, hipHostGetDevicePointer((void **)&e.tdev, e.thost, 0));
         }
         S2R_HIP(s, hipFree(s->tev_copy)); s->tev_copy = nullptr;
@@ -401,7 +449,7 @@ int flush_events(s2r_synth *s, hipStream_t stream, EventSlot **timed_slot, const
         for (const S2rTimedEvent &e : s->tpending) s->tlast[e.voice] = -1;
         s->tpending.clear();
     } else if (done) {
-        sl.state = 2; sl.idx = (uint32_t)(done->flag - s->done_dev); sl.seq = done->value;
+        sl.state = 2; sl.word = s->done_host + (done->flag - s->done_dev); sl.seq = done->value;
     } else {
         S2R_HIP(s, hipEventRecord(sl.done, stream));
         sl.state = 1;
@@ -527,10 +575,372 @@ S2rRenderParams make_params(s2r_synth *s, size_t frames, uint32_t sample_rate) {
     return p;
 }
 
+// ---- one launch per fill (S2rMixTail, s2r_device.h) and the pool-resident kernel (S2rPool) ----
+
+// what a shard's last mixer does with its row when the fill's output is the sum of several shards' rows (a device list)
+struct Exchange {
+    uint32_t *rows_done = nullptr;       // counter in the root's memory, this rows slot's
+    uint32_t rows_target = 0;
+    uint32_t n_rows = 0, row_stride = 0;
+    const float *rows = nullptr;
+    float *final_out = nullptr;
+    S2rDone final_done{nullptr, 0u, nullptr};
+    bool final_stereo = false;
+    volatile uint32_t *slot_word = nullptr;   // the completion word (host view) that says the fill's records are no longer read
+};
+
+bool onepole_single_patch(const s2r_synth *s) {
+    return s->bank.size() == 1 && s->bank[0].osc_kind <= S2R_OSC_SINE && s->bank[0].lpf_kind == S2R_FILT_ONEPOLE;
+}
+
+// The fill's folded frame-0 events become frame-0 records at the head of their voices' chains: a folded record is "restart,
+// then maybe release" or "release" (push_event), which is what one timed record expresses too.
+void merge_pending_into_chains(s2r_synth *s) {
+    if (s->pending.empty()) return;
+    std::vector<int32_t> &first = s->tfirst;
+    for (size_t i = 0; i < s->tpending.size(); i++)
+        if (s->tpending[i].flags & S2R_TEV_FIRST) first[s->tpending[i].voice] = (int32_t)i;
+    for (const S2rVoiceEvent &e : s->pending) {
+        S2rTimedEvent te{};
+        te.voice = e.voice; te.frame = 0; te.flags = (e.flags & (S2R_EV_RESTART | S2R_EV_RELEASE)) | S2R_TEV_FIRST;
+        te.pitch = e.pitch; te.seed = e.seed; te.program = e.flags >> S2R_EV_PROGRAM_SHIFT;
+        te.next = first[e.voice];
+        if (te.next >= 0) s->tpending[(size_t)te.next].flags &= ~S2R_TEV_FIRST;
+        s->tpending.push_back(te);
+    }
+    for (const S2rTimedEvent &e : s->tpending) first[e.voice] = -1;
+    for (const S2rVoiceEvent &e : s->pending) s->pending_slot[e.voice] = -1;
+    s->pending.clear();
+}
+
+// more timed events in one fill than the buffers hold: grow all of them (rare; every user of the old buffers is waited for)
+int ensure_tev_capacity(s2r_synth *s, uint32_t nt, hipStream_t stream) {
+    if (nt <= s->tev_capacity) return S2R_OK;
+    S2R_HIP(s, hipStreamSynchronize(stream));
+    S2R_HIP(s, hipStreamSynchronize(s->stream));
+    if (s->stream_b) S2R_HIP(s, hipStreamSynchronize(s->stream_b));
+    uint32_t cap = s->tev_capacity;
+    while (cap < nt) cap *= 2u;
+    for (EventSlot &e : s->slots) {
+        e.state = 0;                                       // (both streams were just waited for)
+        S2R_HIP(s, hipHostFree(e.thost)); e.thost = nullptr; e.tdev = nullptr;
+        S2R_HIP(s, hipHostMalloc((void **)&e.thost, (size_t)cap * sizeof(S2rTimedEvent), kHostPolled));
+        S2R_HIP(s, hipHostGetDevicePointer((void **)&e.tdev, e.thost, 0));
+    }
+    S2R_HIP(s, hipFree(s->tev_copy)); s->tev_copy = nullptr;
+    S2R_HIP(s, hipMalloc((void **)&s->tev_copy, (size_t)cap * sizeof(S2rTimedEvent)));
+    s->tevcopy2[0] = s->tev_copy;
+    if (s->tevcopy2[1]) {
+        S2R_HIP(s, hipFree(s->tevcopy2[1])); s->tevcopy2[1] = nullptr;
+        S2R_HIP(s, hipMalloc((void **)&s->tevcopy2[1], (size_t)cap * sizeof(S2rTimedEvent)));
+    }
+    s->tev_capacity = cap;
+    return S2R_OK;
+}
+
+// The fill's events — all of them, the folded frame-0 ones as records too — grouped by workgroup in an event slot's mapped
+// buffer, the groups' bounds in s->tbounds.  *slot_out: the slot (nullptr: the fill has no events).
+int fused_events(s2r_synth *s, hipStream_t stream, EventSlot **slot_out, uint32_t *nt_out) {
+    *slot_out = nullptr; *nt_out = 0;
+    merge_pending_into_chains(s);
+    const uint32_t nt = (uint32_t)s->tpending.size();
+    s->tbounds.assign((size_t)s->n_blocks + 1u, 0u);
+    if (nt == 0) return S2R_OK;
+    { int rc = ensure_tev_capacity(s, nt, stream); if (rc != S2R_OK) return rc; }
+    EventSlot &sl = s->slots[s->next_slot];
+    s->next_slot = (s->next_slot + 1) % kEventSlots;
+    { int rc = slot_release(s, sl); if (rc != S2R_OK) return rc; }
+    // counting sort by workgroup; a voice's chain keeps its order (the links are carried over to the new indices)
+    uint32_t *b = s->tbounds.data();
+    for (const S2rTimedEvent &e : s->tpending) b[s->div_block.div(e.voice) + 1u]++;
+    for (uint32_t k = 0; k < s->n_blocks; k++) b[k + 1u] += b[k];
+    s->tperm.resize(nt);
+    {
+        static thread_local std::vector<uint32_t> cur;
+        cur.assign(b, b + s->n_blocks);
+        for (uint32_t i = 0; i < nt; i++) s->tperm[i] = cur[s->div_block.div(s->tpending[i].voice)]++;
+    }
+    s->tsorted.resize(nt);
+    for (uint32_t i = 0; i < nt; i++) {
+        S2rTimedEvent e = s->tpending[i];
+        if (e.next >= 0) e.next = (int32_t)s->tperm[(size_t)e.next];
+        s->tsorted[s->tperm[i]] = e;
+    }
+    std::memcpy(sl.thost, s->tsorted.data(), (size_t)nt * sizeof(S2rTimedEvent));
+    for (const S2rTimedEvent &e : s->tpending) s->tlast[e.voice] = -1;
+    s->tpending.clear();
+    *slot_out = &sl; *nt_out = nt;
+    return S2R_OK;
+}
+
+uint32_t pick_mixers(const s2r_synth *s, size_t frames) {
+    uint32_t m = 16u;
+    if (m > s->n_blocks) m = s->n_blocks;
+    const uint32_t fb = (uint32_t)((frames + 15u) / 16u);
+    if (m > fb) m = fb;
+    return m ? m : 1u;
+}
+
+// the part of S2rMixTail that a shard's geometry fixes
+S2rMixTail mix_tail_of(const s2r_synth *s, bool root_add) {
+    S2rMixTail mt{};
+    mt.n_blocks = s->n_blocks;
+    mt.n_groups = root_add ? s->mix_groups : 1u;
+    mt.blocks_per_group = (s->n_blocks + mt.n_groups - 1u) / mt.n_groups;
+    mt.root_add = root_add ? 1 : 0;
+    return mt;
+}
+
+// Can this shard's fills take the one-launch form?  The one-pole kernel (the general kernel keeps the three-launch form for
+// now), more than one workgroup (a single one writes the output itself), the bounds in the kernel arguments, the mix's run
+// sums in the staging the render kernel has anyway.
+bool fused_shape_ok(const s2r_synth *s) {
+    if (!s->fused_mode || !onepole_single_patch(s) || s->n_blocks < 2u) return false;
+    if ((size_t)s->n_blocks + 1u > 3u * S2R_ARG_MAX_EVENTS) return false;
+    const uint32_t groups = s->mix_groups ? s->mix_groups : 1u;
+    const uint32_t runs = ((s->n_blocks + groups - 1u) / groups + 15u) / 16u * groups;
+    return runs * 16u <= 16u * 32u;                              // (the smallest group-sum buffer: 16 groups x 32 frames)
+}
+
+// events -> ONE render launch on `stream`; the mix (root-added or this shard's partial row) lands in `dev_out`
+int enqueue_fused(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t stream, float *dev_out, bool root_add, bool stereo,
+                  const S2rDone *done, const Exchange *xc) {
+    { int rc = overlap_drain(s); if (rc != S2R_OK) return rc; }
+    { int rc = launch_deferred_mix(s, s->stream); if (rc != S2R_OK) return rc; }
+    bool arg_events = s->use_arg_events && s->tpending.empty() && s->pending.size() <= S2R_ARG_MAX_EVENTS;
+    if (arg_events)
+        for (const S2rVoiceEvent &e : s->pending) if (e.seed != 0u) { arg_events = false; break; }
+    EventSlot *slot = nullptr;
+    uint32_t nt = 0;
+    if (!arg_events) { int rc = fused_events(s, stream, &slot, &nt); if (rc != S2R_OK) return rc; }
+    static thread_local S2rRenderArgs a;
+    S2rRenderParams &p = a.p;
+    p = make_params(s, frames, sample_rate);
+    { int rc = ensure_tables(s, p, sample_rate, stream); if (rc != S2R_OK) return rc; }
+    if (tables_wanted(s)) p.tab = s->tab;
+    p.stamps = s->stamps_dev;
+    if (s->timeline_dev && s->timeline_n < s->timeline_cap) { p.timeline = s->timeline_dev; p.tl_slot = s->timeline_n++; }
+    p.voice_ev_head = s->voice_ev_head;
+    p.ov_fail = s->done_dev + 3;
+    a.n_events = 0;
+    if (arg_events) {
+        a.n_events = (uint32_t)s->pending.size();
+        for (uint32_t i = 0; i < a.n_events; i++) {
+            const S2rVoiceEvent &e = s->pending[i];
+            a.ev[3u * i] = e.voice; a.ev[3u * i + 1u] = e.flags; a.ev[3u * i + 2u] = s2r_f2u(e.pitch);
+        }
+        for (const S2rVoiceEvent &e : s->pending) s->pending_slot[e.voice] = -1;
+        s->pending.clear();
+    } else if (slot) {
+        p.tev = s->tev_copy; p.tev_copy = s->tev_copy; p.tev_src = slot->tdev; p.slices = nullptr;
+        std::memcpy(a.ev, s->tbounds.data(), ((size_t)s->n_blocks + 1u) * sizeof(uint32_t));
+    }
+    p.arrive = s->fz_arrive;
+    s->fz_target[0] += s->n_blocks;
+    p.arrive_target = s->fz_target[0];
+    S2rMixTail &mt = p.mt;
+    mt = mix_tail_of(s, root_add);
+    mt.n_mixers = pick_mixers(s, frames);
+    mt.stereo = stereo ? 1 : 0;
+    mt.out = dev_out;
+    mt.done = done ? *done : S2rDone{nullptr, 0u, s->done_counter + 3};
+    if (xc) {
+        mt.done.flag = nullptr;
+        mt.rows_done = xc->rows_done; mt.rows_target = xc->rows_target;
+        mt.n_rows = xc->n_rows; mt.row_stride = xc->row_stride; mt.rows = xc->rows;
+        mt.final_out = xc->final_out; mt.final_done = xc->final_done; mt.final_stereo = xc->final_stereo ? 1 : 0;
+    }
+    if (s->timing) S2R_HIP(s, hipEventRecord(s->t0, stream));
+    S2R_HIP(s, s2r_launch_render(a, s->block_voices, stream));
+    if (s->timing) { S2R_HIP(s, hipEventRecord(s->t1, stream)); s->timed = true; }
+    if (slot) {                                   // the render kernel is the only reader of the slot's records
+        if (xc && xc->slot_word) { slot->state = 2; slot->word = xc->slot_word; slot->seq = xc->final_done.value; }
+        else if (done && done->flag) { slot->state = 2; slot->word = s->done_host + (done->flag - s->done_dev); slot->seq = done->value; }
+        else { S2R_HIP(s, hipEventRecord(slot->done, stream)); slot->state = 1; }
+    }
+    if (!s->parent) {                             // (a device-list handle moves the shared clock once, after its shards)
+        s->pool->advance(frames - s->fill_time);
+        s->fill_time = 0;
+    }
+    return S2R_OK;
+}
+
+// ---- the pool-resident kernel (S2rPool, s2r_device.h; s2r_set_resident) ----
+
+bool pool_exited(const s2r_synth *s) { return __atomic_load_n(&s->pool_host[0], __ATOMIC_ACQUIRE) == s->pool_launch_id; }
+
+// a fill the pool-resident kernel can take: the one-launch form's shape, a grid that is resident as a whole (at most one
+// workgroup of at most 256 threads per compute unit), nothing that brackets or watches single launches
+bool pool_eligible(const s2r_synth *s, size_t frames) {
+    return s->resident && s->kids.empty() && s->pool_cmd != nullptr && fused_shape_ok(s) && (int)s->n_blocks <= s->n_cu && s->block_voices <= 256u &&
+           !s->timing && s->timeline_dev == nullptr && s->stamps_dev == nullptr && frames <= 0xffffu && frames <= s->cfg.max_frames;
+}
+
+// what the kernel needs besides the handle's ordinary buffers: the command ring, the slices, the decision word, and the second
+// parity's rows, heads and event copy (a workgroup may be a fill ahead of its neighbours)
+int pool_setup(s2r_synth *s) {
+    if (s->pool_cmd) return S2R_OK;
+    S2R_HIP(s, hipSetDevice(s->device));
+    S2R_HIP(s, hipHostMalloc((void **)&s->pool_host, 16 * sizeof(uint32_t), kHostPolled));
+    std::memset(s->pool_host, 0, 16 * sizeof(uint32_t));
+    S2R_HIP(s, hipHostGetDevicePointer((void **)&s->pool_host_dev, s->pool_host, 0));
+    const size_t sl_words = (size_t)S2R_POOL_CMD_SLOTS * (s->n_blocks + 1u);
+    S2R_HIP(s, hipHostMalloc((void **)&s->pool_slices, sl_words * sizeof(uint32_t), kHostPolled));
+    std::memset(s->pool_slices, 0, sl_words * sizeof(uint32_t));
+    S2R_HIP(s, hipHostGetDevicePointer((void **)&s->pool_slices_dev, s->pool_slices, 0));
+    S2R_HIP(s, hipMalloc((void **)&s->pool_decided, sizeof(uint32_t)));
+    const size_t pv = s->padded_voices;
+    if (!s->partials2[1]) S2R_HIP(s, hipMalloc((void **)&s->partials2[1], (size_t)s->n_blocks * partials_stride(s->cfg.max_frames) * sizeof(float)));
+    if (!s->heads2[1]) {
+        S2R_HIP(s, hipMalloc((void **)&s->heads2[1], pv * sizeof(int32_t)));
+        S2R_HIP(s, hipMemset(s->heads2[1], 0xff, pv * sizeof(int32_t)));
+    }
+    if (!s->tevcopy2[1]) S2R_HIP(s, hipMalloc((void **)&s->tevcopy2[1], (size_t)s->tev_capacity * sizeof(S2rTimedEvent)));
+    // The command where the CPU's write is one posted trip and the kernel's polls none: fine-grained device memory behind the
+    // BAR (as the one-workgroup resident kernel's); else mapped host memory.  S2R_RES_CMD_HOST=1 keeps it in host memory.
+    const size_t cmd_words = (size_t)S2R_POOL_CMD_SLOTS * S2R_POOL_CMD_WORDS;
+    int large_bar = 0;
+    const char *force_host = std::getenv("S2R_RES_CMD_HOST");
+    if (!(force_host && force_host[0] == '1') &&
+        hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, s->device) == hipSuccess && large_bar) {
+        uint32_t *v = nullptr;
+        if (hipExtMallocWithFlags((void **)&v, cmd_words * sizeof(uint32_t), hipDeviceMallocFinegrained) == hipSuccess && v) {
+            S2R_HIP(s, hipMemset(v, 0, cmd_words * sizeof(uint32_t)));
+            S2R_HIP(s, hipDeviceSynchronize());
+            s->pool_cmd = v; s->pool_cmd_dev = v; s->pool_cmd_vram = true;
+        } else (void)hipGetLastError();
+    }
+    if (!s->pool_cmd) {
+        uint32_t *h = nullptr;
+        S2R_HIP(s, hipHostMalloc((void **)&h, cmd_words * sizeof(uint32_t), kHostPolled));
+        std::memset(h, 0, cmd_words * sizeof(uint32_t));
+        S2R_HIP(s, hipHostGetDevicePointer((void **)&s->pool_cmd_dev, h, 0));
+        s->pool_cmd = h; s->pool_cmd_vram = false;
+    }
+    return S2R_OK;
+}
+
+// payload first, then word 15, then word 0 (device memory behind the BAR is write-combining: the fences order the stages)
+uint32_t pool_post(s2r_synth *s, const uint32_t *w) {
+    const uint32_t seq = ++s->pool_seq;
+    volatile uint32_t *c = s->pool_cmd + (size_t)(seq % S2R_POOL_CMD_SLOTS) * S2R_POOL_CMD_WORDS;
+    for (uint32_t i = 1; i < 15; i++) c[i] = w[i];
+    if (s->pool_cmd_vram) store_fence();
+    __atomic_store_n(&c[15], seq, __ATOMIC_RELEASE);
+    if (s->pool_cmd_vram) store_fence();
+    __atomic_store_n(&c[0], seq, __ATOMIC_RELEASE);
+    if (s->pool_cmd_vram) store_fence();
+    return seq;
+}
+
+// Ends the pool-resident kernel, if there is one, and waits for it: the stream is the caller's again.
+int pool_stop(s2r_synth *s) {
+    if (!s) return S2R_OK;
+    for (s2r_synth *kid : s->kids) { int rc = pool_stop(kid); if (rc != S2R_OK) { s->err = kid->err; return rc; } }
+    if (!s->pool_running) return S2R_OK;
+    uint32_t w[16] = {0};
+    w[1] = S2R_POOL_FLAG_EXIT << 16;
+    (void)pool_post(s, w);
+    s->pool_running = false;
+    S2R_HIP(s, hipSetDevice(s->device));
+    S2R_HIP(s, hipStreamSynchronize(s->stream));
+    return S2R_OK;
+}
+
+int pool_launch(s2r_synth *s, uint32_t sample_rate, uint32_t first_seq) {
+    S2R_HIP(s, hipSetDevice(s->device));
+    static thread_local S2rRenderArgs a;
+    S2rRenderParams &p = a.p;
+    p = make_params(s, s->cfg.max_frames, sample_rate);          // (p.frames: the longest fill, sizes the staging)
+    { int rc = ensure_tables(s, p, sample_rate, s->stream); if (rc != S2R_OK) return rc; }
+    if (tables_wanted(s)) p.tab = s->tab;
+    p.voice_ev_head = s->voice_ev_head;
+    p.tev = s->tev_copy;                                         // (MODE 2: a fill's events come as chains)
+    a.n_events = 0;
+    S2rPool pl{};
+    pl.cmd = s->pool_cmd_dev; pl.slices = s->pool_slices_dev; pl.slices_stride = s->n_blocks + 1u;
+    for (int k = 0; k < 4; k++) pl.tev_src[k] = s->slots[k].tdev;
+    for (int b = 0; b < 2; b++) { pl.tev_copy[b] = s->tevcopy2[b]; pl.heads[b] = s->heads2[b]; pl.partials[b] = s->partials2[b]; }
+    pl.arrive = s->fz_arrive;
+    pl.out[0] = s->ring_dev[0]; pl.out[1] = s->ring_dev[1]; pl.out[2] = s->out_host_dev;
+    pl.done_flag = s->done_dev; pl.done_counter = s->done_counter;
+    pl.decided = s->pool_decided; pl.exited = s->pool_host_dev; pl.fail = s->done_dev + 3;
+    pl.launch_id = ++s->pool_launch_id; pl.first_seq = first_seq;
+    pl.idle_ticks = s->pool_idle_ticks; pl.max_polls = 1u << 24;
+    s2r_synth *par = s->parent;
+    pl.mt = mix_tail_of(s, par == nullptr);
+    if (par) {                                                   // a shard of a device list: its row, the count, and — the first shard — the sum
+        uint32_t k = 0;
+        while (k < par->kids.size() && par->kids[k] != s) k++;
+        pl.mt.rows_done = par->rows_done;
+        pl.mt.n_rows = (uint32_t)par->kids.size(); pl.mt.row_stride = par->cfg.max_frames;
+        for (int b = 0; b < 2; b++) { pl.rows[b] = par->rows_dev[b]; pl.rows_mine[b] = par->rows_dev[b] + (size_t)k * par->cfg.max_frames; }
+        pl.final_out[0] = par->ring_dev[0]; pl.final_out[1] = par->ring_dev[1]; pl.final_out[2] = par->out_host_dev;
+        pl.final_flag = par->done_dev; pl.final_counter = nullptr;
+    }
+    S2R_HIP(s, hipMemsetD32Async((hipDeviceptr_t)s->pool_decided, (int)((first_seq - 1u) << 1), 1, s->stream));
+    S2R_HIP(s, s2r_launch_pool(a, pl, s->block_voices, s->stream));
+    s->pool_running = true; s->pool_rate = sample_rate;
+    return S2R_OK;
+}
+
+// The kernel has left with commands unexecuted (it ran out of patience just as one was posted): start it again in front of them.
+int pool_recover(s2r_synth *s) {
+    if (!s->pool_running || !pool_exited(s)) return S2R_OK;
+    s->pool_running = false;
+    S2R_HIP(s, hipSetDevice(s->device));
+    S2R_HIP(s, hipStreamSynchronize(s->stream));
+    uint32_t d = 0;
+    S2R_HIP(s, hipMemcpy(&d, s->pool_decided, sizeof d, hipMemcpyDeviceToHost));
+    const uint32_t first = (d & 1u) ? (d >> 1) : (d >> 1) + 1u;  // (left at command d >> 1, or — no bail recorded — after it)
+    if ((int32_t)(s->pool_seq - first) < 0) return S2R_OK;        // nothing was pending
+    return pool_launch(s, s->pool_rate, first);
+}
+
+// One fill through the pool-resident kernel: the events grouped by workgroup, the bounds, the command.  `sel`: where the output
+// goes (0, 1 the ring slots, 2 the synchronous buffer); xc: the shard's part in a device list's exchange.
+int pool_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, uint32_t sel, bool stereo, uint32_t done_value, const Exchange *xc, uint32_t rows_slot) {
+    { int rc = overlap_drain(s); if (rc != S2R_OK) return rc; }
+    { int rc = launch_deferred_mix(s, s->stream); if (rc != S2R_OK) return rc; }
+    if (s->pool_running && (s->pool_rate != sample_rate || pool_exited(s) || s->pending.size() + s->tpending.size() > s->tev_capacity)) {
+        int rc = pool_exited(s) ? pool_recover(s) : S2R_OK;
+        if (rc == S2R_OK) rc = pool_stop(s);
+        if (rc != S2R_OK) return rc;
+    }
+    EventSlot *slot = nullptr;
+    uint32_t nt = 0;
+    { int rc = fused_events(s, s->stream, &slot, &nt); if (rc != S2R_OK) return rc; }
+    const uint32_t par = s->pool_fills++ & 1u;
+    s->fz_target[par] += s->n_blocks;
+    uint32_t w[16] = {0};
+    w[1] = (uint32_t)frames; w[2] = nt; w[3] = done_value; w[4] = sel | (stereo ? 256u : 0u);
+    w[5] = slot ? (uint32_t)(slot - s->slots) : 0u; w[6] = par; w[7] = s->fz_target[par]; w[8] = pick_mixers(s, frames);
+    w[9] = xc ? xc->rows_target : 0u; w[10] = rows_slot;
+    const uint32_t next_seq = s->pool_seq + 1u;
+    std::memcpy(s->pool_slices + (size_t)(next_seq % S2R_POOL_CMD_SLOTS) * (s->n_blocks + 1u), s->tbounds.data(), ((size_t)s->n_blocks + 1u) * sizeof(uint32_t));
+    std::atomic_thread_fence(std::memory_order_release);
+    const uint32_t seq = pool_post(s, w);
+    if (!s->pool_running) { int rc = pool_launch(s, sample_rate, seq); if (rc != S2R_OK) return rc; }
+    if (slot) {
+        slot->state = 2; slot->seq = done_value;
+        slot->word = (xc && xc->slot_word) ? xc->slot_word : s->done_host + sel;
+    }
+    if (!s->parent) {
+        s->pool->advance(frames - s->fill_time);
+        s->fill_time = 0;
+    }
+    return S2R_OK;
+}
+
 // events -> render -> (mix) on `stream`; the partial or final mix lands in `dev_out`
 // `defer_ring_slot` >= 0 (s2r_fill_begin): the fill's mix is left to the next fill_begin / fill_end (DeferredMix)
 int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t stream, float *dev_out,
-                 bool root_add, bool stereo, float *per_voice_dev, int defer_ring_slot = -1, const S2rDone *done = nullptr) {
+                 bool root_add, bool stereo, float *per_voice_dev, int defer_ring_slot = -1, const S2rDone *done = nullptr,
+                 const Exchange *xc = nullptr) {
+    // one launch per fill where the shard's shape allows it (the fills of s2r_fill_begin keep the two streams unless asked)
+    if (dev_out != nullptr && per_voice_dev == nullptr && fused_shape_ok(s) &&
+        (xc != nullptr || s->fused_mode >= 2 || !(s->ov_enabled && defer_ring_slot >= 0 && stream == s->stream && root_add && done != nullptr)))
+        return enqueue_fused(s, frames, sample_rate, stream, dev_out, root_add, stereo, done, xc);
     if (s->dmix.active && stream != s->stream) {
         // a fill on a caller's stream behind one in flight on ours: that one's mix reads the partial rows this fill
         // is about to overwrite
@@ -648,7 +1058,7 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
     S2R_HIP(s, s2r_launch_render(a, s->block_voices, stream));
     if (s->timing) { S2R_HIP(s, hipEventRecord(s->t1, stream)); s->timed = true; }
     if (timed_slot) {                     // the render kernel was the last reader of the slot's records
-        if (done) { timed_slot->state = 2; timed_slot->idx = (uint32_t)(done->flag - s->done_dev); timed_slot->seq = done->value; }
+        if (done) { timed_slot->state = 2; timed_slot->word = s->done_host + (done->flag - s->done_dev); timed_slot->seq = done->value; }
         else { S2R_HIP(s, hipEventRecord(timed_slot->done, stream)); timed_slot->state = 1; }
     }
     if (dev_out && !direct) {
@@ -686,11 +1096,20 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
 // A device-list handle's fill: every shard renders on its own device and stream and leaves its partial mix in row k of rows_dev[slot] on the parent's device; the parent's
 // stream waits for the rows and adds them in shard order rooted at +0.0 (synth.rs:176,195) into `dev_out`.
 int enqueue_multi(s2r_synth *s, size_t frames, uint32_t sample_rate, float *dev_out, bool stereo, float *per_voice_host = nullptr,
-                  const S2rDone *done = nullptr) {
+                  const S2rDone *done = nullptr, int rows_slot_in = -1) {
     const uint32_t n = (uint32_t)s->kids.size();
-    const uint32_t slot = s->rows_slot;
-    s->rows_slot ^= 1u;
-    auto shard_job = [s, frames, sample_rate, slot, per_voice_host](uint32_t k) -> int {
+    // (the rows of a fill of s2r_fill_begin belong to its ring slot; every other fill finds no fill in flight — fill_host and
+    // the other synchronous calls refuse a device-list handle otherwise — and takes the slot the next ring fill will not)
+    const uint32_t slot = rows_slot_in >= 0 ? (uint32_t)rows_slot_in : ((s->ring_head + s->ring_count) & 1u) ^ 1u;
+    // One launch per shard and nothing else (S2rMixTail's exchange): every shard's last mixer counts in on a word in the
+    // parent's memory, and the shard that counts in last adds the rows.  Needs a
+    // completion word to end the fill with (a consumer ordered by the parent's STREAM takes the launches below) and shards
+    // that write their rows where they are read.
+    bool exchange = done != nullptr && done->flag != nullptr && !per_voice_host && s->rows_done != nullptr;
+    for (uint32_t k = 0; k < n && exchange; k++) exchange = fused_shape_ok(s->kids[k]) && s->kid_stage[k] == nullptr;
+    if (exchange) s->rows_target[slot] += n;
+    else { int rc = pool_stop(s); if (rc != S2R_OK) return rc; }
+    auto shard_job = [s, frames, sample_rate, slot, per_voice_host, exchange, n, dev_out, stereo, done](uint32_t k) -> int {
         s2r_synth *kid = s->kids[k];
         if (hipSetDevice(kid->device) != hipSuccess) return set_err(kid, S2R_ERR_HIP, "hipSetDevice(%d) failed", kid->device);
         if (per_voice_host) {                     // (mix disabled: the shard's rows, scattered to pool order by the caller)
@@ -705,6 +1124,18 @@ int enqueue_multi(s2r_synth *s, size_t frames, uint32_t sample_rate, float *dev_
             return S2R_OK;
         }
         float *row = s->rows_dev[slot] + (size_t)k * s->cfg.max_frames;
+        if (exchange) {
+            Exchange xc;
+            xc.rows_done = s->rows_done + slot; xc.rows_target = s->rows_target[slot];
+            xc.n_rows = n; xc.row_stride = s->cfg.max_frames; xc.rows = s->rows_dev[slot];
+            xc.final_out = dev_out; xc.final_done = *done; xc.final_stereo = stereo;
+            xc.slot_word = s->done_host + (done->flag - s->done_dev);
+            if (pool_eligible(kid, frames))
+                return pool_fill(kid, frames, sample_rate, (uint32_t)(done->flag - s->done_dev), stereo, done->value, &xc, slot);
+            { int rc = pool_stop(kid); if (rc != S2R_OK) return rc; }
+            const S2rDone kd{nullptr, 0u, kid->done_counter + slot};
+            return enqueue_fill(kid, frames, sample_rate, kid->stream, row, false, false, nullptr, -1, &kd, &xc);
+        }
         float *dst = s->kid_stage[k] ? s->kid_stage[k] : row;
         // (the shard's own completion word: its event slots are then tracked without an event record per fill)
         const S2rDone kd{kid->done_dev + slot, ++kid->done_seq, kid->done_counter + slot};
@@ -723,7 +1154,7 @@ int enqueue_multi(s2r_synth *s, size_t frames, uint32_t sample_rate, float *dev_
     if (rc != S2R_OK) return rc;
     s->pool->advance(frames - s->fill_time);      // the shared clock, once
     s->fill_time = 0;
-    if (per_voice_host) return S2R_OK;
+    if (per_voice_host || exchange) return S2R_OK;
     S2R_HIP(s, hipSetDevice(s->device));
     for (uint32_t k = 0; k < n; k++) S2R_HIP(s, hipStreamWaitEvent(s->stream, s->kid_done[slot][k], 0));
     S2R_HIP(s, s2r_launch_sum_rows(s->rows_dev[slot], n, (uint32_t)frames, s->cfg.max_frames, stereo ? 1 : 0, dev_out, s->stream, done));
@@ -734,12 +1165,29 @@ int enqueue_multi(s2r_synth *s, size_t frames, uint32_t sample_rate, float *dev_
 // a bounded time, then falls back to the stream — an error on the device never leaves the caller spinning.
 int wait_done(s2r_synth *s, uint32_t idx, uint32_t seq) {
     volatile uint32_t *f = s->done_host + idx;
-    for (int round = 0; round < 400; round++) {               // ~2-4 ms in all
-        for (int i = 0; i < 4000; i++) {
+    // the spin is bounded by wall time (a fill of a big pool lasts milliseconds: no core is burnt for that long), then the
+    // stream decides
+    timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (;;) {
+        for (int i = 0; i < 2000; i++) {
             if ((int32_t)(*f - seq) >= 0) { std::atomic_thread_fence(std::memory_order_acquire); return S2R_OK; }
-            __builtin_ia32_pause();
+            cpu_relax();
         }
+        // a pool-resident kernel that left just as its command was posted is started again in front of it
+        if (s->pool_running && pool_exited(s)) { int rc = pool_recover(s); if (rc != S2R_OK) return rc; }
+        for (s2r_synth *kid : s->kids) if (kid->pool_running && pool_exited(kid)) { int rc = pool_recover(kid); if (rc != S2R_OK) { s->err = kid->err; return rc; } }
+        timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+        const double us = (double)(t1.tv_sec - t0.tv_sec) * 1e6 + (double)(t1.tv_nsec - t0.tv_nsec) * 1e-3;
+        const bool pool = s->pool_running || (!s->kids.empty() && s->kids[0]->pool_running);
+        if (us > (pool ? 200000.0 : 300.0)) break;               // (a resident kernel never ends a stream wait: only the word tells)
     }
+    if (s->pool_running || (!s->kids.empty() && s->kids[0]->pool_running)) {
+        (void)pool_stop(s);
+        if ((int32_t)(*f - seq) < 0) return set_err(s, S2R_ERR_HIP, "the pool-resident kernel did not report the fill");
+        return S2R_OK;
+    }
+    for (s2r_synth *kid : s->kids) { S2R_HIP(s, hipSetDevice(kid->device)); S2R_HIP(s, hipStreamSynchronize(kid->stream)); }
+    S2R_HIP(s, hipSetDevice(s->device));
     S2R_HIP(s, hipStreamSynchronize(s->stream));
     if (s->stream_b) S2R_HIP(s, hipStreamSynchronize(s->stream_b));
     if ((int32_t)(*f - seq) < 0) return set_err(s, S2R_ERR_HIP, "the fill's last kernel finished without signalling completion");
@@ -748,17 +1196,21 @@ int wait_done(s2r_synth *s, uint32_t idx, uint32_t seq) {
 
 // (two streams) a kernel that gave up waiting for the other stream's work says so in done_host[3]
 int overlap_check(s2r_synth *s) {
-    const uint32_t who = *(volatile uint32_t *)(s->done_host + 3);
-    if (who == 0u) return S2R_OK;
+    uint32_t who = *(volatile uint32_t *)(s->done_host + 3);
     s->done_host[3] = 0u;
-    return set_err(s, S2R_ERR_HIP, "%s gave up waiting for the other stream's kernel (S2rOverlapWords): the fill's output is not valid",
-                   who == 1u ? "a render kernel (for its chain heads)" : "a mix (for its partial rows)");
+    for (s2r_synth *kid : s->kids) { const uint32_t w = *(volatile uint32_t *)(kid->done_host + 3); kid->done_host[3] = 0u; if (w) who = w; }
+    if (who == 0u) return S2R_OK;
+    return set_err(s, S2R_ERR_HIP, "%s gave up waiting for another kernel's or workgroup's work: the fill's output is not valid",
+                   who == 1u ? "a render kernel (for its chain heads)" : who == 2u ? "a mix (for its partial rows)" : "the sum of the shards' rows (for a shard's row)");
 }
 
 // the fill of any handle on ITS stream: the final mix (root-added) lands in `dev_out`
 int enqueue_root(s2r_synth *s, size_t frames, uint32_t sample_rate, float *dev_out, bool stereo, int defer_ring_slot = -1,
                  const S2rDone *done = nullptr) {
-    if (!s->kids.empty()) return enqueue_multi(s, frames, sample_rate, dev_out, stereo, nullptr, done);
+    if (!s->kids.empty()) return enqueue_multi(s, frames, sample_rate, dev_out, stereo, nullptr, done, defer_ring_slot);
+    if (done && done->flag && pool_eligible(s, frames))
+        return pool_fill(s, frames, sample_rate, (uint32_t)(done->flag - s->done_dev), stereo, done->value, nullptr, 0u);
+    { int rc = pool_stop(s); if (rc != S2R_OK) return rc; }
     return enqueue_fill(s, frames, sample_rate, s->stream, dev_out, true, stereo, nullptr, defer_ring_slot, done);
 }
 
@@ -767,11 +1219,11 @@ int enqueue_root(s2r_synth *s, size_t frames, uint32_t sample_rate, float *dev_o
 void resident_post(s2r_synth *s, uint32_t seq) {                // payload first, then word 31, then word 0 (S2rResident)
     volatile uint32_t *c = s->res_cmd;
     // (device memory behind the BAR is write-combining: the fences are what orders the three stages on the link)
-    if (s->res_cmd_vram) __builtin_ia32_sfence();
+    if (s->res_cmd_vram) store_fence();
     __atomic_store_n(&c[31], seq, __ATOMIC_RELEASE);
-    if (s->res_cmd_vram) __builtin_ia32_sfence();
+    if (s->res_cmd_vram) store_fence();
     __atomic_store_n(&c[0], seq, __ATOMIC_RELEASE);
-    if (s->res_cmd_vram) __builtin_ia32_sfence();
+    if (s->res_cmd_vram) store_fence();
 }
 
 bool resident_exited(const s2r_synth *s) { return __atomic_load_n(&s->res_host[32], __ATOMIC_ACQUIRE) == s->res_launch_id; }
@@ -857,7 +1309,7 @@ int resident_fill(s2r_synth *s, float *out, size_t frames, uint32_t sample_rate,
         for (int round = 0; round < 4000 && !done; round++) {
             for (int i = 0; i < 1000; i++) {
                 if (arrived()) { done = true; break; }
-                __builtin_ia32_pause();
+                cpu_relax();
             }
             if (!done && resident_exited(s)) break;
         }
@@ -892,6 +1344,8 @@ int fill_host(s2r_synth *s, float *out, size_t frames, uint32_t sample_rate, boo
     if (rc != S2R_OK) return rc;
     if (frames == 0) return S2R_OK;
     if (!out) return set_err(s, S2R_ERR_INVALID, "null output buffer");
+    if (!s->kids.empty() && s->ring_count)
+        return set_err(s, S2R_ERR_INVALID, "a device-list handle takes no synchronous fill while fills of s2r_fill_begin are in flight (their rows are the shards'): s2r_fill_end first");
     // (the resident kernel's fills make no HIP call while it runs)
     if (resident_eligible(s, frames)) return resident_fill(s, out, frames, sample_rate, stereo);
     S2R_HIP(s, hipSetDevice(s->device));
@@ -911,7 +1365,7 @@ int fill_host(s2r_synth *s, float *out, size_t frames, uint32_t sample_rate, boo
 
 void release_all(s2r_synth *s) {
     if (!s) return;
-    (void)resident_stop(s);
+    (void)quiesce(s);
     for (s2r_synth *kid : s->kids) release_all(kid);
     s->kids.clear();
     (void)hipSetDevice(s->device);
@@ -927,6 +1381,12 @@ void release_all(s2r_synth *s) {
         if (sl.thost) (void)hipHostFree(sl.thost);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
+    if (s->fz_arrive) (void)hipFree(s->fz_arrive);
+    if (s->rows_done) (void)hipFree(s->rows_done);
+    if (s->pool_cmd_vram && s->pool_cmd) (void)hipFree(s->pool_cmd);
+    if (s->pool_host) (void)hipHostFree(s->pool_host);
+    if (s->pool_slices) (void)hipHostFree(s->pool_slices);
+    if (s->pool_decided) (void)hipFree(s->pool_decided);
     if (s->voice_mem) (void)hipFree(s->voice_mem);
     if (s->bank_dev) (void)hipFree(s->bank_dev);
     if (s->os_buf) (void)hipFree(s->os_buf);
@@ -1072,26 +1532,31 @@ static int create_single(const s2r_config *cfg, std::shared_ptr<S2rVoicePool> po
     CREATE_HIP(hipMalloc((void **)&s->bank_dev, S2R_MAX_BANK * sizeof(S2rBankEntry)));
     CREATE_HIP(hipMalloc((void **)&s->block_partials, (size_t)s->n_blocks * partials_stride(cfg->max_frames) * sizeof(float)));
     CREATE_HIP(hipMalloc((void **)&s->out_dev, (size_t)2 * cfg->max_frames * sizeof(float)));
-    CREATE_HIP(hipHostMalloc((void **)&s->out_host, (size_t)2 * cfg->max_frames * sizeof(float), hipHostMallocMapped));
+    CREATE_HIP(hipHostMalloc((void **)&s->out_host, (size_t)2 * cfg->max_frames * sizeof(float), kHostPolled));
     CREATE_HIP(hipHostGetDevicePointer((void **)&s->out_host_dev, s->out_host, 0));
     for (int k = 0; k < 2; k++) {
-        CREATE_HIP(hipHostMalloc((void **)&s->ring_host[k], (size_t)cfg->max_frames * sizeof(float), hipHostMallocMapped));
+        CREATE_HIP(hipHostMalloc((void **)&s->ring_host[k], (size_t)cfg->max_frames * sizeof(float), kHostPolled));
         CREATE_HIP(hipHostGetDevicePointer((void **)&s->ring_dev[k], s->ring_host[k], 0));
         CREATE_HIP(hipEventCreateWithFlags(&s->ring_done[k], hipEventDisableTiming));
     }
-    CREATE_HIP(hipHostMalloc((void **)&s->done_host, 16 * sizeof(uint32_t), hipHostMallocMapped));
+    CREATE_HIP(hipHostMalloc((void **)&s->done_host, 16 * sizeof(uint32_t), kHostPolled));
     std::memset(s->done_host, 0, 16 * sizeof(uint32_t));
     CREATE_HIP(hipHostGetDevicePointer((void **)&s->done_dev, s->done_host, 0));
     CREATE_HIP(hipMalloc((void **)&s->done_counter, 4 * sizeof(uint32_t)));
     CREATE_HIP(hipMemsetAsync(s->done_counter, 0, 4 * sizeof(uint32_t), s->stream));
+    CREATE_HIP(hipMalloc((void **)&s->fz_arrive, 2 * sizeof(uint32_t)));
+    CREATE_HIP(hipMemsetAsync(s->fz_arrive, 0, 2 * sizeof(uint32_t), s->stream));
+    s->div_block.set(bv);
+    { const char *e = std::getenv("S2R_FUSED"); if (e && e[0] >= '0' && e[0] <= '2') s->fused_mode = e[0] - '0'; }
+    if (hipDeviceGetAttribute(&s->n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) s->n_cu = 0;
     s->tev_capacity = shard_voices < 4096u ? 4096u : shard_voices;
     s->tlast.assign(shard_voices, -1);
     s->tfirst.assign(shard_voices, -1);
     for (EventSlot &sl : s->slots) {
-        CREATE_HIP(hipHostMalloc((void **)&sl.host, (size_t)shard_voices * sizeof(S2rVoiceEvent), hipHostMallocMapped));
+        CREATE_HIP(hipHostMalloc((void **)&sl.host, (size_t)shard_voices * sizeof(S2rVoiceEvent), kHostPolled));
         CREATE_HIP(hipHostGetDevicePointer((void **)&sl.dev, sl.host, 0));
         CREATE_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-        CREATE_HIP(hipHostMalloc((void **)&sl.thost, (size_t)s->tev_capacity * sizeof(S2rTimedEvent), hipHostMallocMapped));
+        CREATE_HIP(hipHostMalloc((void **)&sl.thost, (size_t)s->tev_capacity * sizeof(S2rTimedEvent), kHostPolled));
         CREATE_HIP(hipHostGetDevicePointer((void **)&sl.tdev, sl.thost, 0));
     }
     CREATE_HIP(hipMalloc((void **)&s->voice_ev_head, pv * sizeof(int32_t)));
@@ -1104,10 +1569,10 @@ static int create_single(const s2r_config *cfg, std::shared_ptr<S2rVoicePool> po
         // chain-heads workgroups it waits for always find room beside it.  (A grid of two workgroups per CU holds every
         // register: its waiting workgroups would keep out the ones they wait for — seen at 131 072 voices, as the bounded
         // wait's error.)
+        // (a shard of a device list never begins a fill of its own: no second stream, no second buffers for it)
         const char *e = std::getenv("S2R_OVERLAP");
-        int n_cu = 0;
-        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 0;
-        if (s->n_blocks > 1 && (int)s->n_blocks <= n_cu && s->block_voices <= 256u && !(e && e[0] == '0')) {
+        const int n_cu = s->n_cu;
+        if (!parent && s->n_blocks > 1 && (int)s->n_blocks <= n_cu && s->block_voices <= 256u && !(e && e[0] == '0')) {
             CREATE_HIP(hipStreamCreateWithFlags(&s->stream_b, hipStreamNonBlocking));
             CREATE_HIP(hipMalloc((void **)&s->partials2[1], (size_t)s->n_blocks * partials_stride(cfg->max_frames) * sizeof(float)));
             CREATE_HIP(hipMalloc((void **)&s->heads2[1], pv * sizeof(int32_t)));
@@ -1199,35 +1664,49 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
         s->kid_done[b].assign(n, nullptr);
     }
     CREATE_HIP(hipMalloc((void **)&s->out_dev, (size_t)2 * cfg->max_frames * sizeof(float)));
-    CREATE_HIP(hipHostMalloc((void **)&s->out_host, (size_t)2 * cfg->max_frames * sizeof(float), hipHostMallocMapped));
+    CREATE_HIP(hipHostMalloc((void **)&s->out_host, (size_t)2 * cfg->max_frames * sizeof(float), kHostPolled));
     CREATE_HIP(hipHostGetDevicePointer((void **)&s->out_host_dev, s->out_host, 0));
     for (int k = 0; k < 2; k++) {
-        CREATE_HIP(hipHostMalloc((void **)&s->ring_host[k], (size_t)cfg->max_frames * sizeof(float), hipHostMallocMapped));
+        CREATE_HIP(hipHostMalloc((void **)&s->ring_host[k], (size_t)cfg->max_frames * sizeof(float), kHostPolled));
         CREATE_HIP(hipHostGetDevicePointer((void **)&s->ring_dev[k], s->ring_host[k], 0));
         CREATE_HIP(hipEventCreateWithFlags(&s->ring_done[k], hipEventDisableTiming));
     }
-    CREATE_HIP(hipHostMalloc((void **)&s->done_host, 16 * sizeof(uint32_t), hipHostMallocMapped));
+    CREATE_HIP(hipHostMalloc((void **)&s->done_host, 16 * sizeof(uint32_t), kHostPolled));
     std::memset(s->done_host, 0, 16 * sizeof(uint32_t));
     CREATE_HIP(hipHostGetDevicePointer((void **)&s->done_dev, s->done_host, 0));
     CREATE_HIP(hipMalloc((void **)&s->done_counter, 4 * sizeof(uint32_t)));
     CREATE_HIP(hipMemsetAsync(s->done_counter, 0, 4 * sizeof(uint32_t), s->stream));
+    CREATE_HIP(hipMalloc((void **)&s->rows_done, 2 * sizeof(uint32_t)));
+    CREATE_HIP(hipMemsetAsync(s->rows_done, 0, 2 * sizeof(uint32_t), s->stream));
     CREATE_HIP(hipStreamSynchronize(s->stream));
     // A shard on another device writes its row straight into the parent's buffer when the devices are peers (one
-    // 4 KiB write over xGMI by its mix kernel: SURVEY 5's preferred shape); otherwise into a row of its own that a
-    // peer copy moves.
+    // 4 KiB write over xGMI by its mixers: SURVEY 5's preferred shape); otherwise into a row of its own that a
+    // peer copy moves.  On a box with ONE device the two multi-device branches are still reachable (tests/test_gpu_device_list.py
+    // runs under both): S2R_FORCE_PEER=1 sends a shard on the parent's own device through the peer set-up (the queries and
+    // hipDeviceEnablePeerAccess, whose refusal of a device as its own peer is the one error tolerated), S2R_FORCE_STAGE=1
+    // gives every shard the staging row and the peer copy.
+    { const char *e = std::getenv("S2R_FORCE_STAGE"); s->force_stage = e && e[0] == '1'; }
+    { const char *e = std::getenv("S2R_FORCE_PEER"); s->force_peer = e && e[0] == '1'; }
     s->kid_stage.assign(n, nullptr);
     for (uint32_t k = 0; k < n; k++) {
         s2r_synth *kid = s->kids[k];
         CREATE_HIP(hipSetDevice(kid->device));
         for (int b = 0; b < 2; b++) CREATE_HIP(hipEventCreateWithFlags(&s->kid_done[b][k], hipEventDisableTiming));
-        if (kid->device == s->device) continue;
-        int can = 0;
-        bool direct = false;
-        if (hipDeviceCanAccessPeer(&can, kid->device, s->device) == hipSuccess && can) {
-            const hipError_t e = hipDeviceEnablePeerAccess(s->device, 0);
-            direct = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+        const bool same = kid->device == s->device;
+        bool direct = same;
+        if (!same || s->force_peer) {
+            int can = 0;
+            const hipError_t q = hipDeviceCanAccessPeer(&can, kid->device, s->device);
             (void)hipGetLastError();
+            if (same) can = 1;                                   // (a device reaches its own memory whatever the query says of it as a peer)
+            direct = false;
+            if ((q == hipSuccess || same) && can) {
+                const hipError_t e = hipDeviceEnablePeerAccess(s->device, 0);
+                direct = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled || same;
+                (void)hipGetLastError();
+            }
         }
+        if (s->force_stage) direct = false;
         if (!direct) CREATE_HIP(hipMalloc((void **)&s->kid_stage[k], (size_t)cfg->max_frames * sizeof(float)));
     }
 #undef CREATE_HIP
@@ -1403,7 +1882,7 @@ int s2r_fill_begin(s2r_synth *s, size_t frames, uint32_t sample_rate_hz) {
     int rc = check_fill(s, frames, sample_rate_hz);
     if (rc != S2R_OK) return rc;
     if (s->ring_count >= 2) return set_err(s, S2R_ERR_INVALID, "two fills are already in flight: s2r_fill_end first");
-    S2R_QUIESCE(s);
+    { const int rc_r = resident_stop(s); if (rc_r != S2R_OK) return rc_r; }      // (the pool-resident kernel stays: enqueue_root decides)
     S2R_HIP(s, hipSetDevice(s->device));
     const uint32_t slot = (s->ring_head + s->ring_count) & 1u;
     if (frames) {
@@ -1452,6 +1931,7 @@ int s2r_fill_oversampled(s2r_synth *s, float *mono_out, size_t frames, uint32_t 
     if (!s) return S2R_ERR_INVALID;
     if (sample_rate_hz > 0xffffffffu / S2R_OVERSAMPLE) return set_err(s, S2R_ERR_INVALID, "sample rate too high to oversample");
     S2R_QUIESCE(s);
+    if (!s->kids.empty() && s->ring_count) return set_err(s, S2R_ERR_INVALID, "a device-list handle takes no synchronous fill while fills are in flight: s2r_fill_end first");
     const size_t os_frames = frames * S2R_OVERSAMPLE;
     int rc = check_fill(s, os_frames, sample_rate_hz * S2R_OVERSAMPLE);
     if (rc != S2R_OK) return rc;
@@ -1519,6 +1999,7 @@ int s2r_render_voices(s2r_synth *s, float *per_voice_out, size_t frames, uint32_
     if (!s->tpending.empty()) return set_err(s, S2R_ERR_INVALID, "s2r_render_voices does not take timed events; use s2r_fill");
     S2R_QUIESCE(s);
     if (!s->kids.empty()) {                       // every shard's rows, put back into pool order
+        if (s->ring_count) return set_err(s, S2R_ERR_INVALID, "a device-list handle takes no synchronous fill while fills are in flight: s2r_fill_end first");
         for (s2r_synth *kid : s->kids) if (!kid->tpending.empty()) return set_err(s, S2R_ERR_INVALID, "s2r_render_voices does not take timed events; use s2r_fill");
         rc = enqueue_multi(s, frames, sample_rate_hz, nullptr, false, per_voice_out);
         if (rc != S2R_OK) return rc;
@@ -1681,11 +2162,11 @@ int s2r_set_low_latency(s2r_synth *s, int enabled) {
     S2R_QUIESCE(s);
     if (enabled && !s->res_host) {
         S2R_HIP(s, hipSetDevice(s->device));
-        S2R_HIP(s, hipHostMalloc((void **)&s->res_host, 64 * sizeof(uint32_t), hipHostMallocMapped));
+        S2R_HIP(s, hipHostMalloc((void **)&s->res_host, 64 * sizeof(uint32_t), kHostPolled));
         std::memset(s->res_host, 0, 64 * sizeof(uint32_t));
         S2R_HIP(s, hipHostGetDevicePointer((void **)&s->res_dev, s->res_host, 0));
         s->res_cmd = s->res_host; s->res_cmd_dev = s->res_dev; s->res_cmd_vram = false;
-        S2R_HIP(s, hipHostMalloc((void **)&s->res_gran, S2R_RES_GRANULE_FRAMES * sizeof(unsigned long long), hipHostMallocMapped));
+        S2R_HIP(s, hipHostMalloc((void **)&s->res_gran, S2R_RES_GRANULE_FRAMES * sizeof(unsigned long long), kHostPolled));
         std::memset(s->res_gran, 0, S2R_RES_GRANULE_FRAMES * sizeof(unsigned long long));
         S2R_HIP(s, hipHostGetDevicePointer((void **)&s->res_gran_dev, s->res_gran, 0));
         // Where the whole of device memory is visible to the CPU (large BAR: hipDeviceAttributeIsLargeBar), the command lives
@@ -1710,6 +2191,48 @@ int s2r_set_low_latency(s2r_synth *s, int enabled) {
 
 int s2r_low_latency_active(const s2r_synth *s) { return (s && s->res_running) ? 1 : 0; }
 
+int s2r_set_resident(s2r_synth *s, int enabled) {
+    if (!s || s->parent) return S2R_ERR_INVALID;
+    S2R_QUIESCE(s);
+    std::vector<s2r_synth *> shards(s->kids.begin(), s->kids.end());
+    if (shards.empty()) shards.push_back(s);
+    // Resident kernels of one process on ONE device each hold a stream, and streams share the runtime's hardware queues (4
+    // unless GPU_MAX_HW_QUEUES says otherwise): two resident kernels in one queue would run one after the other, each waiting
+    // out the other's patience.  Shards of a device list that share a device stay resident only while every one of them (and
+    // the parent's stream) has a queue to itself — a rehearsal of N shards on one device sets GPU_MAX_HW_QUEUES >= N + 1
+    // before the first HIP call; N devices need nothing.
+    int hw_queues = 4;
+    { const char *e = std::getenv("GPU_MAX_HW_QUEUES"); if (e && std::atoi(e) > 0) hw_queues = std::atoi(e); }
+    for (s2r_synth *t : shards) {
+        int same_device = 0, grid_total = 0;
+        for (s2r_synth *u : shards) if (u->device == t->device) { same_device++; grid_total += (int)u->n_blocks; }
+        const bool queues_ok = shards.size() == 1 || (same_device + 1 <= hw_queues && grid_total <= t->n_cu);
+        // (a shard whose grid cannot be resident as a whole — more workgroups than compute units, workgroups of more than 256
+        // threads — or of a single workgroup keeps its launches; a single-workgroup handle has s2r_set_low_latency's kernel)
+        if (enabled && queues_ok && t->n_blocks > 1u && (int)t->n_blocks <= t->n_cu && t->block_voices <= 256u) {
+            const int rc = pool_setup(t);
+            if (rc != S2R_OK) { s->err = t->err; return rc; }
+        }
+        t->resident = enabled != 0;
+    }
+    s->resident = enabled != 0;
+    if (s->kids.empty() && s->n_blocks == 1u) return s2r_set_low_latency(s, enabled);
+    return S2R_OK;
+}
+
+int s2r_resident_active(const s2r_synth *s) {
+    if (!s) return 0;
+    if (s->res_running || s->pool_running) return 1;
+    for (const s2r_synth *kid : s->kids) if (kid->pool_running) return 1;
+    return 0;
+}
+
+int s2r_quiesce(s2r_synth *s) {
+    if (!s) return S2R_ERR_INVALID;
+    S2R_QUIESCE(s);
+    return S2R_OK;
+}
+
 int s2r_set_timing(s2r_synth *s, int enabled) {
     if (!s) return S2R_ERR_INVALID;
     S2R_QUIESCE(s);
@@ -1720,7 +2243,7 @@ int s2r_set_timing(s2r_synth *s, int enabled) {
 }
 
 float s2r_last_render_ms(s2r_synth *s) {
-    if (s) (void)resident_stop(s);
+    if (s) (void)quiesce(s);
     if (s && !s->kids.empty()) {                  // the longest of the shards' render kernels
         float worst = -1.0f;
         for (s2r_synth *kid : s->kids) { const float ms = s2r_last_render_ms(kid); if (ms < 0.0f) return -1.0f; if (ms > worst) worst = ms; }
@@ -1740,7 +2263,7 @@ const char *s2r_last_error(const s2r_synth *s) { return s ? s->err.c_str() : "nu
 extern "C" uint32_t s2r_debug_read_stamps(s2r_synth *s, unsigned long long *out, uint32_t max_waves) {
 #if defined(S2R_STAMPS)
     if (!s) return 0;
-    (void)resident_stop(s);
+    (void)quiesce(s);
     const uint32_t waves = s->padded_voices / 64u;
     if (hipSetDevice(s->device) != hipSuccess) return 0;
     if (!s->stamps_dev) {
@@ -1765,7 +2288,7 @@ extern "C" uint32_t s2r_debug_read_stamps(s2r_synth *s, unsigned long long *out,
 extern "C" uint32_t s2r_debug_timeline(s2r_synth *s, unsigned long long *out, uint32_t max_launches) {
 #if defined(S2R_STAMPS)
     if (!s) return 0;
-    (void)resident_stop(s);
+    (void)quiesce(s);
     if (hipSetDevice(s->device) != hipSuccess) return 0;
     if (!out) {
         if (s->timeline_dev) { (void)hipFree(s->timeline_dev); s->timeline_dev = nullptr; }

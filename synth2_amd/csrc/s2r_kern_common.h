@@ -613,10 +613,10 @@ __device__ __forceinline__ float frame_sisd(const P &p, VoiceRegs &r, uint32_t o
 // The end of a fill's last kernel (S2rDone): every workgroup, once its part of the output has left for host memory,
 // counts itself in; the last one of `n_workgroups` resets the counter and stores the fill's sequence number where the
 // host is polling.  Called by every thread of the workgroup.  The output lives in mapped, coherent host memory
-// (hipHostMalloc's default): stores to it are not held in the L2, so a wave's `s_waitcnt vmcnt(0)` says they are on
-// (hipHostMalloc's default) and is stored at system scope (out_store): a wave's `s_waitcnt vmcnt(0)` then says those
-// stores are performed in host memory, and the flag store that follows the last such wait cannot overtake them — no
-// agent- or system-scope cache write-back (2-6 us with a fill's partial rows freshly dirtied in the L2) is needed.
+// (hipHostMallocCoherent, asked for explicitly: s2r_host.cpp kHostPolled) and is stored at system scope (out_store): a wave's
+// `s_waitcnt vmcnt(0)` then says those stores are performed in host memory, and the flag store that follows the last such
+// wait cannot overtake them — no agent- or system-scope cache write-back (2-6 us with a fill's partial rows freshly
+// dirtied in the L2) is needed.
 // diagnostic builds (-DS2R_STAMPS): a launch's first entry and last exit on the GPU's own 100 MHz clock (tools/gpu_timeline.py)
 __device__ __forceinline__ void tl_mark(unsigned long long *timeline, uint32_t slot, int which) {
 #if defined(S2R_STAMPS)
@@ -685,14 +685,18 @@ __device__ __forceinline__ void ov_raise(uint32_t *fail, uint32_t who) {      //
 template <typename T> __device__ __forceinline__ T ov_load(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <typename T> __device__ __forceinline__ void ov_store(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // sixteen bytes with one write-through store (a dword store of this kind is one fabric write each: six times the time per byte)
+// (the two wait states behind it are the hardware's: a store of more than 64 bits reads its data registers late, and a vector
+// instruction that writes one of them may not follow within two states on gfx940-class parts — a hazard the compiler pads for
+// its own stores and cannot see inside this statement; found as every fourth record of fused_heads carrying the NEXT
+// instruction's result in its second word)
 __device__ __forceinline__ void ov_store4(float *p, f4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 
 // a record of the fill's event copy: plainly, or (two streams: the copy comes from a kernel on the other one) `sc1`
-__device__ __forceinline__ S2rTimedEvent tev_load(const S2rRenderParams &p, bool ovh, int32_t i) {
-    if (!ovh) return p.tev[i];
-    const uint32_t *w = reinterpret_cast<const uint32_t *>(p.tev + i);
+__device__ __forceinline__ S2rTimedEvent tev_load(const S2rTimedEvent *tev, bool ovh, int32_t i) {
+    if (!ovh) return tev[i];
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(tev + i);
     S2rTimedEvent e;
     e.voice = 0u; e._pad = 0u;
     e.frame = ov_load(w + 1); e.flags = ov_load(w + 2); e.pitch = s2r_u2f(ov_load(w + 3));
@@ -765,7 +769,38 @@ struct FillCtl {
     // waits for a store to be acknowledged across the link (MI355X_MICROARCH.md's R2 granule).  nullptr: not used.
     unsigned long long *granules;
     uint32_t granule_tag;
+    // the fill's buffers (by parity where two fills are in flight)
+    float *partials;         // [n_blocks][frames_stride]: the workgroups' partial rows
+    int32_t *heads;          // [padded voices]: the voices' chain heads
+    const S2rTimedEvent *tev;   // the fill's records in HBM
+    // one launch per fill (S2rMixTail, s2r_device.h): this workgroup's slice of the fill's records and the in-kernel mix
+    bool fused;
+    const S2rTimedEvent *tev_src;
+    S2rTimedEvent *tev_copy;
+    uint32_t slice_lo, slice_hi;
+    uint32_t *arrive;
+    uint32_t arrive_target;
+    uint32_t *fail;
+    S2rMixTail mt;
 };
+
+// a launch is a fill: everything from the kernel arguments
+__device__ __forceinline__ FillCtl fill_ctl_from_args(const S2rRenderArgs &a) {
+    const S2rRenderParams &p = a.p;
+    FillCtl c;
+    c.frames = p.frames; c.n_events = a.n_events; c.ev = a.ev; c.done = p.done; c.granules = nullptr; c.granule_tag = 0u;
+    c.partials = p.block_partials; c.heads = p.voice_ev_head; c.tev = p.tev;
+    c.fused = p.arrive != nullptr;
+    c.tev_src = p.tev_src; c.tev_copy = p.tev_copy;
+    c.slice_lo = 0u; c.slice_hi = 0u;
+    if (c.fused && p.tev_src != nullptr) {
+        const uint32_t *sl = p.slices ? p.slices : a.ev;
+        c.slice_lo = sl[blockIdx.x]; c.slice_hi = sl[blockIdx.x + 1u];
+    }
+    c.arrive = p.arrive; c.arrive_target = p.arrive_target; c.fail = p.ov_fail;
+    c.mt = p.mt;
+    return c;
+}
 
 // ---------------------------------------------------------------------------------------
 // The fill's note events when they ride in the kernel arguments (S2rRenderArgs): every wave looks at 64 records per
@@ -895,7 +930,7 @@ __device__ __forceinline__ f4 pk_add4(f4 a, f4 b) {
 // entries past n_sc are read and not used.  bp: the block's row at the super-chunk's first frame, 16-byte aligned.
 __device__ __forceinline__ void combine_groups(const S2rRenderParams &p, const S2rDone &done, const float *sWbuf, uint32_t n_groups, uint32_t super_frames,
                                                uint32_t n_sc, uint32_t sc0, float *bp_sc, uint32_t tid, uint32_t n_threads,
-                                               unsigned long long *granules = nullptr, uint32_t granule_tag = 0u) {
+                                               unsigned long long *granules = nullptr, uint32_t granule_tag = 0u, bool wt = false) {
     for (uint32_t f = 4u * tid; f < n_sc; f += 4u * n_threads) {
         const float *row = sWbuf + f;
         f4 acc;
@@ -911,7 +946,7 @@ __device__ __forceinline__ void combine_groups(const S2rRenderParams &p, const S
             acc = pk_add4(pk_add4(pk_add4(pk_add4(acc, v0), v1), v2), v3);
         }
         const uint32_t n = n_sc - f < 4u ? n_sc - f : 4u;
-        if (p.ov_render_counter != nullptr) {                    // two streams: the row is handed to a mix that runs beside this kernel
+        if (wt || p.ov_render_counter != nullptr) {              // the row is handed to workgroups of another compute unit (a mix beside or behind this kernel)
             if (n == 4u) ov_store4(bp_sc + f, acc);
             else for (uint32_t j = 0; j < n; ++j) ov_store(bp_sc + f + j, acc[j]);
         } else if (n == 4u) *reinterpret_cast<f4 *>(bp_sc + f) = acc;
@@ -930,6 +965,142 @@ __device__ __forceinline__ void combine_groups(const S2rRenderParams &p, const S
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// The mix of the workgroups' partial rows in the fixed order of DESIGN.md 4.3:
+//   runs of 16 consecutive workgroups sequentially -> the run sums of a mix group sequentially
+//   -> the mix groups sequentially -> root (+0.0) + total.
+// One workgroup (256 threads) handles one block of 16 frames: thread (slot, f) adds whole runs (16 independent loads in
+// flight each), the run sums meet in LDS (s_run: [total runs][16 frames]), 16 threads finish.  Runs never straddle a mix
+// group.  `ov`: the rows come from workgroups of other compute units that may still be running (sc1 loads, ov_load).
+// `sys`: the output goes to memory the host or another device reads behind a flag (system-scope stores).
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t kMixRun = 16;
+
+__device__ __forceinline__ void mix_block(const S2rMixParams &m, uint32_t block, float *s_run, bool ov, bool sys) {
+    const uint32_t f_local = threadIdx.x & 15u, slot = threadIdx.x >> 4;
+    const uint32_t f = block * 16u + f_local;
+    const uint32_t runs_per_group = (m.blocks_per_group + kMixRun - 1) / kMixRun;
+    const uint32_t total_runs = runs_per_group * m.n_groups;
+    if (f < m.frames) {
+        for (uint32_t run = slot; run < total_runs; run += 16u) {
+            const uint32_t g = run / runs_per_group, rg = run % runs_per_group;
+            const uint32_t gb0 = g * m.blocks_per_group;
+            uint32_t gb1 = gb0 + m.blocks_per_group; if (gb1 > m.n_blocks) gb1 = m.n_blocks;
+            const uint32_t b0 = gb0 + rg * kMixRun;
+            float v[kMixRun];
+#pragma unroll
+            for (uint32_t j = 0; j < kMixRun; ++j) {
+                const float *src = m.block_partials + (size_t)(b0 + j) * m.frames_stride + f;
+                v[j] = (b0 + j < gb1) ? (ov ? ov_load(src) : *src) : 0.0f;
+            }
+            float acc = v[0];
+#pragma unroll
+            for (uint32_t j = 1; j < kMixRun; ++j) if (b0 + j < gb1) acc += v[j];
+            s_run[run * 16u + f_local] = (b0 < gb1) ? acc : 0.0f;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 16u && f < m.frames) {
+        float total = 0.0f;                                      // accum = splat(0.0), synth.rs:176
+        for (uint32_t g = 0; g < m.n_groups; ++g) {
+            const uint32_t gb0 = g * m.blocks_per_group;
+            uint32_t gb1 = gb0 + m.blocks_per_group; if (gb1 > m.n_blocks) gb1 = m.n_blocks;
+            if (gb0 >= gb1) continue;
+            const uint32_t n_runs = (gb1 - gb0 + kMixRun - 1) / kMixRun;
+            float acc = s_run[(g * runs_per_group) * 16u + f_local];
+            for (uint32_t r = 1; r < n_runs; ++r) acc += s_run[(g * runs_per_group + r) * 16u + f_local];
+            total = (m.root_add || g > 0) ? total + acc : acc;
+        }
+        if (sys) {
+            if (m.stereo) { __hip_atomic_store(m.out + 2 * f, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            __hip_atomic_store(m.out + 2 * f + 1, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+            else __hip_atomic_store(m.out + f, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else if (m.stereo) { m.out[2 * f] = total; m.out[2 * f + 1] = total; }
+        else m.out[f] = total;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// One launch per fill (S2rMixTail, s2r_device.h).
+// fused_heads: this workgroup's slice of the fill's records — mapped host memory, read at system scope: in the
+// pool-resident kernel no kernel boundary stands between the host's writes and these loads — copied into HBM, and the
+// chain heads of its own voices published (heads_body of s2r_aux.hip for one slice).  Write-through stores, a barrier: the
+// lanes that follow their voices' chains read both `sc1` (tev_load / ov_load), whichever wave of the workgroup wrote them.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void fused_heads(const FillCtl &ctl) {
+    for (uint32_t i = ctl.slice_lo + threadIdx.x; i < ctl.slice_hi; i += blockDim.x) {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(ctl.tev_src + i);
+        uint32_t r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = __hip_atomic_load(w + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        float *dst = reinterpret_cast<float *>(ctl.tev_copy + i);
+        ov_store4(dst, (f4){s2r_u2f(r[0]), s2r_u2f(r[1]), s2r_u2f(r[2]), s2r_u2f(r[3])});
+        ov_store4(dst + 4, (f4){s2r_u2f(r[4]), s2r_u2f(r[5]), s2r_u2f(r[6]), 0.0f});
+        if (r[2] & S2R_TEV_FIRST) ov_store(ctl.heads + r[0], (int32_t)i);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+// fused_tail: called by every thread of the workgroup once its partial row and its voices' state are stored.  s_run: LDS the
+// workgroup no longer needs ([total runs][16] floats); s_word: one LDS word.
+__device__ __forceinline__ void fused_tail(const S2rRenderParams &p, const FillCtl &ctl, float *s_run, uint32_t *s_word) {
+    const S2rMixTail &mt = ctl.mt;
+    if (mt.n_mixers == 0u) return;
+    // the row (stored sc1 by combine_groups) has left this compute unit's caches once every wave's stores are acknowledged
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) *s_word = __hip_atomic_fetch_add(ctl.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const uint32_t pos = *s_word - (ctl.arrive_target - mt.n_blocks);    // this workgroup's place among the fill's arrivals
+    __syncthreads();                                             // (s_word is written again below)
+    if (pos + mt.n_mixers < mt.n_blocks) return;                 // (uniform over the workgroup) not one of the last
+    const uint32_t mixer = pos - (mt.n_blocks - mt.n_mixers);
+    if (threadIdx.x == 0 && !ov_wait(ctl.arrive, ctl.arrive_target)) ov_raise(ctl.fail, 2u);
+    __syncthreads();
+    S2rMixParams m{};
+    m.block_partials = ctl.partials; m.n_blocks = mt.n_blocks; m.blocks_per_group = mt.blocks_per_group; m.n_groups = mt.n_groups;
+    m.frames = ctl.frames; m.frames_stride = p.frames_stride; m.root_add = mt.root_add; m.stereo = mt.stereo; m.out = mt.out;
+    const uint32_t n_fb = (ctl.frames + 15u) / 16u;
+    for (uint32_t b = mixer; b < n_fb; b += mt.n_mixers) { mix_block(m, b, s_run, true, true); __syncthreads(); }
+    // this mixer's part of the output is on its way; the last mixer to get here ends the fill
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (mt.n_mixers > 1u) {
+        if (threadIdx.x == 0) {
+            const uint32_t arrived = __hip_atomic_fetch_add(mt.done.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool last = arrived + 1u == mt.n_mixers;
+            if (last) __hip_atomic_store(mt.done.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *s_word = last ? 1u : 0u;
+        }
+        __syncthreads();
+        if (*s_word == 0u) return;
+    }
+    if (mt.rows_done == nullptr) {
+        if (threadIdx.x == 0 && mt.done.flag != nullptr) __hip_atomic_store(mt.done.flag, mt.done.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    // exchange: this shard's row is in the root's memory (system-scope stores, acknowledged); count in — and whoever counts in
+    // LAST, whichever shard that is, adds the rows in shard order.  Nobody waits for anybody: shards whose kernels share a
+    // hardware queue, or run one after the other, still finish.
+    if (threadIdx.x == 0) {
+        const uint32_t before = __hip_atomic_fetch_add(mt.rows_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        *s_word = (before + 1u == mt.rows_target) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (*s_word == 0u) return;
+    for (uint32_t f = threadIdx.x; f < ctl.frames; f += blockDim.x) {
+        float total = 0.0f;                                      // accum = splat(0.0), synth.rs:176
+        for (uint32_t r = 0; r < mt.n_rows; ++r) total += __hip_atomic_load(mt.rows + (size_t)r * mt.row_stride + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (mt.final_stereo) { __hip_atomic_store(mt.final_out + 2u * f, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                               __hip_atomic_store(mt.final_out + 2u * f + 1u, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+        else __hip_atomic_store(mt.final_out + f, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && mt.final_done.flag != nullptr) __hip_atomic_store(mt.final_done.flag, mt.final_done.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------------------------

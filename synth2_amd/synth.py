@@ -171,6 +171,9 @@ def load_library():
         "s2r_set_timing": (C.c_int, [H, C.c_int]),
         "s2r_set_low_latency": (C.c_int, [H, C.c_int]),
         "s2r_low_latency_active": (C.c_int, [H]),
+        "s2r_set_resident": (C.c_int, [H, C.c_int]),
+        "s2r_resident_active": (C.c_int, [H]),
+        "s2r_quiesce": (C.c_int, [H]),
         "s2r_set_flat_shortcut": (C.c_int, [H, C.c_int]),
         "s2r_set_coeff_stream": (C.c_int, [H, C.c_int]),
         "s2r_last_render_ms": (C.c_float, [H]),
@@ -436,6 +439,19 @@ class Synth:
     @property
     def low_latency_active(self):
         return bool(self.L.s2r_low_latency_active(self.h))
+
+    def set_resident(self, enabled=True):
+        """keep the shard's whole render grid on the device between fills (s2r.h: s2r_set_resident): a fill is a posted
+        command, not a launch; with two fills in flight the workgroups run ahead of each other"""
+        self._check(self.L.s2r_set_resident(self.h, 1 if enabled else 0))
+
+    @property
+    def resident_active(self):
+        return bool(self.L.s2r_resident_active(self.h))
+
+    def quiesce(self):
+        """stop any resident kernel of the handle and wait for it (before a device-wide synchronize)"""
+        self._check(self.L.s2r_quiesce(self.h))
 
     def set_timing(self, enabled=True):
         self._check(self.L.s2r_set_timing(self.h, 1 if enabled else 0))

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# Shards of a device list that all live on this box's ONE device each keep a resident kernel on a stream of their own: give every
+# stream a hardware queue (the runtime's default is 4; read at its first call).  N devices need nothing (s2r.h: s2r_set_resident).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
