@@ -42,6 +42,10 @@ import time
 
 import numpy as np
 
+# (a device list rehearsed on ONE device keeps a resident kernel per shard, each on a stream of its own: a hardware queue for
+# every stream; read by the HIP runtime at its first call.  N devices need nothing: s2r.h, s2r_set_resident)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -440,6 +444,11 @@ def main():
     synth = sh.renderer
     block_voices = synth.block_voices
     sh.load_patch("synth mySynth {\n\n}\n")       # example.synth2: empty body == default patch
+    # N = 1: the pool-resident render kernel (s2r_set_resident: a fill is a posted command, the grid stays on the device and its
+    # workgroups run ahead of each other across the two fills in flight).  S2R_BENCH_RESIDENT=0: a launch per fill (A/B).
+    resident = world == 1 and os.environ.get("S2R_BENCH_RESIDENT", "1") != "0"
+    if resident:
+        synth.set_resident(True)
     if os.environ.get("S2R_COEFF_STREAM_MODE"):       # measurement aid (see s2r_set_coeff_stream); results are bit-identical
         synth.set_coeff_stream(int(os.environ["S2R_COEFF_STREAM_MODE"]))
 
@@ -498,6 +507,7 @@ def main():
             synth.sample_end(out_host)
             in_flight[0] -= 1
         sh.flush()
+        synth.quiesce()                           # (a resident kernel would sit out its patience inside a device-wide synchronize)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -659,7 +669,7 @@ def main():
                                     "before the warm-up" % (vpg, PERIOD, PERIOD, n_events_per_step)) if args.workload == "c3" else
                                    ("churn: %d voices per GPU, default patch, 48 kHz, 1024-frame buffers, all on at frame 0, then %d note-off + %d "
                                     "note-on per buffer per 64k voices" % (vpg, args.churn, args.churn)),
-                       "timed_call": "s2r_note_events + s2r_fill_begin / s2r_fill_end: the host-buffer API with two buffers in flight (s2_bin's own arrangement); voice state resident in HBM, events H2D and every mix's D2H into the caller's buffer inside the timed region" if world == 1 else
+                       "timed_call": "s2r_note_events + s2r_fill_begin / s2r_fill_end: the host-buffer API with two buffers in flight (s2_bin's own arrangement); voice state resident in HBM, events H2D and every mix's D2H into the caller's buffer inside the timed region" + ("; render grid resident on the device (s2r_set_resident): a fill is a posted command, no launch" if resident else "; a launch per fill") if world == 1 else
                                      "s2r_note_events + s2r_fill_device per rank, all-gather, rank-ordered sum, async D2H of the mix on rank 0",
                        "voices_total": total, "frames": FRAMES, "sample_rate": SR,
                        "parallelism": ("one process, one handle over the device list %s: policy run once, every shard on its own device's stream, rows added in shard order on the first device" % dev_list) if dev_list else

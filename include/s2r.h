@@ -333,6 +333,14 @@ uint32_t s2r_voice_pool_note_on(s2r_voice_pool *p, uint8_t note, float velocity)
 int64_t s2r_voice_pool_note_off(s2r_voice_pool *p, uint8_t note);                  /* released index or -1 */
 void s2r_voice_pool_advance(s2r_voice_pool *p, uint64_t frames);
 uint32_t s2r_voice_pool_next_voice(const s2r_voice_pool *p);                       /* synth.rs:101-120 */
+/* The batch form s2r_note_events runs: the whole array at once — what a loop of s2r_voice_pool_advance (to each event's
+ * frame) / _note_on / _note_off computes, with the same results, voice_out[k] = the voice event k takes or releases (-1: a
+ * note_off that found none, a program change).  `frames_moved`: how far the clock already is inside the fill the events belong
+ * to; returns the last event's frame.  s2r_voice_pool_set_threads: batches of at least `batch_threshold` events are resolved
+ * by the calling thread (the queue: synth.rs:101-120 depends on earlier note_ons alone) plus `worker_threads` threads that
+ * share the notes among them (synth.rs:82-90 depends on one note's events alone); 0 = the calling thread alone. */
+void s2r_voice_pool_set_threads(s2r_voice_pool *p, uint32_t worker_threads, size_t batch_threshold);
+uint32_t s2r_voice_pool_resolve(s2r_voice_pool *p, const s2r_note_event *events, size_t n, uint32_t frames_moved, int64_t *voice_out);
 int s2r_voice_pool_query(const s2r_voice_pool *p, uint32_t voice_index, s2r_voice_state *out);
 
 #ifdef __cplusplus

@@ -673,11 +673,13 @@ int fused_events(s2r_synth *s, hipStream_t stream, EventSlot **slot_out, uint32_
     return S2R_OK;
 }
 
+// How many of the fill's last workgroups add the rows up: one per 16-frame block of the fill where the grid is big enough to
+// spare them (what s2r_mix_kernel's grid was: the mix is then ~3 us behind the last row), never more than half the grid.
 uint32_t pick_mixers(const s2r_synth *s, size_t frames) {
-    uint32_t m = 16u;
-    if (m > s->n_blocks) m = s->n_blocks;
-    const uint32_t fb = (uint32_t)((frames + 15u) / 16u);
-    if (m > fb) m = fb;
+    uint32_t m = (uint32_t)((frames + 15u) / 16u);
+    const uint32_t half = s->n_blocks > 1u ? s->n_blocks / 2u : 1u;
+    if (m > half) m = half;
+    if (m > 64u) m = 64u;
     return m ? m : 1u;
 }
 
@@ -773,7 +775,7 @@ bool pool_exited(const s2r_synth *s) { return __atomic_load_n(&s->pool_host[0], 
 // workgroup of at most 256 threads per compute unit), nothing that brackets or watches single launches
 bool pool_eligible(const s2r_synth *s, size_t frames) {
     return s->resident && s->kids.empty() && s->pool_cmd != nullptr && fused_shape_ok(s) && (int)s->n_blocks <= s->n_cu && s->block_voices <= 256u &&
-           !s->timing && s->timeline_dev == nullptr && s->stamps_dev == nullptr && frames <= 0xffffu && frames <= s->cfg.max_frames;
+           !s->timing && s->timeline_dev == nullptr && frames <= 0xffffu && frames <= s->cfg.max_frames;
 }
 
 // what the kernel needs besides the handle's ordinary buffers: the command ring, the slices, the decision word, and the second
@@ -855,6 +857,7 @@ int pool_launch(s2r_synth *s, uint32_t sample_rate, uint32_t first_seq) {
     { int rc = ensure_tables(s, p, sample_rate, s->stream); if (rc != S2R_OK) return rc; }
     if (tables_wanted(s)) p.tab = s->tab;
     p.voice_ev_head = s->voice_ev_head;
+    p.stamps = s->stamps_dev;                                    // (diagnostic builds: tools/stamps_pool.py)
     p.tev = s->tev_copy;                                         // (MODE 2: a fill's events come as chains)
     a.n_events = 0;
     S2rPool pl{};
@@ -1452,6 +1455,16 @@ const char *s2r_status_string(int status) {
     }
 }
 
+// Worker threads of the allocation policy's batch form (S2rVoicePool::resolve_batch): S2R_POLICY_THREADS, else three for the
+// pools of multi-GPU runs (every rank resolves the WHOLE pool's events: 16 384 per buffer at 8 x 65 536 voices), none below.
+// Only batches of at least 4096 events use them.
+static void configure_policy_threads(S2rVoicePool *pool, uint32_t total_voices) {
+    const char *e = std::getenv("S2R_POLICY_THREADS");
+    uint32_t n = total_voices >= 262144u ? 3u : 0u;
+    if (e && e[0] >= '0' && e[0] <= '9') n = (uint32_t)std::atoi(e);
+    pool->set_workers(n, 4096);
+}
+
 // one shard on one device (s2r_create without a device list, and each shard of one with).  `pool` != null: a shard of
 // the device-list handle `parent`, which owns the pool and runs the allocation policy.
 static int create_single(const s2r_config *cfg, std::shared_ptr<S2rVoicePool> pool, s2r_synth *parent, s2r_synth **out) {
@@ -1496,7 +1509,7 @@ static int create_single(const s2r_config *cfg, std::shared_ptr<S2rVoicePool> po
     s->bank.resize(1);
     s2r_default_patch(&s->bank[0]);
     if (pool) s->pool = pool;
-    else { s->pool.reset(new S2rVoicePool(cfg->total_voices)); s->seed_override.assign(cfg->total_voices, 0u); }
+    else { s->pool.reset(new S2rVoicePool(cfg->total_voices)); s->seed_override.assign(cfg->total_voices, 0u); configure_policy_threads(s->pool.get(), cfg->total_voices); }
     s->pending_slot.assign(shard_voices, -1);
     build_pitch_table(s->pitch_table);
 
@@ -1635,6 +1648,7 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
     s->bank.resize(1);
     s2r_default_patch(&s->bank[0]);
     s->pool.reset(new S2rVoicePool(cfg->total_voices));
+    configure_policy_threads(s->pool.get(), cfg->total_voices);
     s->seed_override.assign(cfg->total_voices, 0u);
     build_pitch_table(s->pitch_table);
     for (uint32_t k = 0; k < n; k++) {
@@ -1826,6 +1840,15 @@ int s2r_note_events(s2r_synth *s, const s2r_note_event *events, size_t n) {
             t = frame;
         }
     }
+    // The allocation policy for the whole batch at once (S2rVoicePool::resolve_batch: what the loop of pool clock moves, note_on
+    // and note_off over the events computes — on several threads for a multi-GPU-sized batch): the voice every event takes or
+    // releases.  An event inside the next fill first moves the pool's clock to its frame (the policy sees the offsets every
+    // voice has AT that frame, like the reference between two 16-frame calls); frame-0 events take effect before the fill.
+    static thread_local std::vector<int64_t> chosen;
+    if (chosen.size() < n) chosen.resize(n);
+    static_assert(sizeof(S2rPolicyEvent) == 4 && S2R_NOTE_ON == S2R_POLICY_NOTE_ON && S2R_NOTE_OFF == S2R_POLICY_NOTE_OFF, "s2r_note_event's first four bytes");
+    if (n) s->fill_time = s->pool->resolve_batch(reinterpret_cast<const S2rPolicyEvent *>(events), sizeof(s2r_note_event), n, s->fill_time, chosen.data(),
+                                                 &events[0].velocity, sizeof(s2r_note_event));
     for (size_t k = 0; k < n; k++) {
         const s2r_note_event &e = events[k];
         if (e.kind == S2R_PROGRAM_CHANGE) {      // host-side state: which patch the following note_ons get
@@ -1833,30 +1856,16 @@ int s2r_note_events(s2r_synth *s, const s2r_note_event *events, size_t n) {
             continue;
         }
         const uint32_t frame = e.frame;
+        const int64_t vi = chosen[k];
+        if (vi < 0) { s->double_release++; continue; }           // synth.rs:77 logs "double release" and carries on
         if (frame == 0) {                     // takes effect before the next fill: folded per voice
-            if (e.kind == S2R_NOTE_ON) {
-                const uint32_t i = s->pool->note_on(e.note, e.velocity);
-                push_event(s, i, S2R_EV_RESTART, s->pitch_table[e.note], s->seed_override[i], s->program);
-            } else {
-                const int64_t i = s->pool->note_off(e.note);
-                if (i >= 0) push_event(s, (uint32_t)i, S2R_EV_RELEASE, 0.0f, 0u);
-                else s->double_release++;         // synth.rs:77 logs "double release" and carries on
-            }
+            if (e.kind == S2R_NOTE_ON) push_event(s, (uint32_t)vi, S2R_EV_RESTART, s->pitch_table[e.note], s->seed_override[(size_t)vi], s->program);
+            else push_event(s, (uint32_t)vi, S2R_EV_RELEASE, 0.0f, 0u);
             continue;
         }
-        // inside the next fill: move the pool's clock to the event (the allocation policy sees the
-        // offsets every voice has AT that frame, like the reference between two 16-frame calls)
-        s->pool->advance(frame - s->fill_time);
-        s->fill_time = frame;
-        int64_t vi; uint32_t fl; float pitch = 0.0f; uint32_t seed = 0;
-        if (e.kind == S2R_NOTE_ON) {
-            vi = s->pool->note_on(e.note, e.velocity);
-            fl = S2R_EV_RESTART; pitch = s->pitch_table[e.note]; seed = s->seed_override[(size_t)vi];
-        } else {
-            vi = s->pool->note_off(e.note);
-            fl = S2R_EV_RELEASE;
-            if (vi < 0) { s->double_release++; continue; }
-        }
+        uint32_t fl; float pitch = 0.0f; uint32_t seed = 0;
+        if (e.kind == S2R_NOTE_ON) { fl = S2R_EV_RESTART; pitch = s->pitch_table[e.note]; seed = s->seed_override[(size_t)vi]; }
+        else fl = S2R_EV_RELEASE;
         uint32_t local = 0;
         s2r_synth *sh = shard_of(s, (uint32_t)vi, &local);
         if (!sh) continue;
@@ -2322,6 +2331,12 @@ uint32_t s2r_voice_pool_note_on(s2r_voice_pool *p, uint8_t note, float velocity)
 int64_t s2r_voice_pool_note_off(s2r_voice_pool *p, uint8_t note) { return p->pool.note_off(note); }
 void s2r_voice_pool_advance(s2r_voice_pool *p, uint64_t frames) { p->pool.advance(frames); }
 uint32_t s2r_voice_pool_next_voice(const s2r_voice_pool *p) { return p->pool.next_voice(); }
+void s2r_voice_pool_set_threads(s2r_voice_pool *p, uint32_t worker_threads, size_t batch_threshold) { if (p) p->pool.set_workers(worker_threads, batch_threshold); }
+uint32_t s2r_voice_pool_resolve(s2r_voice_pool *p, const s2r_note_event *events, size_t n, uint32_t frames_moved, int64_t *voice_out) {
+    if (!p || (!events && n) || !voice_out) return frames_moved;
+    return p->pool.resolve_batch(reinterpret_cast<const S2rPolicyEvent *>(events), sizeof(s2r_note_event), n, frames_moved, voice_out,
+                                 n ? &events[0].velocity : nullptr, sizeof(s2r_note_event));
+}
 int s2r_voice_pool_query(const s2r_voice_pool *p, uint32_t voice_index, s2r_voice_state *out) {
     if (!p || !out || voice_index >= p->pool.size()) return S2R_ERR_INVALID;
     const S2rHostVoice &v = p->pool.voice(voice_index);

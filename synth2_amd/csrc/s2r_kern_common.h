@@ -1030,15 +1030,32 @@ __device__ __forceinline__ void mix_block(const S2rMixParams &m, uint32_t block,
 // lanes that follow their voices' chains read both `sc1` (tev_load / ov_load), whichever wave of the workgroup wrote them.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void fused_heads(const FillCtl &ctl) {
-    for (uint32_t i = ctl.slice_lo + threadIdx.x; i < ctl.slice_hi; i += blockDim.x) {
-        const uint32_t *w = reinterpret_cast<const uint32_t *>(ctl.tev_src + i);
-        uint32_t r[8];
+    // A lane moves HALF a record — 16 bytes, so that a wave reads one contiguous kilobyte of host memory (the link serves
+    // eight 128-byte reads, not five hundred 4-byte ones: found as 27 us on the fill's busiest workgroups) — and the lane with
+    // a record's first half (voice, frame, flags, pitch) publishes the chain head.
+    // Four halves per thread with all four reads in flight: the busiest workgroups (a cohort of note-ons and its releases: ~450
+    // records) pay ONE trip over the link, not one per 128 records.
+    const uint32_t n_halves = (ctl.slice_hi - ctl.slice_lo) * 2u;
+    for (uint32_t h0 = 0; h0 < n_halves; h0 += 4u * blockDim.x) {
+        f4 v[4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) r[k] = __hip_atomic_load(w + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        float *dst = reinterpret_cast<float *>(ctl.tev_copy + i);
-        ov_store4(dst, (f4){s2r_u2f(r[0]), s2r_u2f(r[1]), s2r_u2f(r[2]), s2r_u2f(r[3])});
-        ov_store4(dst + 4, (f4){s2r_u2f(r[4]), s2r_u2f(r[5]), s2r_u2f(r[6]), 0.0f});
-        if (r[2] & S2R_TEV_FIRST) ov_store(ctl.heads + r[0], (int32_t)i);
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const uint32_t h = h0 + k * blockDim.x + threadIdx.x;
+            const uint32_t hc = h < n_halves ? h : 0u;
+            const float *src = reinterpret_cast<const float *>(ctl.tev_src + ctl.slice_lo + (hc >> 1)) + 4u * (hc & 1u);
+            asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[k]) : "v"(src) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : : "memory");
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const uint32_t h = h0 + k * blockDim.x + threadIdx.x;
+            if (h < n_halves) {
+                const uint32_t i = ctl.slice_lo + (h >> 1);
+                float *dst = reinterpret_cast<float *>(ctl.tev_copy + i) + 4u * (h & 1u);
+                ov_store4(dst, v[k]);
+                if ((h & 1u) == 0u && (s2r_f2u(v[k].z) & S2R_TEV_FIRST)) ov_store(ctl.heads + s2r_f2u(v[k].x), (int32_t)i);
+            }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1046,9 +1063,14 @@ __device__ __forceinline__ void fused_heads(const FillCtl &ctl) {
 
 // fused_tail: called by every thread of the workgroup once its partial row and its voices' state are stored.  s_run: LDS the
 // workgroup no longer needs ([total runs][16] floats); s_word: one LDS word.
-__device__ __forceinline__ void fused_tail(const S2rRenderParams &p, const FillCtl &ctl, float *s_run, uint32_t *s_word) {
+__device__ __forceinline__ void fused_tail(const S2rRenderParams &p, const FillCtl &ctl, float *s_run, uint32_t *s_word, unsigned long long *st = nullptr) {
     const S2rMixTail &mt = ctl.mt;
     if (mt.n_mixers == 0u) return;
+#if defined(S2R_STAMPS)
+#define S2R_TAIL_STAMP(k) do { if (st && (threadIdx.x & 63u) == 0u) st[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define S2R_TAIL_STAMP(k) do { (void)st; } while (0)
+#endif
     // the row (stored sc1 by combine_groups) has left this compute unit's caches once every wave's stores are acknowledged
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1056,10 +1078,15 @@ __device__ __forceinline__ void fused_tail(const S2rRenderParams &p, const FillC
     __syncthreads();
     const uint32_t pos = *s_word - (ctl.arrive_target - mt.n_blocks);    // this workgroup's place among the fill's arrivals
     __syncthreads();                                             // (s_word is written again below)
+    S2R_TAIL_STAMP(4);
+#if defined(S2R_STAMPS)
+    if (st && (threadIdx.x & 63u) == 0u) st[9] = pos;
+#endif
     if (pos + mt.n_mixers < mt.n_blocks) return;                 // (uniform over the workgroup) not one of the last
     const uint32_t mixer = pos - (mt.n_blocks - mt.n_mixers);
     if (threadIdx.x == 0 && !ov_wait(ctl.arrive, ctl.arrive_target)) ov_raise(ctl.fail, 2u);
     __syncthreads();
+    S2R_TAIL_STAMP(5);
     S2rMixParams m{};
     m.block_partials = ctl.partials; m.n_blocks = mt.n_blocks; m.blocks_per_group = mt.blocks_per_group; m.n_groups = mt.n_groups;
     m.frames = ctl.frames; m.frames_stride = p.frames_stride; m.root_add = mt.root_add; m.stereo = mt.stereo; m.out = mt.out;
@@ -1068,6 +1095,7 @@ __device__ __forceinline__ void fused_tail(const S2rRenderParams &p, const FillC
     // this mixer's part of the output is on its way; the last mixer to get here ends the fill
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    S2R_TAIL_STAMP(6);
     if (mt.n_mixers > 1u) {
         if (threadIdx.x == 0) {
             const uint32_t arrived = __hip_atomic_fetch_add(mt.done.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

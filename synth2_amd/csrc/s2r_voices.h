@@ -11,13 +11,28 @@
 //   note_off (synth.rs:72-96): the LAST index whose note matches and which is active
 //     (started and not yet released).
 //
+// State is struct-of-arrays (a note per voice is one byte: the whole pool's notes stay in the cache), "released" is not
+// stored at all — a started voice is released exactly when it is not in its note's set of active voices — and a BATCH of
+// events (s2r_note_events' whole array) can be resolved by several threads (resolve_batch): every rank of an N-GPU run
+// simulates the WHOLE pool's events, 16 384 per buffer at 8 x 65 536 voices under bench.py's C3 schedule, and the
+// reference's policy is sequential in them — but only through ONE queue: which voice a note_on takes depends on the
+// earlier note_ons alone (the oldest start; whether a voice is released does not matter, synth.rs:101-120), and which
+// voice a note_off(n) releases depends on the events of note n alone plus the note_ons that took a voice away from n.
+// So the caller's thread runs the queue (phase A: the chosen voice and the note it held, per note_on) and P workers, each
+// owning the notes n with n % P == its number, replay the batch behind it and keep their notes' sets (phase B).
+//
 // Pure C++ (no HIP) so it is unit-testable on a CPU-only machine.
 #pragma once
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
+#include <cstring>
 #include <deque>
 #include <functional>
-#include <queue>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -37,6 +52,7 @@ struct FastDiv {
     inline uint32_t mod(uint32_t x) const { return x - div(x) * d; }
 };
 
+// one voice as the entry points that ask about single voices see it (s2r_export_state, s2r_voice_pool_query)
 struct S2rHostVoice {
     uint8_t note = 0;
     bool started = false;
@@ -47,8 +63,7 @@ struct S2rHostVoice {
 };
 
 // A set of voice indices with "greatest member" in three word operations: a bitmap and two
-// levels of summary bits (one bit per 64-bit word below).  Every rank of an N-GPU run simulates the
-// WHOLE pool's events, so note_off's "last active voice holding this note" is on its critical path.
+// levels of summary bits (one bit per 64-bit word below).
 class S2rIndexSet {
   public:
     void init(uint32_t n) {
@@ -57,13 +72,22 @@ class S2rIndexSet {
         l2_.assign((l1_.size() + 63) / 64, 0);
     }
     bool ready() const { return !l0_.empty(); }
+    bool test(uint32_t i) const { return ready() && ((l0_[i >> 6] >> (i & 63)) & 1ull) != 0; }
     void set(uint32_t i) {
-        l0_[i >> 6] |= 1ull << (i & 63);
+        uint64_t &w = l0_[i >> 6];
+        const bool was_empty = w == 0;
+        w |= 1ull << (i & 63);
+        if (!was_empty) return;                   // (the summaries already say so)
         l1_[i >> 12] |= 1ull << ((i >> 6) & 63);
         l2_[i >> 18] |= 1ull << ((i >> 12) & 63);
     }
+    // removes i if it is a member (a voice taken over by a note_on may or may not still be held)
     void clear(uint32_t i) {
-        if ((l0_[i >> 6] &= ~(1ull << (i & 63))) != 0) return;
+        if (!ready()) return;
+        uint64_t &w = l0_[i >> 6];
+        const uint64_t bit = 1ull << (i & 63);
+        if (!(w & bit)) return;
+        if ((w &= ~bit) != 0) return;
         if ((l1_[i >> 12] &= ~(1ull << ((i >> 6) & 63))) != 0) return;
         l2_[i >> 18] &= ~(1ull << ((i >> 12) & 63));
     }
@@ -81,36 +105,37 @@ class S2rIndexSet {
     std::vector<uint64_t> l0_, l1_, l2_;
 };
 
+// one event of a batch as resolve_batch sees it (s2r_note_event's first four bytes)
+struct S2rPolicyEvent { uint8_t kind, note; uint16_t frame; };
+#define S2R_POLICY_NOTE_OFF 0
+#define S2R_POLICY_NOTE_ON 1
+
 class S2rVoicePool {
   public:
-    explicit S2rVoicePool(uint32_t total) : voices_(total) { rebuild(); }
-    uint32_t size() const { return (uint32_t)voices_.size(); }
+    explicit S2rVoicePool(uint32_t total) : n_(total), note_(total, 0), started_(total, 0), velocity_(total, 0.0f), start_(total, 0), release_(total, 0) { rebuild(); }
+    ~S2rVoicePool() { stop_workers(); }
+    S2rVoicePool(const S2rVoicePool &) = delete;
+    S2rVoicePool &operator=(const S2rVoicePool &) = delete;
+    uint32_t size() const { return n_; }
     uint64_t clock() const { return now_; }
-    const S2rHostVoice &voice(uint32_t i) const { return voices_[i]; }
+    S2rHostVoice voice(uint32_t i) const {
+        S2rHostVoice v;
+        v.note = note_[i]; v.started = started_[i] != 0; v.released = v.started && !active_[v.note].test(i);
+        v.velocity = velocity_[i]; v.start_clock = start_[i]; v.release_clock = v.released ? release_[i] : 0;
+        return v;
+    }
 
     // synth.rs:101-120
     uint32_t next_voice() const {
         if (idle_head_ < idle_.size()) return idle_[idle_head_];
-        return started_front().second;
+        return front();
     }
 
     // synth.rs:61-70; returns the chosen index
     uint32_t note_on(uint8_t note, float velocity) {
-        uint32_t i;
-        if (idle_head_ < idle_.size()) {
-            i = idle_[idle_head_++];
-        } else {
-            // the chosen voice is always the queue's minimum, so it never holds stale entries
-            i = started_front().second;
-            started_pop();
-            const S2rHostVoice &old = voices_[i];
-            if (!old.released) active_[old.note].clear(i);     // stolen while still held
-        }
-        S2rHostVoice &v = voices_[i];
-        v.note = note; v.velocity = velocity;
-        v.started = true; v.released = false;
-        v.start_clock = now_; v.release_clock = 0;
-        started_push(now_, i);
+        uint8_t old_note; bool was_started;
+        const uint32_t i = take_voice(note, velocity, &old_note, &was_started);
+        if (was_started) active_[old_note].clear(i);           // stolen, possibly while still held
         mark_active(note, i);
         return i;
     }
@@ -122,116 +147,283 @@ class S2rVoicePool {
         const int64_t i = a.last();
         if (i < 0) return -1;
         a.clear((uint32_t)i);
-        S2rHostVoice &v = voices_[(size_t)i];
-        v.released = true;
-        v.release_clock = now_;
+        release_[(size_t)i] = now_;
         return i;
     }
 
     // every started voice's offset grows by `frames` (synth.rs:197)
     void advance(uint64_t frames) { now_ += frames; }
 
+    // A whole batch of events at once — what a loop of advance / note_on / note_off over `ev` computes, with the same
+    // results: voice_out[k] = the voice event k takes (note_on) or releases (note_off; -1: none).  `t0`: the frames the
+    // clock has already moved inside the fill the events belong to (an event at frame f first moves it by f - t); returns
+    // the last event's frame (>= t0).  Batches of at least `mt_threshold` events are resolved by the worker threads.
+    uint32_t resolve_batch(const S2rPolicyEvent *ev, size_t stride_bytes, size_t n, uint32_t t0, int64_t *voice_out, const float *velocity = nullptr,
+                           size_t velocity_stride = 0) {
+        if (n >= mt_threshold_ && workers_wanted_ > 0) return resolve_mt(ev, stride_bytes, n, t0, voice_out, velocity, velocity_stride);
+        uint32_t t = t0;
+        for (size_t k = 0; k < n; k++) {
+            const S2rPolicyEvent &e = *reinterpret_cast<const S2rPolicyEvent *>(reinterpret_cast<const char *>(ev) + k * stride_bytes);
+            if (e.frame > t) { now_ += e.frame - t; t = e.frame; }
+            if (e.kind == S2R_POLICY_NOTE_ON) {
+                const float vel = velocity ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(velocity) + k * velocity_stride) : 1.0f;
+                voice_out[k] = note_on(e.note, vel);
+            } else if (e.kind == S2R_POLICY_NOTE_OFF) voice_out[k] = note_off(e.note);
+            else voice_out[k] = -1;
+        }
+        return t;
+    }
+    // worker threads for resolve_batch (0: always the calling thread alone) and the batch size from which they are used
+    void set_workers(uint32_t n_workers, size_t threshold = 4096) {
+        if (n_workers != workers_wanted_) stop_workers();
+        workers_wanted_ = n_workers > 16u ? 16u : n_workers; mt_threshold_ = threshold;
+    }
+    uint32_t workers() const { return workers_wanted_; }
+
     // current_frame_offset of a started voice (saturating like synth.rs:197)
     uint32_t offset_of(uint32_t i) const {
-        const uint64_t d = now_ - voices_[i].start_clock;
+        const uint64_t d = now_ - start_[i];
         return d > 0xffffffffull ? 0xffffffffu : (uint32_t)d;
     }
     uint32_t release_offset_of(uint32_t i) const {
-        const uint64_t d = voices_[i].release_clock - voices_[i].start_clock;
+        const uint64_t d = release_[i] - start_[i];
         return d > 0xffffffffull ? 0xffffffffu : (uint32_t)d;
     }
     // greatest current_frame_offset among started voices (0 if none)
     uint64_t oldest_offset() const {
         if (buckets_.empty()) return 0;
-        return now_ - started_front().first;
+        return now_ - buckets_.front().clock;
     }
 
     // restore one voice (import_state); call rebuild() afterwards
     void set_voice(uint32_t i, uint8_t note, bool started, bool released, uint32_t offset,
                    uint32_t release_offset, float velocity) {
-        S2rHostVoice &v = voices_[i];
-        v.note = note; v.started = started; v.released = started && released; v.velocity = velocity;
+        note_[i] = note; started_[i] = started ? 1 : 0; velocity_[i] = velocity;
         if (started && now_ < offset) pending_min_clock_ = std::max<uint64_t>(pending_min_clock_, offset);
-        pending_.push_back({i, offset, release_offset});
+        pending_.push_back({i, offset, release_offset, started && released});
     }
     void rebuild() {
+        // (a voice set_voice did not touch keeps its state: released or not is read off the sets before they are rebuilt)
+        std::vector<uint8_t> rel(n_, 0);
+        for (uint32_t i = 0; i < n_; i++) rel[i] = (started_[i] && !active_[note_[i]].test(i)) ? 1 : 0;
+        for (const auto &p : pending_) rel[p.i] = p.released ? 1 : 0;
         if (now_ < pending_min_clock_) {
             // shift the whole time base forward so no start_clock underflows; offsets are unchanged
             const uint64_t shift = pending_min_clock_ - now_;
-            for (auto &v : voices_) { v.start_clock += shift; v.release_clock += shift; }
+            for (uint32_t i = 0; i < n_; i++) { start_[i] += shift; release_[i] += shift; }
             now_ += shift;
         }
         for (const auto &p : pending_) {
-            S2rHostVoice &v = voices_[p.i];
-            if (v.started) {
-                v.start_clock = now_ - p.offset;
-                v.release_clock = v.released ? v.start_clock + p.release_offset : 0;
+            if (started_[p.i]) {
+                start_[p.i] = now_ - p.offset;
+                release_[p.i] = p.released ? start_[p.i] + p.release_offset : 0;
             }
         }
         pending_.clear(); pending_min_clock_ = 0;
         idle_.clear(); idle_head_ = 0;
-        buckets_.clear();
+        buckets_.clear(); ring_.clear(); ring_head_ = 0;
         std::vector<std::pair<uint64_t, uint32_t>> all;
         for (int n = 0; n < 256; n++) active_[n] = S2rIndexSet();
-        for (uint32_t i = 0; i < voices_.size(); i++) {
-            const S2rHostVoice &v = voices_[i];
-            if (!v.started) { idle_.push_back(i); continue; }
-            all.push_back({v.start_clock, i});
-            if (!v.released) mark_active(v.note, i);
+        for (uint32_t i = 0; i < n_; i++) {
+            if (!started_[i]) { idle_.push_back(i); continue; }
+            all.push_back({start_[i], i});
+            if (!rel[i]) mark_active(note_[i], i);
         }
         std::sort(all.begin(), all.end());
-        for (const auto &e : all) started_push(e.first, e.second);
+        for (const auto &e : all) push(e.first, e.second);
     }
 
   private:
-    struct Pending { uint32_t i, offset, release_offset; };
+    struct Pending { uint32_t i, offset, release_offset; bool released; };
 
-    // Started voices ordered by (start_clock, index).  The pool clock never goes back, so keys
-    // arrive in non-decreasing clock order: a deque of per-clock buckets, each an index list that
-    // is sorted lazily when it reaches the front.  pop-min and push are O(1) amortised (one
-    // std::sort per bucket), against two ~19-level heap operations on a half-million-entry heap.
-    struct Bucket {
-        uint64_t clock;
-        std::vector<uint32_t> idx;
-        size_t head = 0;
-        bool sorted = true;
-    };
-    std::pair<uint64_t, uint32_t> started_front() const {     // (lazy sort: buckets_ is mutable)
+    // Started voices ordered by (start_clock, index): every one of them sits exactly once in `ring_` (the live part is
+    // [ring_head_, ring_.size()); compacted when the dead part outgrows it), cut into per-clock BUCKETS.  The pool clock
+    // never goes back, so a push goes to the last bucket (or opens one); inside a bucket the indices are sorted lazily
+    // when it reaches the front.  pop-min and push are O(1) amortised.
+    struct Bucket { uint64_t clock; size_t begin, end; bool sorted; };
+    uint32_t front() const {
         Bucket &b = buckets_.front();
-        if (!b.sorted) { std::sort(b.idx.begin() + (std::ptrdiff_t)b.head, b.idx.end()); b.sorted = true; }
-        return {b.clock, b.idx[b.head]};
+        if (!b.sorted) { std::sort(ring_.begin() + (std::ptrdiff_t)b.begin, ring_.begin() + (std::ptrdiff_t)b.end); b.sorted = true; }
+        return ring_[b.begin];
     }
-    void started_pop() {
+    void pop() {
         Bucket &b = buckets_.front();
-        if (++b.head == b.idx.size()) buckets_.pop_front();
+        ring_head_ = ++b.begin;
+        if (b.begin == b.end) buckets_.pop_front();
     }
-    void started_push(uint64_t clock, uint32_t i) {
+    void push(uint64_t clock, uint32_t i) {
         if (buckets_.empty() || buckets_.back().clock != clock) {
-            buckets_.emplace_back();
-            buckets_.back().clock = clock;
+            if (ring_head_ > ring_.size() / 2 + 1024 && ring_.size() >= 4096) compact();
+            buckets_.push_back(Bucket{clock, ring_.size(), ring_.size(), true});
         }
         Bucket &b = buckets_.back();
-        if (b.head > 0 && b.head < b.idx.size() && b.sorted && i <= b.idx[b.head]) {
-            b.idx[--b.head] = i;                  // re-queued at its own clock: still the minimum
+        if (buckets_.size() == 1 && b.sorted && b.begin > 0 && b.begin < b.end && b.begin == ring_head_ && i <= ring_[b.begin]) {
+            ring_[--b.begin] = i; ring_head_ = b.begin;       // re-queued at its own clock: still the minimum
             return;
         }
-        if (b.idx.size() > b.head && i < b.idx.back()) b.sorted = false;
-        b.idx.push_back(i);
+        if (b.end > b.begin && i < ring_[b.end - 1]) b.sorted = false;
+        ring_.push_back(i);
+        b.end = ring_.size();
+    }
+    void compact() {
+        const size_t dead = ring_head_;
+        ring_.erase(ring_.begin(), ring_.begin() + (std::ptrdiff_t)dead);
+        for (Bucket &b : buckets_) { b.begin -= dead; b.end -= dead; }
+        ring_head_ = 0;
+    }
+
+    // the queue's half of a note_on: which voice, what it held
+    uint32_t take_voice(uint8_t note, float velocity, uint8_t *old_note, bool *was_started) {
+        uint32_t i;
+        if (idle_head_ < idle_.size()) { i = idle_[idle_head_++]; *was_started = false; *old_note = 0; started_[i] = 1; }
+        else { i = front(); pop(); *was_started = true; *old_note = note_[i]; }   // (the chosen voice is always the queue's minimum)
+        note_[i] = note; velocity_[i] = velocity; start_[i] = now_;
+        push(now_, i);
+        return i;
     }
 
     // active = started and not yet released; one index set per note, created on first use
     void mark_active(uint8_t note, uint32_t i) {
         S2rIndexSet &a = active_[note];
-        if (!a.ready()) a.init((uint32_t)voices_.size());
+        if (!a.ready()) a.init(n_);
         a.set(i);
     }
 
-    std::vector<S2rHostVoice> voices_;
+    // ---- resolve_batch on several threads ----
+    struct Job {
+        const char *ev = nullptr; size_t stride = 0, n = 0;
+        int64_t *voice_out = nullptr;
+        std::vector<uint8_t> old_note;             // per event: the note a note_on's voice held (valid where old_valid)
+        std::vector<uint8_t> old_valid;
+        std::vector<uint64_t> clock;               // per event: the pool clock it happens at
+    };
+    uint32_t resolve_mt(const S2rPolicyEvent *ev, size_t stride, size_t n, uint32_t t0, int64_t *voice_out, const float *velocity, size_t velocity_stride) {
+        start_workers();
+        Job &j = job_;
+        j.ev = reinterpret_cast<const char *>(ev); j.stride = stride; j.n = n; j.voice_out = voice_out;
+        for (size_t k = 0; k < n; k++) {                          // (no set is created while the workers run)
+            const S2rPolicyEvent &e = *reinterpret_cast<const S2rPolicyEvent *>(j.ev + k * stride);
+            if (e.kind == S2R_POLICY_NOTE_ON && !active_[e.note].ready()) active_[e.note].init(n_);
+        }
+        if (j.old_note.size() < n) { j.old_note.resize(n); j.old_valid.resize(n); j.clock.resize(n); }
+        a_done_.store(0, std::memory_order_relaxed);
+        generation_.fetch_add(1, std::memory_order_release);
+        wake_workers();
+        // phase A, this thread: the queue.  Published to the workers every 128 events.
+        uint32_t t = t0;
+        for (size_t k = 0; k < n; k++) {
+            const S2rPolicyEvent &e = *reinterpret_cast<const S2rPolicyEvent *>(j.ev + k * stride);
+            if (e.frame > t) { now_ += e.frame - t; t = e.frame; }
+            j.clock[k] = now_;
+            if (e.kind == S2R_POLICY_NOTE_ON) {
+                const float vel = velocity ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(velocity) + k * velocity_stride) : 1.0f;
+                uint8_t old; bool was;
+                voice_out[k] = take_voice(e.note, vel, &old, &was);
+                j.old_note[k] = old; j.old_valid[k] = was ? 1 : 0;
+            } else if (e.kind != S2R_POLICY_NOTE_OFF) voice_out[k] = -1;
+            if ((k & 127u) == 127u) a_done_.store(k + 1, std::memory_order_release);
+        }
+        a_done_.store(n, std::memory_order_release);
+        for (auto &w : workers_) while (w->done.load(std::memory_order_acquire) != generation_.load(std::memory_order_relaxed)) cpu_pause();
+        return t;
+    }
+    // phase B, worker `me` of `P`: the sets of the notes it owns, event by event behind phase A
+    void worker_batch(uint32_t me, uint32_t P) {
+        const Job &j = job_;
+        size_t avail = 0;
+        for (size_t k = 0; k < j.n; k++) {
+            while (k >= avail) { avail = a_done_.load(std::memory_order_acquire); if (k >= avail) cpu_pause(); }
+            const S2rPolicyEvent &e = *reinterpret_cast<const S2rPolicyEvent *>(j.ev + k * j.stride);
+            if (e.kind == S2R_POLICY_NOTE_ON) {
+                const uint32_t i = (uint32_t)j.voice_out[k];
+                if (j.old_valid[k] && j.old_note[k] % P == me) active_[j.old_note[k]].clear(i);
+                if (e.note % P == me) active_[e.note].set(i);
+            } else if (e.kind == S2R_POLICY_NOTE_OFF && e.note % P == me) {
+                S2rIndexSet &a = active_[e.note];
+                const int64_t i = a.last();
+                if (i >= 0) {
+                    a.clear((uint32_t)i);
+                    // The clock of the voice's LATEST release.  A voice released under this worker's note, taken over by a
+                    // later note_on and released again under another worker's note is written by both, in either order:
+                    // clocks only grow with the events, so the greater value is the later release's.
+                    uint64_t *r = &release_[(size_t)i];
+                    uint64_t cur = __atomic_load_n(r, __ATOMIC_RELAXED);
+                    while (cur < j.clock[k] && !__atomic_compare_exchange_n(r, &cur, j.clock[k], true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+                }
+                j.voice_out[k] = i;
+            }
+        }
+    }
+    struct Worker { std::thread th; std::atomic<uint64_t> done{0}; };
+    static void cpu_pause() {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#elif defined(__aarch64__)
+        asm volatile("yield" ::: "memory");
+#endif
+    }
+    void start_workers() {
+        if (!workers_.empty()) return;
+        quit_.store(false);
+        const uint32_t P = workers_wanted_;
+        for (uint32_t w = 0; w < P; w++) {
+            workers_.emplace_back(new Worker());
+            Worker *me = workers_.back().get();
+            me->done.store(generation_.load());
+            me->th = std::thread([this, me, w, P] {
+                uint64_t seen = me->done.load();
+                for (;;) {
+                    // spin for a while (the next batch of a caller in a loop comes within tens of microseconds), then sleep
+                    uint64_t g = seen; uint32_t spins = 0;
+                    while ((g = generation_.load(std::memory_order_acquire)) == seen && !quit_.load(std::memory_order_relaxed)) {
+                        if (++spins < 200000u) cpu_pause();
+                        else {
+                            std::unique_lock<std::mutex> lk(mu_);
+                            sleepers_++;
+                            cv_.wait(lk, [&] { return generation_.load(std::memory_order_acquire) != seen || quit_.load(); });
+                            sleepers_--;
+                        }
+                    }
+                    if (quit_.load()) return;
+                    worker_batch(w, P);
+                    seen = g;
+                    me->done.store(g, std::memory_order_release);
+                }
+            });
+        }
+    }
+    void wake_workers() {
+        if (sleepers_ > 0) { std::lock_guard<std::mutex> lk(mu_); cv_.notify_all(); }
+    }
+    void stop_workers() {
+        if (workers_.empty()) return;
+        { std::lock_guard<std::mutex> lk(mu_); quit_.store(true); cv_.notify_all(); }
+        for (auto &w : workers_) if (w->th.joinable()) w->th.join();
+        workers_.clear();
+    }
+
+    uint32_t n_;
+    std::vector<uint8_t> note_, started_;
+    std::vector<float> velocity_;
+    std::vector<uint64_t> start_, release_;
     std::vector<uint32_t> idle_;        // ascending; consumed from idle_head_ (voices never go idle again)
     size_t idle_head_ = 0;
-    mutable std::deque<Bucket> buckets_;   // one entry per started voice
+    mutable std::vector<uint32_t> ring_;
+    size_t ring_head_ = 0;
+    mutable std::deque<Bucket> buckets_;
     S2rIndexSet active_[256];
     std::vector<Pending> pending_;
     uint64_t pending_min_clock_ = 0;
     uint64_t now_ = 0;
+    // worker threads
+    uint32_t workers_wanted_ = 0;
+    size_t mt_threshold_ = 4096;
+    std::vector<std::unique_ptr<Worker>> workers_;
+    std::atomic<uint64_t> generation_{0};
+    std::atomic<size_t> a_done_{0};
+    std::atomic<bool> quit_{false};
+    std::atomic<int> sleepers_{0};
+    std::mutex mu_;
+    std::condition_variable cv_;
+    Job job_;
 };

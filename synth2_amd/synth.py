@@ -185,6 +185,8 @@ def load_library():
         "s2r_voice_pool_note_off": (C.c_int64, [H, C.c_uint8]),
         "s2r_voice_pool_advance": (None, [H, C.c_uint64]),
         "s2r_voice_pool_next_voice": (C.c_uint32, [H]),
+        "s2r_voice_pool_set_threads": (None, [H, C.c_uint32, C.c_size_t]),
+        "s2r_voice_pool_resolve": (C.c_uint32, [H, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
         "s2r_voice_pool_query": (C.c_int, [H, C.c_uint32, C.POINTER(VoiceState)]),
     }
     for name, (res, args) in sig.items():
@@ -255,6 +257,16 @@ class VoicePool:
 
     def advance(self, frames):
         self.L.s2r_voice_pool_advance(self.p, frames)
+
+    def set_threads(self, worker_threads, batch_threshold=4096):
+        self.L.s2r_voice_pool_set_threads(self.p, worker_threads, batch_threshold)
+
+    def resolve(self, events, frames_moved=0):
+        """the batch form: (voice per event, frame of the last event)"""
+        ev = np.ascontiguousarray(events, dtype=NOTE_EVENT_DTYPE)
+        out = np.empty(ev.size, dtype=np.int64)
+        t = self.L.s2r_voice_pool_resolve(self.p, ev.ctypes.data, ev.size, frames_moved, out.ctypes.data)
+        return out, int(t)
 
     def next_voice(self):
         return self.L.s2r_voice_pool_next_voice(self.p)

@@ -272,3 +272,59 @@ def test_the_library_is_bound_to_its_sources_by_content(tmp_path):
         os.utime(g, (old, old))
     assert b.source_hash(str(csrc)) != b.source_hash()
     assert b.needs_build(str(csrc)), "a library built from other sources must be refused or rebuilt, whatever the times say"
+
+
+@pytest.mark.parametrize("threads", [0, 3])
+def test_voice_pool_batch_form_equals_event_by_event(threads):
+    """S2rVoicePool::resolve_batch — what s2r_note_events runs; with `threads` > 0 the queue on the caller's thread and the
+    notes' sets shared among worker threads — makes the choices of the event-by-event policy (itself held against the oracle's
+    O(V) restatement of synth.rs:61-120 above) on random streams: stolen voices still held, note_offs that find nothing,
+    several boundaries per batch, batches below and above the threshold, a pool smaller than a batch."""
+    rng = np.random.RandomState(100 + threads)
+    for voices, n_batches, n_ev in ((64, 30, 300), (5000, 12, 3000), (70000, 4, 9000)):
+        a = s2.VoicePool(voices)
+        b = s2.VoicePool(voices)
+        b.set_threads(threads, 256)
+        ora = s2o.OracleSynth(voices) if voices <= 5000 else None
+        for k in range(n_batches):
+            n = int(rng.randint(1, n_ev))
+            ev = np.zeros(n, dtype=s2.NOTE_EVENT_DTYPE)
+            ev["kind"] = (rng.rand(n) < 0.55).astype(np.uint8)
+            ev["note"] = rng.randint(30, 30 + (12 if k % 3 else 90), n)
+            ev["velocity"] = rng.rand(n).astype(np.float32)
+            ev["frame"] = np.sort(rng.randint(0, 64, n)) * 16 if k % 2 else 0
+            want = np.empty(n, dtype=np.int64)
+            t = 0
+            for j in range(n):
+                f = int(ev["frame"][j])
+                if f > t:
+                    a.advance(f - t)
+                    if ora is not None:
+                        for v in range(voices):              # (the oracle's clock is its voices' offsets: synth.rs:196-199)
+                            vo = ora.p.contents.voices[v]
+                            if vo.has_current:
+                                vo.current_frame_offset += f - t
+                    t = f
+                if ev["kind"][j] == 1:
+                    if ora is not None:
+                        assert a.next_voice() == ora.next_voice_index()
+                        ora.note_on(int(ev["note"][j]), float(ev["velocity"][j]))
+                    want[j] = a.note_on(int(ev["note"][j]), float(ev["velocity"][j]))
+                else:
+                    want[j] = a.note_off(int(ev["note"][j]))
+                    if ora is not None:
+                        ora.note_off(int(ev["note"][j]))
+            got, t_end = b.resolve(ev)
+            assert t_end == t
+            assert np.array_equal(got, want), "batch %d of %d voices: first difference at event %d" % (k, voices, int(np.nonzero(got != want)[0][0]))
+            a.advance(1024 - t); b.advance(1024 - t)
+            if ora is not None:
+                for v in range(voices):
+                    vo = ora.p.contents.voices[v]
+                    if vo.has_current:
+                        vo.current_frame_offset += 1024 - t
+            for v in rng.randint(0, voices, 40):
+                qa, qb = a.query(int(v)), b.query(int(v))
+                assert (qa.note, qa.started, qa.released, qa.current_frame_offset) == (qb.note, qb.started, qb.released, qb.current_frame_offset)
+                if qa.released:
+                    assert qa.release_frame_offset == qb.release_frame_offset

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
 def test_voice_pool_and_parser_under_asan_ubsan(tmp_path):
     exe = str(tmp_path / "san_host")
-    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                            "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "synth2_amd", "csrc"),
                            os.path.join(ROOT, "tests", "native", "san_host.cpp"),
                            os.path.join(ROOT, "synth2_amd", "csrc", "s2r_patch.cpp"),
@@ -23,6 +23,20 @@ def test_voice_pool_and_parser_under_asan_ubsan(tmp_path):
     assert "pool ok" in out.stdout
     # s2r_stream_frame_json with the buffer sized exactly as advertised (16 chars per sample overflowed)
     assert "stream ok" in out.stdout and "longest element 16 chars" in out.stdout, out.stdout
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_policy_threads_under_tsan(tmp_path):
+    """the allocation policy's batch form on four threads (S2rVoicePool::resolve_batch: the queue on the caller's thread, the
+    notes' sets shared among three workers) under ThreadSanitizer, its choices and the voices' clocks equal to the
+    event-by-event policy's on random batches (tests/native/tsan_policy.cpp)"""
+    exe = str(tmp_path / "tsan_policy")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", "-I", os.path.join(ROOT, "synth2_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "native", "tsan_policy.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    if out.returncode != 0 and "unexpected memory mapping" in out.stderr:
+        pytest.skip("ThreadSanitizer cannot map its shadow here")
+    assert out.returncode == 0 and "policy threads ok" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
 
 
 @pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc not available")

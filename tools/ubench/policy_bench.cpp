@@ -1,15 +1,18 @@
 // development aid: host cost of the allocation policy (s2r_voices.h) on the C3 event schedule, ns per event.
-//   g++ -O2 -std=c++17 -I synth2_amd/csrc tools/ubench/policy_bench.cpp -o tools/ubench/_build/policy_bench && tools/ubench/_build/policy_bench
+//   g++ -O2 -std=c++17 -pthread -I synth2_amd/csrc tools/ubench/policy_bench.cpp -o tools/ubench/_build/policy_bench && tools/ubench/_build/policy_bench
 #include <chrono>
 #include <cstdio>
 #include <cstdint>
 #include <vector>
 #include <algorithm>
+#include <cstdlib>
 #include "s2r_voices.h"
 
 struct Ev { uint8_t kind, note; uint16_t frame; };
 
+// usage: policy_bench [worker threads for the batch form, default 3]
 int main(int argc, char **argv) {
+    const uint32_t n_workers = argc > 1 ? (uint32_t)atoi(argv[1]) : 3u;
     for (uint32_t V : {65536u, 524288u, 1048576u}) {
         const uint32_t period = 64, frames = 1024;
         std::vector<std::vector<Ev>> cyc(period);
@@ -45,8 +48,30 @@ int main(int argc, char **argv) {
         auto t0 = std::chrono::steady_clock::now();
         for (uint32_t k = 0; k < 4 * period; k++) run(k);
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        printf("%8u voices: %6.1f ns per event, %7.1f us per buffer (%llu events per buffer)  [%llu]\n", V, dt * 1e9 / n, dt * 1e6 / (4 * period),
+        printf("%8u voices: one event at a time %6.1f ns per event, %7.1f us per buffer (%llu events per buffer)  [%llu]\n", V, dt * 1e9 / n, dt * 1e6 / (4 * period),
                (unsigned long long)(n / (4 * period)), (unsigned long long)sink);
+        // the batch form (what s2r_note_events calls): one thread, then the caller's thread + n_workers
+        for (uint32_t workers : {0u, n_workers}) {
+            S2rVoicePool bp(V);
+            bp.set_workers(workers, 1024);
+            std::vector<int64_t> out(V);
+            uint64_t sink2 = 0, nb = 0;
+            auto runb = [&](uint32_t k) {
+                const std::vector<Ev> &b = cyc[k % period];
+                static_assert(sizeof(Ev) == sizeof(S2rPolicyEvent), "same layout");
+                const uint32_t t = bp.resolve_batch(reinterpret_cast<const S2rPolicyEvent *>(b.data()), sizeof(Ev), b.size(), 0u, out.data());
+                bp.advance(frames - t);
+                for (size_t i = 0; i < b.size(); i += 64) sink2 += (uint64_t)out[i];
+                nb += b.size();
+            };
+            for (uint32_t k = 0; k < 2 * period; k++) runb(k);
+            nb = 0;
+            auto tb0 = std::chrono::steady_clock::now();
+            for (uint32_t k = 0; k < 4 * period; k++) runb(k);
+            const double dtb = std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count();
+            printf("%8u voices: batch, %u worker threads    %6.1f ns per event, %7.1f us per buffer  [%llu]\n", V, workers, dtb * 1e9 / nb, dtb * 1e6 / (4 * period),
+                   (unsigned long long)sink2);
+        }
     }
     return 0;
 }
