@@ -266,6 +266,7 @@ struct S2rResident {
 #define S2R_POOL_CMD_SLOTS 4u
 #define S2R_POOL_CMD_WORDS 16u
 #define S2R_POOL_FLAG_EXIT 1u
+#define S2R_POOL_FLAG_TWO_STREAMS 2u   // the fill's chain heads and mix are a launch on the other stream (S2rOverlapWords); [11] the heads' target
 struct S2rPool {
     const uint32_t *cmd;              // [S2R_POOL_CMD_SLOTS][16]
     const uint32_t *slices;           // [S2R_POOL_CMD_SLOTS][n_blocks + 1], mapped host memory
@@ -275,6 +276,8 @@ struct S2rPool {
     int32_t *heads[2];
     float *partials[2];
     uint32_t *arrive;                 // [2] by parity
+    const uint32_t *ov_heads;         // S2rOverlapWords.heads_done[2], .render_done[2] (two-stream fills)
+    uint32_t *ov_render;
     float *out[3];                    // ring slot 0, ring slot 1, the synchronous buffer (mapped host memory) — or this shard's rows
     uint32_t *done_flag, *done_counter;   // [3] each, as `out`
     uint32_t *decided;                // device memory

@@ -340,7 +340,9 @@ int launch_deferred_mix(s2r_synth *s, hipStream_t stream) {
 int overlap_drain(s2r_synth *s) {
     if (!s->ov_busy) return S2R_OK;
     if (s->dmix.active && s->dmix.overlap) { int rc = launch_deferred_mix(s, s->stream); if (rc != S2R_OK) return rc; }
-    S2R_HIP(s, hipStreamSynchronize(s->stream));
+    // (a pool-resident kernel never ends a wait for its stream; the last mix on stream_b waits in the kernel for the rows of
+    // every workgroup of its fill, so it says what the render side's stream would)
+    if (!s->pool_running) S2R_HIP(s, hipStreamSynchronize(s->stream));
     S2R_HIP(s, hipStreamSynchronize(s->stream_b));
     s->ov_busy = false;
     return S2R_OK;
@@ -354,8 +356,10 @@ int slot_release(s2r_synth *s, EventSlot &sl) {
         // mix, possibly still deferred — has not reported yet)
         int rc = launch_deferred_mix(s, s->stream);
         if (rc != S2R_OK) return rc;
-        S2R_HIP(s, hipStreamSynchronize(s->stream));
+        if (!s->pool_running) S2R_HIP(s, hipStreamSynchronize(s->stream));
         if (s->ov_busy) S2R_HIP(s, hipStreamSynchronize(s->stream_b));
+        // (a fill of the pool-resident kernel: only its completion word tells)
+        for (int spin = 0; s->pool_running && (int32_t)(*sl.word - sl.seq) < 0 && spin < 2000000; spin++) cpu_relax();
     }
     sl.state = 0;
     return S2R_OK;
@@ -865,6 +869,7 @@ int pool_launch(s2r_synth *s, uint32_t sample_rate, uint32_t first_seq) {
     for (int k = 0; k < 4; k++) pl.tev_src[k] = s->slots[k].tdev;
     for (int b = 0; b < 2; b++) { pl.tev_copy[b] = s->tevcopy2[b]; pl.heads[b] = s->heads2[b]; pl.partials[b] = s->partials2[b]; }
     pl.arrive = s->fz_arrive;
+    if (s->ov_words) { pl.ov_heads = s->ov_words->heads_done; pl.ov_render = s->ov_words->render_done; }
     pl.out[0] = s->ring_dev[0]; pl.out[1] = s->ring_dev[1]; pl.out[2] = s->out_host_dev;
     pl.done_flag = s->done_dev; pl.done_counter = s->done_counter;
     pl.decided = s->pool_decided; pl.exited = s->pool_host_dev; pl.fail = s->done_dev + 3;
@@ -939,7 +944,7 @@ int pool_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, uint32_t sel, b
 // `defer_ring_slot` >= 0 (s2r_fill_begin): the fill's mix is left to the next fill_begin / fill_end (DeferredMix)
 int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t stream, float *dev_out,
                  bool root_add, bool stereo, float *per_voice_dev, int defer_ring_slot = -1, const S2rDone *done = nullptr,
-                 const Exchange *xc = nullptr) {
+                 const Exchange *xc = nullptr, bool via_pool = false) {
     // one launch per fill where the shard's shape allows it (the fills of s2r_fill_begin keep the two streams unless asked)
     if (dev_out != nullptr && per_voice_dev == nullptr && fused_shape_ok(s) &&
         (xc != nullptr || s->fused_mode >= 2 || !(s->ov_enabled && defer_ring_slot >= 0 && stream == s->stream && root_add && done != nullptr)))
@@ -963,6 +968,18 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
     bool arg_events = s->use_arg_events && s->tpending.empty() && s->pending.size() <= S2R_ARG_MAX_EVENTS;
     if (arg_events)
         for (const S2rVoiceEvent &e : s->pending) if (e.seed != 0u) { arg_events = false; break; }
+    via_pool = via_pool && overlap;
+    if (via_pool) {
+        // The fill goes to the pool-resident kernel in its two-stream form: the render launch becomes a posted command, the
+        // chain heads and the mix stay the other stream's launch.  Every event comes as a chain (no kernel arguments to ride in).
+        if (s->pool_running && (s->pool_rate != sample_rate || pool_exited(s) || s->pending.size() + s->tpending.size() > s->tev_capacity)) {
+            int rc = pool_exited(s) ? pool_recover(s) : S2R_OK;
+            if (rc == S2R_OK) rc = pool_stop(s);
+            if (rc != S2R_OK) return rc;
+        }
+        arg_events = false;
+        merge_pending_into_chains(s);
+    }
     EventSlot *timed_slot = nullptr;
     const S2rTimedEvent *tev_dev = nullptr;
     if (!arg_events) {
@@ -1057,9 +1074,17 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
     // a shard of one workgroup needs no mix launch: its only partial row, root-added, is the output
     const bool direct = dev_out != nullptr && root_add && s->n_blocks == 1;
     if (direct) { p.direct_out = dev_out; p.direct_stereo = stereo ? 1 : 0; if (done) p.done = *done; }
+    if (via_pool) {
+        uint32_t w[16] = {0};
+        w[1] = (uint32_t)frames | (S2R_POOL_FLAG_TWO_STREAMS << 16); w[2] = tev_dev ? 1u : 0u; w[6] = (uint32_t)ov_parity;
+        w[11] = s->ov_heads_target[ov_parity];
+        const uint32_t seq = pool_post(s, w);
+        if (!s->pool_running) { int rc = pool_launch(s, sample_rate, seq); if (rc != S2R_OK) return rc; }
+    } else {
     if (s->timing) S2R_HIP(s, hipEventRecord(s->t0, stream));      // brackets the render kernel alone
     S2R_HIP(s, s2r_launch_render(a, s->block_voices, stream));
     if (s->timing) { S2R_HIP(s, hipEventRecord(s->t1, stream)); s->timed = true; }
+    }
     if (timed_slot) {                     // the render kernel was the last reader of the slot's records
         if (done) { timed_slot->state = 2; timed_slot->word = s->done_host + (done->flag - s->done_dev); timed_slot->seq = done->value; }
         else { S2R_HIP(s, hipEventRecord(timed_slot->done, stream)); timed_slot->state = 1; }
@@ -1211,8 +1236,13 @@ int overlap_check(s2r_synth *s) {
 int enqueue_root(s2r_synth *s, size_t frames, uint32_t sample_rate, float *dev_out, bool stereo, int defer_ring_slot = -1,
                  const S2rDone *done = nullptr) {
     if (!s->kids.empty()) return enqueue_multi(s, frames, sample_rate, dev_out, stereo, nullptr, done, defer_ring_slot);
-    if (done && done->flag && pool_eligible(s, frames))
+    if (done && done->flag && pool_eligible(s, frames)) {
+        // (S2R_POOL_FORM=fused: every fill in the one-launch form, the chain heads and the mix in the render kernel itself)
+        static const bool fused_only = [] { const char *e = std::getenv("S2R_POOL_FORM"); return e && e[0] == 'f'; }();
+        if (s->ov_enabled && defer_ring_slot >= 0 && !stereo && !fused_only)
+            return enqueue_fill(s, frames, sample_rate, s->stream, dev_out, true, stereo, nullptr, defer_ring_slot, done, nullptr, true);
         return pool_fill(s, frames, sample_rate, (uint32_t)(done->flag - s->done_dev), stereo, done->value, nullptr, 0u);
+    }
     { int rc = pool_stop(s); if (rc != S2R_OK) return rc; }
     return enqueue_fill(s, frames, sample_rate, s->stream, dev_out, true, stereo, nullptr, defer_ring_slot, done);
 }
@@ -1455,12 +1485,16 @@ const char *s2r_status_string(int status) {
     }
 }
 
-// Worker threads of the allocation policy's batch form (S2rVoicePool::resolve_batch): S2R_POLICY_THREADS, else three for the
-// pools of multi-GPU runs (every rank resolves the WHOLE pool's events: 16 384 per buffer at 8 x 65 536 voices), none below.
-// Only batches of at least 4096 events use them.
+// Worker threads of the allocation policy's batch form (S2rVoicePool::resolve_batch): S2R_POLICY_THREADS, default NONE.
+// Built for the pools of multi-GPU runs (every rank resolves the WHOLE pool's events: 16 384 per buffer at 8 x 65 536 voices),
+// bit-identical (tests/native/tsan_policy.cpp) and measured SLOWER than one thread on the bench host at every pool size
+// (profiles/r04/ngpu_host_cost.txt: 6.7 ns per event alone, 11.5 with three workers in the caller's core complex, 40 across
+// complexes): what one thread spends per event is less than one cache line's trip between two cores, and the hand-over
+// from the queue to the notes' owners is a line per eight events per worker.
 static void configure_policy_threads(S2rVoicePool *pool, uint32_t total_voices) {
+    (void)total_voices;
     const char *e = std::getenv("S2R_POLICY_THREADS");
-    uint32_t n = total_voices >= 262144u ? 3u : 0u;
+    uint32_t n = 0u;
     if (e && e[0] >= '0' && e[0] <= '9') n = (uint32_t)std::atoi(e);
     pool->set_workers(n, 4096);
 }

@@ -782,6 +782,10 @@ struct FillCtl {
     uint32_t arrive_target;
     uint32_t *fail;
     S2rMixTail mt;
+    // two streams (S2rOverlapWords): the chain heads come from a kernel on the other stream, the rows go to a mix there
+    const uint32_t *ov_heads_counter;
+    uint32_t ov_heads_target;
+    uint32_t *ov_render_counter;
 };
 
 // a launch is a fill: everything from the kernel arguments
@@ -799,6 +803,7 @@ __device__ __forceinline__ FillCtl fill_ctl_from_args(const S2rRenderArgs &a) {
     }
     c.arrive = p.arrive; c.arrive_target = p.arrive_target; c.fail = p.ov_fail;
     c.mt = p.mt;
+    c.ov_heads_counter = p.ov_heads_counter; c.ov_heads_target = p.ov_heads_target; c.ov_render_counter = p.ov_render_counter;
     return c;
 }
 
@@ -946,7 +951,7 @@ __device__ __forceinline__ void combine_groups(const S2rRenderParams &p, const S
             acc = pk_add4(pk_add4(pk_add4(pk_add4(acc, v0), v1), v2), v3);
         }
         const uint32_t n = n_sc - f < 4u ? n_sc - f : 4u;
-        if (wt || p.ov_render_counter != nullptr) {              // the row is handed to workgroups of another compute unit (a mix beside or behind this kernel)
+        if (wt) {                                                // the row is handed to workgroups of another compute unit (a mix beside or behind this kernel)
             if (n == 4u) ov_store4(bp_sc + f, acc);
             else for (uint32_t j = 0; j < n; ++j) ov_store(bp_sc + f + j, acc[j]);
         } else if (n == 4u) *reinterpret_cast<f4 *>(bp_sc + f) = acc;

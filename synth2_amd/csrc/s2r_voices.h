@@ -290,22 +290,27 @@ class S2rVoicePool {
     }
 
     // ---- resolve_batch on several threads ----
+    // What phase A hands to the workers, one 8-byte word per event, written once by the caller's thread and only read by the
+    // others (no line is written from two cores): the voice a note_on took, the note it held (256: none).  The workers' own
+    // results — the voices their note_offs released — go to lists of their own and are put in place by the caller afterwards:
+    // results written straight into the caller's array, a worker's note_offs next to the caller's note_ons, made every event a
+    // cache line bouncing between cores (measured: the threaded form five times SLOWER than one thread).
+    struct Handover { uint32_t voice; uint16_t old_note; uint16_t pad; };
     struct Job {
         const char *ev = nullptr; size_t stride = 0, n = 0;
-        int64_t *voice_out = nullptr;
-        std::vector<uint8_t> old_note;             // per event: the note a note_on's voice held (valid where old_valid)
-        std::vector<uint8_t> old_valid;
-        std::vector<uint64_t> clock;               // per event: the pool clock it happens at
+        uint32_t t0 = 0; uint64_t now0 = 0;
+        std::vector<Handover> h;
     };
     uint32_t resolve_mt(const S2rPolicyEvent *ev, size_t stride, size_t n, uint32_t t0, int64_t *voice_out, const float *velocity, size_t velocity_stride) {
         start_workers();
         Job &j = job_;
-        j.ev = reinterpret_cast<const char *>(ev); j.stride = stride; j.n = n; j.voice_out = voice_out;
+        j.ev = reinterpret_cast<const char *>(ev); j.stride = stride; j.n = n;
         for (size_t k = 0; k < n; k++) {                          // (no set is created while the workers run)
             const S2rPolicyEvent &e = *reinterpret_cast<const S2rPolicyEvent *>(j.ev + k * stride);
             if (e.kind == S2R_POLICY_NOTE_ON && !active_[e.note].ready()) active_[e.note].init(n_);
         }
-        if (j.old_note.size() < n) { j.old_note.resize(n); j.old_valid.resize(n); j.clock.resize(n); }
+        if (j.h.size() < n) j.h.resize(n);
+        j.t0 = t0; j.now0 = now_;
         a_done_.store(0, std::memory_order_relaxed);
         generation_.fetch_add(1, std::memory_order_release);
         wake_workers();
@@ -314,33 +319,45 @@ class S2rVoicePool {
         for (size_t k = 0; k < n; k++) {
             const S2rPolicyEvent &e = *reinterpret_cast<const S2rPolicyEvent *>(j.ev + k * stride);
             if (e.frame > t) { now_ += e.frame - t; t = e.frame; }
-            j.clock[k] = now_;
             if (e.kind == S2R_POLICY_NOTE_ON) {
                 const float vel = velocity ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(velocity) + k * velocity_stride) : 1.0f;
                 uint8_t old; bool was;
-                voice_out[k] = take_voice(e.note, vel, &old, &was);
-                j.old_note[k] = old; j.old_valid[k] = was ? 1 : 0;
-            } else if (e.kind != S2R_POLICY_NOTE_OFF) voice_out[k] = -1;
-            if ((k & 127u) == 127u) a_done_.store(k + 1, std::memory_order_release);
+                const uint32_t i = take_voice(e.note, vel, &old, &was);
+                voice_out[k] = i;
+                j.h[k] = Handover{i, (uint16_t)(was ? old : 256u), 0};
+            } else voice_out[k] = -1;
+            if ((k & 255u) == 255u) a_done_.store(k + 1, std::memory_order_release);
         }
         a_done_.store(n, std::memory_order_release);
         for (auto &w : workers_) while (w->done.load(std::memory_order_acquire) != generation_.load(std::memory_order_relaxed)) cpu_pause();
+        // the workers' note_offs, in event order per worker, back into the caller's array
+        const uint32_t P = (uint32_t)workers_.size();
+        size_t cur[16] = {0};
+        for (size_t k = 0; k < n; k++) {
+            const S2rPolicyEvent &e = *reinterpret_cast<const S2rPolicyEvent *>(j.ev + k * stride);
+            if (e.kind == S2R_POLICY_NOTE_OFF) { const uint32_t w = e.note % P; voice_out[k] = workers_[w]->released[cur[w]++]; }
+        }
         return t;
     }
     // phase B, worker `me` of `P`: the sets of the notes it owns, event by event behind phase A
     void worker_batch(uint32_t me, uint32_t P) {
         const Job &j = job_;
+        std::vector<int64_t> &rel = workers_[me]->released;
+        rel.clear();
         size_t avail = 0;
+        uint32_t t = j.t0; uint64_t now = j.now0;
         for (size_t k = 0; k < j.n; k++) {
             while (k >= avail) { avail = a_done_.load(std::memory_order_acquire); if (k >= avail) cpu_pause(); }
             const S2rPolicyEvent &e = *reinterpret_cast<const S2rPolicyEvent *>(j.ev + k * j.stride);
+            if (e.frame > t) { now += e.frame - t; t = e.frame; }            // (the clock, as phase A moves it)
             if (e.kind == S2R_POLICY_NOTE_ON) {
-                const uint32_t i = (uint32_t)j.voice_out[k];
-                if (j.old_valid[k] && j.old_note[k] % P == me) active_[j.old_note[k]].clear(i);
-                if (e.note % P == me) active_[e.note].set(i);
+                const Handover h = j.h[k];
+                if (h.old_note < 256u && h.old_note % P == me) active_[h.old_note].clear(h.voice);
+                if (e.note % P == me) active_[e.note].set(h.voice);
             } else if (e.kind == S2R_POLICY_NOTE_OFF && e.note % P == me) {
                 S2rIndexSet &a = active_[e.note];
-                const int64_t i = a.last();
+                const int64_t i = a.ready() ? a.last() : -1;
+                rel.push_back(i);
                 if (i >= 0) {
                     a.clear((uint32_t)i);
                     // The clock of the voice's LATEST release.  A voice released under this worker's note, taken over by a
@@ -348,13 +365,12 @@ class S2rVoicePool {
                     // clocks only grow with the events, so the greater value is the later release's.
                     uint64_t *r = &release_[(size_t)i];
                     uint64_t cur = __atomic_load_n(r, __ATOMIC_RELAXED);
-                    while (cur < j.clock[k] && !__atomic_compare_exchange_n(r, &cur, j.clock[k], true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+                    while (cur < now && !__atomic_compare_exchange_n(r, &cur, now, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
                 }
-                j.voice_out[k] = i;
             }
         }
     }
-    struct Worker { std::thread th; std::atomic<uint64_t> done{0}; };
+    struct alignas(128) Worker { std::thread th; std::atomic<uint64_t> done{0}; std::vector<int64_t> released; };
     static void cpu_pause() {
 #if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();

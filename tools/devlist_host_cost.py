@@ -4,6 +4,7 @@ side by side on per-device host threads).  The pool and the event stream stay th
 step — and are cut into N shards; on a one-GPU box every shard lives on device 0.
     python tools/devlist_host_cost.py [N ...]"""
 import sys, os, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # (N shards on ONE device, each with a resident kernel on a stream of its own: s2r.h, s2r_set_resident)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import synth2_amd as s2
@@ -11,8 +12,11 @@ from bench import make_c3_events, FRAMES, SR, PERIOD
 
 V = int(os.environ.get("V", 65536))
 cyc = make_c3_events(V, PERIOD)
-for n in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
+modes = os.environ.get("MODES", "launch,resident").split(",")
+for mode, n in [(m, int(a)) for m in modes for a in (sys.argv[1:] or [1, 2, 4, 8])]:
     s = s2.Synth(V, max_frames=FRAMES, devices=[0] * n, shard_interleave=64) if n > 1 else s2.Synth(V, max_frames=FRAMES)
+    if mode == "resident":
+        s.set_resident(True)
     bufs = [np.empty(FRAMES, dtype=np.float32) for _ in range(2)]
     for k in range(PERIOD):
         s.note_events(cyc[k]); s.sample(bufs[0], SR)
@@ -28,6 +32,6 @@ for n in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
         t_ev += b - a; t_b += c - b; t_e += d - c
     s.sample_end(bufs[0])
     tot = time.perf_counter() - t0
-    print("device list of %d (%5d voices per shard): step %6.1f us = note_events %5.1f + fill_begin %5.1f + fill_end (wait + copy) %5.1f" % (
-        n, V // n, tot / reps * 1e6, t_ev / reps * 1e6, t_b / reps * 1e6, t_e / reps * 1e6))
+    print("%-8s device list of %d (%5d voices per shard): step %6.1f us = note_events %5.1f + fill_begin %5.1f + fill_end (wait + copy) %5.1f" % (
+        mode, n, V // n, tot / reps * 1e6, t_ev / reps * 1e6, t_b / reps * 1e6, t_e / reps * 1e6))
     s.close()
