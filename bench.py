@@ -59,7 +59,7 @@ PERIOD = 64                     # buffers between two lives of a voice (workload
 BYTES_PER_VOICE_FILL = 28 + 12
 # fp32-equivalent flops per voice-sample of the x16 path with the default patch
 FLOPS_PER_VOICE_SAMPLE = 250.0
-PROFILE_ROUND = "r03"                 # profiles/<round>/c3_summary.json: the rocprofv3 summary bench.py quotes counters from
+PROFILE_ROUND = "r04"                 # profiles/<round>/c3_summary.json: the rocprofv3 summary bench.py quotes counters from
 HBM_PEAK_GBS = 8000.0
 VALU_PEAK_TFLOPS = 157.3
 # one wave-instruction per SIMD per 2 cycles (SIMD-32, MI355X_MICROARCH.md): 1024 SIMDs x 2.4 GHz / 2
@@ -320,6 +320,8 @@ def run_config_leg(name, voices, patch_text, steps, warmup, oversampled=False, b
            "roofline": {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_voice_per_fill": bytes_per_voice},
            "mix_checksum": float(np.abs(out).sum())}
+    # what the leg's render kernel EXECUTED (committed rocprofv3 summary of this build: tools/profile_leg.sh): issue and fp32 fractions
+    leg["roofline_valu"] = executed_roofline(committed_profile("c4_summary.json" if oversampled else "c2_summary.json"), voices * (4 if oversampled else 1), kernel_ms)
     if oversampled:
         leg["internal_rate_voice_samples_per_s"] = leg["value"] * 4.0
         leg["timed_call"] = "s2r_note_events + s2r_fill_oversampled (4 096 internal frames at 192 kHz -> 1 024 at 48 kHz), one buffer at a time"
@@ -360,11 +362,11 @@ def kernel_source_hash():
     return _b.source_hash()
 
 
-def committed_profile():
+def committed_profile(name="c3_summary.json"):
     """PMC figures of the render kernel from the committed rocprofv3 summary — only if it was taken on THIS build of
     the kernels (same source hash); otherwise None (a stale profile is not evidence for the line being printed)."""
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "c3_summary.json")))
+        prof = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, name)))
     except Exception:
         return None
     if prof.get("kernel_source_hash") != kernel_source_hash():
@@ -446,7 +448,21 @@ def main():
     sh.load_patch("synth mySynth {\n\n}\n")       # example.synth2: empty body == default patch
     # N = 1: the pool-resident render kernel (s2r_set_resident: a fill is a posted command, the grid stays on the device and its
     # workgroups run ahead of each other across the two fills in flight).  S2R_BENCH_RESIDENT=0: a launch per fill (A/B).
-    resident = world == 1 and os.environ.get("S2R_BENCH_RESIDENT", "1") != "0"
+    # N > 1 (one process per GPU): the partial rows are exchanged INSIDE the render kernels through a block of rank 0's device
+    # memory (s2r_exchange_create / _attach: no collective, no torch call per step); S2R_BENCH_EXCHANGE=torch keeps the
+    # all-gather of round 3.  The handle travels once, at start-up, over torch.distributed.
+    use_xg = world > 1 and not dev_list and os.environ.get("S2R_BENCH_EXCHANGE", "ipc") == "ipc"
+    if use_xg:
+        objs = [synth.exchange_create(world) if rank == 0 else None]
+        dist.broadcast_object_list(objs, src=0)
+        if rank != 0:
+            synth.exchange_attach(rank, world, objs[0])
+        dist.barrier()
+    host_api = world == 1 or use_xg               # the step is s2r_note_events + s2r_fill_begin / s2r_fill_end
+    # The pool-resident render kernel (s2r_set_resident: a fill is a posted command, no launch).  On by default where the host's
+    # share of a step decides (N > 1: every rank resolves the whole pool's events); at N = 1 the launches' two-stream form is
+    # as fast on the GPU side and is what is timed (S2R_BENCH_RESIDENT=1 / 0 force either: tools/ab_modes.sh).
+    resident = host_api and os.environ.get("S2R_BENCH_RESIDENT", "1" if world > 1 else "0") != "0"
     if resident:
         synth.set_resident(True)
     if os.environ.get("S2R_COEFF_STREAM_MODE"):       # measurement aid (see s2r_set_coeff_stream); results are bit-identical
@@ -486,7 +502,7 @@ def main():
     host_t = [0.0, 0.0, 0.0]                      # seconds inside s2r_note_events / s2r_fill_begin / s2r_fill_end (N = 1)
 
     def step(k):
-        if world == 1:
+        if host_api:
             ta = time.perf_counter()
             sh.note_events(events_of(k))
             tb = time.perf_counter()
@@ -536,7 +552,7 @@ def main():
     t_loop = time.perf_counter() - t0
     fence()
     dt = time.perf_counter() - t0
-    host_split = {"note_events_us": 1e6 * host_t[0] / args.steps, "fill_begin_us": 1e6 * host_t[1] / args.steps,
+    host_split = None if not host_api else {"note_events_us": 1e6 * host_t[0] / args.steps, "fill_begin_us": 1e6 * host_t[1] / args.steps,
                   "fill_end_us": 1e6 * host_t[2] / args.steps, "final_fence_us": 1e6 * (dt - t_loop),
                   "note": "host time per timed step inside the three calls (fill_end includes the wait for the GPU), and the fence behind the last step"}
     k0 += args.steps
@@ -545,7 +561,7 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
-    mix_host = (out_host.copy() if world == 1 else pinned.numpy().copy()) if rank == 0 else None
+    mix_host = (out_host.copy() if host_api else pinned.numpy().copy()) if rank == 0 else None
 
     # ---- the same steps through the synchronous host API (N = 1): s2r_fill returns each buffer in host memory ----
     host_api_sync = None
@@ -669,11 +685,12 @@ def main():
                                     "before the warm-up" % (vpg, PERIOD, PERIOD, n_events_per_step)) if args.workload == "c3" else
                                    ("churn: %d voices per GPU, default patch, 48 kHz, 1024-frame buffers, all on at frame 0, then %d note-off + %d "
                                     "note-on per buffer per 64k voices" % (vpg, args.churn, args.churn)),
-                       "timed_call": "s2r_note_events + s2r_fill_begin / s2r_fill_end: the host-buffer API with two buffers in flight (s2_bin's own arrangement); voice state resident in HBM, events H2D and every mix's D2H into the caller's buffer inside the timed region" + ("; render grid resident on the device (s2r_set_resident): a fill is a posted command, no launch" if resident else "; a launch per fill") if world == 1 else
+                       "timed_call": ("s2r_note_events + s2r_fill_begin / s2r_fill_end: the host-buffer API with two buffers in flight (s2_bin's own arrangement); voice state resident in HBM, events H2D and every mix's D2H into the caller's buffer inside the timed region" + ("; render grid resident on the device (s2r_set_resident): a fill is a posted command, no launch" if resident else "; a launch per fill") +
+                                      ("; every rank the same calls on its shard, the partial rows exchanged inside the render kernels through rank 0's device memory (s2r_exchange_create / _attach) and added there in rank order" if use_xg else "")) if host_api else
                                      "s2r_note_events + s2r_fill_device per rank, all-gather, rank-ordered sum, async D2H of the mix on rank 0",
                        "voices_total": total, "frames": FRAMES, "sample_rate": SR,
                        "parallelism": ("one process, one handle over the device list %s: policy run once, every shard on its own device's stream, rows added in shard order on the first device" % dev_list) if dev_list else
-                                      "voice-shard x%d, %s of partial mixes" % (world, "reduce(sum) to rank 0" if args.reduce else "all-gather + rank-ordered sum"),
+                                      "voice-shard x%d, %s of partial mixes" % (world, "in-kernel exchange: rows into rank 0's device memory, rank-ordered sum by its last workgroup" if use_xg else "reduce(sum) to rank 0" if args.reduce else "all-gather + rank-ordered sum"),
                        "block_voices": block_voices},
             "msamples_per_s": value / 1e6,
             "realtime_factor_64k_voices": value / (65536.0 * SR),
@@ -699,13 +716,18 @@ def main():
                         "`frac`: the whole pool re-triggered and held, every voice inside its mod decay, no note events; "
                         "`frac_c3_launches`: the C3 launches in the same mode"})(
                 valu_tf, (FLOPS_PER_VOICE_SAMPLE * vpg * FRAMES / (kernel_ms_full_plain * 1e-3) / 1e12) if kernel_ms_full_plain else None),
-            "host_time_per_step": host_split if world == 1 else None,
+            "host_time_per_step": host_split,
                "value_host_api_sync": host_api_sync,
             "value_host_api_sync_note": "the same steps through s2r_fill, which returns every buffer in the caller's host memory before the next events are handed over (host event processing and GPU time add up instead of overlapping)",
             "value_kernel_only": vpg * FRAMES / kernel_s,
             "value_all_voices_modulating": all_mod,
             "value_all_voices_modulating_note": "every voice re-triggered, then 8 buffers inside the 9 600-frame mod decay; device-resident fills queued back to back, product path (tables on)",
             "mix_checksum": float(np.abs(mix_host).sum()),
+            # the library that was timed says which sources it was built from (s2r_build_id; synth2_amd.load_library refuses one that
+            # does not match the sources on disk): its first half is the hash the committed profiles are keyed by
+            "build_id": s2.load_library().s2r_build_id().decode(),
+            "kernel_source_hash": kernel_source_hash(),
+            "mix_note": "the mix follows the build's documented tree (DESIGN.md 4.3), bit-equal to the oracle's same tree; the reference's sequential order is 46 / 2 887 / 7 278 ULP away at 1 024 / 65 536 / 131 072 voices (profiles/r03/mix_deviation.json)",
         }
         if config_legs is not None:
             out["config_legs"] = config_legs

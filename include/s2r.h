@@ -30,7 +30,8 @@ extern "C" {
 #endif
 
 /* Changes when a struct layout or an existing signature changes.  Entry points added since 4.0 without touching either:
- * s2r_set_low_latency, s2r_low_latency_active, s2r_build_id, s2r_set_resident, s2r_resident_active, s2r_quiesce. */
+ * s2r_set_low_latency, s2r_low_latency_active, s2r_build_id, s2r_set_resident, s2r_resident_active, s2r_quiesce,
+ * s2r_exchange_create, s2r_exchange_attach, s2r_voice_pool_set_threads, s2r_voice_pool_resolve. */
 #define S2R_ABI_VERSION 4
 
 typedef enum {
@@ -287,6 +288,17 @@ int s2r_low_latency_active(const s2r_synth *s);
  * s2r_resident_active: 1 while a resident kernel of either kind is believed to be on the device.
  * s2r_quiesce: stops any resident kernel of the handle and waits for it — what a caller does before it synchronises the
  * whole device (hipDeviceSynchronize would otherwise wait out the kernel's patience). */
+/* One process per GPU WITHOUT a collective library in the step (SURVEY 8e's preferred shape): the ranks' partial rows are
+ * written into one block of the root's device memory — mapped by the other ranks through an IPC handle; a peer-to-peer store
+ * over xGMI where the ranks' devices differ — and added in rank order from +0.0 (synth.rs:176,195) by the root's last
+ * workgroup, all inside the render kernels.  Rank 0 calls s2r_exchange_create on its shard's handle and hands the 64 handle
+ * bytes to the other ranks by whatever channel the caller has (once, at start-up); they call s2r_exchange_attach.  From
+ * then on every rank drives its handle with the SAME events and the same s2r_fill / s2r_fill_begin / s2r_fill_end calls;
+ * the root's buffers receive the mix, the other ranks' buffers silence.  Bit for bit what one device returns with
+ * mix_groups = n_ranks (contiguous shards).  Shards of more than one workgroup with a single one-pole patch. */
+#define S2R_EXCHANGE_HANDLE_BYTES 64
+int s2r_exchange_create(s2r_synth *s, uint32_t n_ranks, void *handle_out, size_t handle_bytes);
+int s2r_exchange_attach(s2r_synth *s, uint32_t rank, uint32_t n_ranks, const void *handle, size_t handle_bytes);
 int s2r_set_resident(s2r_synth *s, int enabled);
 int s2r_resident_active(const s2r_synth *s);
 int s2r_quiesce(s2r_synth *s);

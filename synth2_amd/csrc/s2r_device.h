@@ -116,7 +116,8 @@ struct S2rMixTail {
     // exchange of partial rows between shards (device list, one process per GPU): nullptr = none
     uint32_t *rows_done;          // counter in the root's memory (system scope)
     uint32_t rows_target;         // value it has when every shard has counted in for this fill
-    int32_t reserved;
+    int32_t xmode;                // 0: the shard that counts in last adds the rows; 1: this shard is the ROOT of a group of
+                                  // processes: it waits for every rank and adds the rows; 2: a rank other than the root
     uint32_t n_rows, row_stride;
     const float *rows;            // [n_rows][row_stride], the root's
     float *final_out;

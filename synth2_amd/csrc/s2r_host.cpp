@@ -211,6 +211,13 @@ struct s2r_synth {
     // exchange of partial rows between the shards of a device list: a counter per rows slot in the parent's device memory
     uint32_t *rows_done = nullptr;
     uint32_t rows_target[2] = {0, 0};
+    // exchange between PROCESSES (one process per GPU; s2r_exchange_create / _attach): the ranks' rows and the counters live in
+    // one block of the root's device memory that the other ranks map through an IPC handle
+    bool xg_on = false;
+    uint32_t xg_rank = 0, xg_n = 0, xg_target[2] = {0, 0};
+    float *xg_rows = nullptr;                    // [2][xg_n][max_frames]
+    uint32_t *xg_done = nullptr;                 // [2], behind the rows
+    void *xg_block = nullptr; bool xg_owner = false;
     bool force_stage = false, force_peer = false;   // S2R_FORCE_STAGE / S2R_FORCE_PEER: the multi-device branches on one device (tests)
     // The pool-resident render kernel (S2rPool, s2r_device.h; s2r_set_resident): running on `stream` between fills while
     // pool_running; stopped by every entry point that touches the device or what the kernel's arguments were built from
@@ -249,6 +256,11 @@ struct s2r_synth {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool timing = false, timed = false, no_flat_shortcut = false;
     uint64_t double_release = 0;
+    // A kernel that gave up a bounded wait for another kernel's (or workgroup's) work left the fill unrendered — it touches
+    // neither the voices' state nor the chain heads then — while the host's pool clock and event bookkeeping had moved on:
+    // the handle says so from then on instead of rendering something else than what its caller believes (import a checkpoint
+    // into a new handle to go on).
+    bool broken = false;
     std::string err = "";
 };
 
@@ -433,6 +445,14 @@ int flush_events(s2r_synth *s, hipStream_t stream, EventSlot **timed_slot, const
             // the kernel) on stream_b, beside whatever render kernel is running
             uint32_t *hc = &s->ov_words->heads_done[ov_parity];
             s->ov_heads_target[ov_parity] += (nt + 255u) / 256u;
+            // (test hook: S2R_DEBUG_WITHHOLD_HEADS=k leaves out the k-th such launch — a producer that never runs; the render
+            // kernel's bounded wait, the fill's error and the handle's refusal afterwards are what tests/test_gpu_parity.py holds)
+            static const long withhold = [] { const char *e = std::getenv("S2R_DEBUG_WITHHOLD_HEADS"); return e ? std::atol(e) : 0L; }();
+            static long n_heads_launches = 0;
+            const bool skip_heads = withhold > 0 && ++n_heads_launches == withhold;
+            if (skip_heads) {
+                if (s->dmix.active && s->dmix.overlap) { int rc = launch_deferred_mix(s, s->stream); if (rc != S2R_OK) return rc; }
+            } else
             if (s->dmix.active && s->dmix.overlap) {
                 s->dmix.active = false;
                 S2rMixParams m = s->dmix.m;
@@ -463,8 +483,11 @@ int flush_events(s2r_synth *s, hipStream_t stream, EventSlot **timed_slot, const
     return S2R_OK;
 }
 
+#define S2R_REFUSE_BROKEN(s) do { if ((s)->broken) return set_err((s), S2R_ERR_HIP, "an earlier fill failed on the device (a bounded wait between kernels ran out): the device's voices no longer match the host's bookkeeping; destroy the handle"); } while (0)
+
 int check_fill(s2r_synth *s, size_t frames, uint32_t sample_rate) {
     if (!s) return S2R_ERR_INVALID;
+    S2R_REFUSE_BROKEN(s);
     if (frames > s->cfg.max_frames) return set_err(s, S2R_ERR_TOO_MANY_FRAMES, "frames %zu > max_frames %u", frames, s->cfg.max_frames);
     if (sample_rate == 0) return set_err(s, S2R_ERR_INVALID, "sample_rate_hz must be > 0");
     // process.rs:36,71: offset.checked_add(..).expect("overflow") — the reference panics once a
@@ -591,6 +614,7 @@ struct Exchange {
     S2rDone final_done{nullptr, 0u, nullptr};
     bool final_stereo = false;
     volatile uint32_t *slot_word = nullptr;   // the completion word (host view) that says the fill's records are no longer read
+    int xmode = 0;                            // S2rMixTail.xmode
 };
 
 bool onepole_single_patch(const s2r_synth *s) {
@@ -751,7 +775,8 @@ int enqueue_fused(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t
     mt.out = dev_out;
     mt.done = done ? *done : S2rDone{nullptr, 0u, s->done_counter + 3};
     if (xc) {
-        mt.done.flag = nullptr;
+        if (xc->xmode != 2) mt.done.flag = nullptr;               // (a rank other than the root reports its own completion)
+        mt.xmode = xc->xmode;
         mt.rows_done = xc->rows_done; mt.rows_target = xc->rows_target;
         mt.n_rows = xc->n_rows; mt.row_stride = xc->row_stride; mt.rows = xc->rows;
         mt.final_out = xc->final_out; mt.final_done = xc->final_done; mt.final_stereo = xc->final_stereo ? 1 : 0;
@@ -826,6 +851,15 @@ int pool_setup(s2r_synth *s) {
     return S2R_OK;
 }
 
+// Device memory that kernels on OTHER devices (or in other processes) write and this device's kernels read while they run —
+// the shards' rows and the counters of an exchange: fine-grained, so that no L2 holds a line of it across a peer's store (a
+// coarse-grained allocation is only coherent at kernel boundaries); plain device memory where the runtime has none to give.
+hipError_t malloc_exchange(void **p, size_t bytes) {
+    if (hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained) == hipSuccess && *p) return hipSuccess;
+    (void)hipGetLastError();
+    return hipMalloc(p, bytes);
+}
+
 // payload first, then word 15, then word 0 (device memory behind the BAR is write-combining: the fences order the stages)
 uint32_t pool_post(s2r_synth *s, const uint32_t *w) {
     const uint32_t seq = ++s->pool_seq;
@@ -885,6 +919,14 @@ int pool_launch(s2r_synth *s, uint32_t sample_rate, uint32_t first_seq) {
         for (int b = 0; b < 2; b++) { pl.rows[b] = par->rows_dev[b]; pl.rows_mine[b] = par->rows_dev[b] + (size_t)k * par->cfg.max_frames; }
         pl.final_out[0] = par->ring_dev[0]; pl.final_out[1] = par->ring_dev[1]; pl.final_out[2] = par->out_host_dev;
         pl.final_flag = par->done_dev; pl.final_counter = nullptr;
+    }
+    if (s->xg_on) {                                               // a rank of a group of processes
+        pl.mt = mix_tail_of(s, false);
+        pl.mt.xmode = s->xg_rank == 0 ? 1 : 2;
+        pl.mt.rows_done = s->xg_done; pl.mt.n_rows = s->xg_n; pl.mt.row_stride = s->cfg.max_frames;
+        for (int b = 0; b < 2; b++) { pl.rows[b] = s->xg_rows + (size_t)b * s->xg_n * s->cfg.max_frames; pl.rows_mine[b] = pl.rows[b] + (size_t)s->xg_rank * s->cfg.max_frames; }
+        pl.final_out[0] = s->ring_dev[0]; pl.final_out[1] = s->ring_dev[1]; pl.final_out[2] = s->out_host_dev;
+        pl.final_flag = s->done_dev; pl.final_counter = nullptr;
     }
     S2R_HIP(s, hipMemsetD32Async((hipDeviceptr_t)s->pool_decided, (int)((first_seq - 1u) << 1), 1, s->stream));
     S2R_HIP(s, s2r_launch_pool(a, pl, s->block_voices, s->stream));
@@ -1228,6 +1270,7 @@ int overlap_check(s2r_synth *s) {
     s->done_host[3] = 0u;
     for (s2r_synth *kid : s->kids) { const uint32_t w = *(volatile uint32_t *)(kid->done_host + 3); kid->done_host[3] = 0u; if (w) who = w; }
     if (who == 0u) return S2R_OK;
+    s->broken = true;
     return set_err(s, S2R_ERR_HIP, "%s gave up waiting for another kernel's or workgroup's work: the fill's output is not valid",
                    who == 1u ? "a render kernel (for its chain heads)" : who == 2u ? "a mix (for its partial rows)" : "the sum of the shards' rows (for a shard's row)");
 }
@@ -1236,6 +1279,24 @@ int overlap_check(s2r_synth *s) {
 int enqueue_root(s2r_synth *s, size_t frames, uint32_t sample_rate, float *dev_out, bool stereo, int defer_ring_slot = -1,
                  const S2rDone *done = nullptr) {
     if (!s->kids.empty()) return enqueue_multi(s, frames, sample_rate, dev_out, stereo, nullptr, done, defer_ring_slot);
+    if (s->xg_on) {
+        // One process per GPU: this rank's partial row goes into the root's block and the rows are added by the root's last
+        // mixer, all inside the render kernels (S2rMixTail.xmode 1 / 2) — no collective, no call into another library per step.
+        if (!(done && done->flag) || !fused_shape_ok(s))
+            return set_err(s, S2R_ERR_INVALID, "a handle in a process group fills through s2r_fill / s2r_fill_begin with a single one-pole patch and more than one workgroup");
+        const uint32_t slot = defer_ring_slot >= 0 ? (uint32_t)defer_ring_slot : ((s->ring_head + s->ring_count) & 1u) ^ 1u;
+        Exchange xc;
+        s->xg_target[slot] += s->xg_n;
+        xc.xmode = s->xg_rank == 0 ? 1 : 2;
+        xc.rows_done = s->xg_done + slot; xc.rows_target = s->xg_target[slot];
+        xc.n_rows = s->xg_n; xc.row_stride = s->cfg.max_frames; xc.rows = s->xg_rows + (size_t)slot * s->xg_n * s->cfg.max_frames;
+        xc.final_out = dev_out; xc.final_done = *done; xc.final_stereo = stereo;
+        xc.slot_word = s->done_host + (done->flag - s->done_dev);
+        float *row = s->xg_rows + ((size_t)slot * s->xg_n + s->xg_rank) * s->cfg.max_frames;
+        if (pool_eligible(s, frames)) return pool_fill(s, frames, sample_rate, (uint32_t)(done->flag - s->done_dev), stereo, done->value, &xc, slot);
+        { int rc = pool_stop(s); if (rc != S2R_OK) return rc; }
+        return enqueue_fill(s, frames, sample_rate, s->stream, row, false, false, nullptr, -1, done, &xc);
+    }
     if (done && done->flag && pool_eligible(s, frames)) {
         // (S2R_POOL_FORM=fused: every fill in the one-launch form, the chain heads and the mix in the render kernel itself)
         static const bool fused_only = [] { const char *e = std::getenv("S2R_POOL_FORM"); return e && e[0] == 'f'; }();
@@ -1392,7 +1453,9 @@ int fill_host(s2r_synth *s, float *out, size_t frames, uint32_t sample_rate, boo
     const size_t n = frames * (stereo ? 2 : 1);
     rc = wait_done(s, 2, done.value);
     if (rc != S2R_OK) return rc;
-    std::memcpy(out, s->out_host, n * sizeof(float));
+    { int rc2 = overlap_check(s); if (rc2 != S2R_OK) return rc2; }
+    if (s->xg_on && s->xg_rank != 0) std::memset(out, 0, n * sizeof(float));        // (the mix is the root's)
+    else std::memcpy(out, s->out_host, n * sizeof(float));
     return S2R_OK;
 }
 
@@ -1414,6 +1477,7 @@ void release_all(s2r_synth *s) {
         if (sl.thost) (void)hipHostFree(sl.thost);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
+    if (s->xg_block) { if (s->xg_owner) (void)hipFree(s->xg_block); else (void)hipIpcCloseMemHandle(s->xg_block); }
     if (s->fz_arrive) (void)hipFree(s->fz_arrive);
     if (s->rows_done) (void)hipFree(s->rows_done);
     if (s->pool_cmd_vram && s->pool_cmd) (void)hipFree(s->pool_cmd);
@@ -1707,7 +1771,7 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
     CREATE_HIP(hipSetDevice(s->device));
     CREATE_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     for (int b = 0; b < 2; b++) {
-        CREATE_HIP(hipMalloc((void **)&s->rows_dev[b], (size_t)n * cfg->max_frames * sizeof(float)));
+        CREATE_HIP(malloc_exchange((void **)&s->rows_dev[b], (size_t)n * cfg->max_frames * sizeof(float)));
         CREATE_HIP(hipMemsetAsync(s->rows_dev[b], 0, (size_t)n * cfg->max_frames * sizeof(float), s->stream));
         s->kid_done[b].assign(n, nullptr);
     }
@@ -1724,7 +1788,7 @@ int s2r_create(const s2r_config *cfg, s2r_synth **out) {
     CREATE_HIP(hipHostGetDevicePointer((void **)&s->done_dev, s->done_host, 0));
     CREATE_HIP(hipMalloc((void **)&s->done_counter, 4 * sizeof(uint32_t)));
     CREATE_HIP(hipMemsetAsync(s->done_counter, 0, 4 * sizeof(uint32_t), s->stream));
-    CREATE_HIP(hipMalloc((void **)&s->rows_done, 2 * sizeof(uint32_t)));
+    CREATE_HIP(malloc_exchange((void **)&s->rows_done, 2 * sizeof(uint32_t)));
     CREATE_HIP(hipMemsetAsync(s->rows_done, 0, 2 * sizeof(uint32_t), s->stream));
     CREATE_HIP(hipStreamSynchronize(s->stream));
     // A shard on another device writes its row straight into the parent's buffer when the devices are peers (one
@@ -1851,6 +1915,7 @@ int s2r_note_off(s2r_synth *s, uint8_t note) {
 
 int s2r_note_events(s2r_synth *s, const s2r_note_event *events, size_t n) {
     if (!s || (!events && n)) return S2R_ERR_INVALID;
+    S2R_REFUSE_BROKEN(s);
     // The whole batch is checked before the first event touches the pool, the pool clock or the pending lists: a
     // rejected batch leaves the handle exactly as it was (the reference's note_on / note_off cannot fail at all,
     // synth.rs:61-80, so every error here is a malformed batch, not a state of the synth).
@@ -1957,13 +2022,21 @@ int s2r_fill_end(s2r_synth *s, float *mono_out, size_t capacity) {
         int rc = launch_deferred_mix(s, s->stream);
         if (rc != S2R_OK) return rc;
     }
-    if (s->ring_seq[slot]) { int rc = wait_done(s, slot, s->ring_seq[slot]); if (rc != S2R_OK) return rc; }
-    else S2R_HIP(s, hipEventSynchronize(s->ring_done[slot]));
-    { int rc = overlap_check(s); if (rc != S2R_OK) return rc; }
-    if (s->ring_frames[slot]) std::memcpy(mono_out, s->ring_host[slot], s->ring_frames[slot] * sizeof(float));
+    // A fill that failed on the device is reported ONCE, with its buffer zeroed, and leaves the ring like any other: the next
+    // s2r_fill_end is the next fill's (which, the handle being broken by then, reports that).
+    int rc_fill = S2R_OK;
+    if (s->ring_seq[slot]) rc_fill = wait_done(s, slot, s->ring_seq[slot]);
+    else if (hipEventSynchronize(s->ring_done[slot]) != hipSuccess) rc_fill = set_err(s, S2R_ERR_HIP, "hipEventSynchronize failed");
+    if (rc_fill == S2R_OK) rc_fill = overlap_check(s);
+    if (rc_fill == S2R_OK && s->broken)          // (begun before the failure was known: rendered from voices a fill behind the host's clock)
+        rc_fill = set_err(s, S2R_ERR_HIP, "an earlier fill failed on the device: this one was rendered from voices that no longer match the host's bookkeeping");
+    if (s->ring_frames[slot]) {
+        if (rc_fill != S2R_OK || (s->xg_on && s->xg_rank != 0)) std::memset(mono_out, 0, s->ring_frames[slot] * sizeof(float));    // (or: the mix is the root's)
+        else std::memcpy(mono_out, s->ring_host[slot], s->ring_frames[slot] * sizeof(float));
+    }
     s->ring_head ^= 1u;
     s->ring_count--;
-    return S2R_OK;
+    return rc_fill;
 }
 
 int s2r_fill_stereo(s2r_synth *s, float *interleaved_lr_out, size_t frames, uint32_t sample_rate_hz) {
@@ -2268,6 +2341,46 @@ int s2r_resident_active(const s2r_synth *s) {
     if (s->res_running || s->pool_running) return 1;
     for (const s2r_synth *kid : s->kids) if (kid->pool_running) return 1;
     return 0;
+}
+
+static size_t xg_block_bytes(const s2r_synth *s, uint32_t n_ranks) { return ((size_t)2 * n_ranks * s->cfg.max_frames) * sizeof(float) + 64; }
+
+static int xg_bind(s2r_synth *s, void *block, bool owner, uint32_t rank, uint32_t n_ranks) {
+    s->xg_block = block; s->xg_owner = owner; s->xg_rank = rank; s->xg_n = n_ranks;
+    s->xg_rows = (float *)block;
+    s->xg_done = (uint32_t *)((char *)block + (size_t)2 * n_ranks * s->cfg.max_frames * sizeof(float));
+    s->xg_target[0] = s->xg_target[1] = 0;
+    s->xg_on = true;
+    return S2R_OK;
+}
+
+int s2r_exchange_create(s2r_synth *s, uint32_t n_ranks, void *handle_out, size_t handle_bytes) {
+    if (!s || s->parent || !s->kids.empty() || n_ranks < 1 || n_ranks > 64 || !handle_out || handle_bytes < sizeof(hipIpcMemHandle_t)) return S2R_ERR_INVALID;
+    if (s->xg_on) return set_err(s, S2R_ERR_INVALID, "the handle is in a process group already");
+    if (!fused_shape_ok(s)) return set_err(s, S2R_ERR_INVALID, "a process group takes shards of more than one workgroup with a single one-pole patch");
+    S2R_QUIESCE(s);
+    S2R_HIP(s, hipSetDevice(s->device));
+    void *block = nullptr;
+    S2R_HIP(s, malloc_exchange(&block, xg_block_bytes(s, n_ranks)));
+    S2R_HIP(s, hipMemset(block, 0, xg_block_bytes(s, n_ranks)));
+    S2R_HIP(s, hipDeviceSynchronize());
+    hipIpcMemHandle_t h;
+    if (hipIpcGetMemHandle(&h, block) != hipSuccess) { (void)hipFree(block); return set_err(s, S2R_ERR_HIP, "hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment?)"); }
+    std::memcpy(handle_out, &h, sizeof h);
+    return xg_bind(s, block, true, 0u, n_ranks);
+}
+
+int s2r_exchange_attach(s2r_synth *s, uint32_t rank, uint32_t n_ranks, const void *handle, size_t handle_bytes) {
+    if (!s || s->parent || !s->kids.empty() || rank == 0 || rank >= n_ranks || n_ranks > 64 || !handle || handle_bytes < sizeof(hipIpcMemHandle_t)) return S2R_ERR_INVALID;
+    if (s->xg_on) return set_err(s, S2R_ERR_INVALID, "the handle is in a process group already");
+    if (!fused_shape_ok(s)) return set_err(s, S2R_ERR_INVALID, "a process group takes shards of more than one workgroup with a single one-pole patch");
+    S2R_QUIESCE(s);
+    S2R_HIP(s, hipSetDevice(s->device));
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle, sizeof h);
+    void *block = nullptr;
+    S2R_HIP(s, hipIpcOpenMemHandle(&block, h, hipIpcMemLazyEnablePeerAccess));
+    return xg_bind(s, block, false, rank, n_ranks);
 }
 
 int s2r_quiesce(s2r_synth *s) {

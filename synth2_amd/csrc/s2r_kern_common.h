@@ -1115,12 +1115,28 @@ __device__ __forceinline__ void fused_tail(const S2rRenderParams &p, const FillC
         if (threadIdx.x == 0 && mt.done.flag != nullptr) __hip_atomic_store(mt.done.flag, mt.done.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
-    // exchange: this shard's row is in the root's memory (system-scope stores, acknowledged); count in — and whoever counts in
-    // LAST, whichever shard that is, adds the rows in shard order.  Nobody waits for anybody: shards whose kernels share a
-    // hardware queue, or run one after the other, still finish.
+    // exchange: this shard's row is in the root's memory (system-scope stores, acknowledged); count in.
+    //   xmode 0 (the shards of ONE process's device list): whoever counts in LAST, whichever shard that is, adds the rows in
+    //     shard order.  Nobody waits for anybody: shards whose kernels share a hardware queue, or run one after the other, still
+    //     finish.
+    //   xmode 1 / 2 (one process per GPU; the output is host memory of the ROOT's process, which only the root's kernels
+    //     reach): a rank other than the root (2) counts in and reports its own completion; the root's last mixer (1) counts in,
+    //     WAITS for every rank — bounded; the ranks' kernels run on devices of their own — and adds the rows.
     if (threadIdx.x == 0) {
         const uint32_t before = __hip_atomic_fetch_add(mt.rows_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        *s_word = (before + 1u == mt.rows_target) ? 1u : 0u;
+        uint32_t mine = (before + 1u == mt.rows_target) ? 1u : 0u;
+        if (mt.xmode == 2) {
+            if (mt.done.flag != nullptr) __hip_atomic_store(mt.done.flag, mt.done.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            mine = 0u;
+        } else if (mt.xmode == 1) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            mine = 1u;
+            while ((int32_t)(__hip_atomic_load(mt.rows_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - mt.rows_target) < 0) {
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 5000000ull) { ov_raise(ctl.fail, 3u); break; }
+                __builtin_amdgcn_s_sleep(20);
+            }
+        }
+        *s_word = mine;
     }
     __syncthreads();
     if (*s_word == 0u) return;

@@ -174,6 +174,8 @@ def load_library():
         "s2r_set_resident": (C.c_int, [H, C.c_int]),
         "s2r_resident_active": (C.c_int, [H]),
         "s2r_quiesce": (C.c_int, [H]),
+        "s2r_exchange_create": (C.c_int, [H, C.c_uint32, C.c_void_p, C.c_size_t]),
+        "s2r_exchange_attach": (C.c_int, [H, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t]),
         "s2r_set_flat_shortcut": (C.c_int, [H, C.c_int]),
         "s2r_set_coeff_stream": (C.c_int, [H, C.c_int]),
         "s2r_last_render_ms": (C.c_float, [H]),
@@ -464,6 +466,16 @@ class Synth:
     def quiesce(self):
         """stop any resident kernel of the handle and wait for it (before a device-wide synchronize)"""
         self._check(self.L.s2r_quiesce(self.h))
+
+    def exchange_create(self, n_ranks):
+        """rank 0 of a group of processes (one per GPU): the rows' block; returns the 64 handle bytes for the other ranks"""
+        buf = C.create_string_buffer(64)
+        self._check(self.L.s2r_exchange_create(self.h, n_ranks, buf, 64))
+        return buf.raw
+
+    def exchange_attach(self, rank, n_ranks, handle):
+        buf = C.create_string_buffer(bytes(handle), 64)
+        self._check(self.L.s2r_exchange_attach(self.h, rank, n_ranks, buf, 64))
 
     def set_timing(self, enabled=True):
         self._check(self.L.s2r_set_timing(self.h, 1 if enabled else 0))

@@ -1,0 +1,40 @@
+"""One process per GPU without a collective in the step (s2r_exchange_create / _attach, s2r.h): two processes sharing this box's
+card, each rendering its contiguous half of the pool, the rows exchanged through the root's IPC-mapped block and added by the
+root's last workgroup — bit for bit what ONE device returns with mix_groups = 2."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import assert_bits_equal
+import synth2_amd as s2
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("resident", [0, 1])
+def test_two_processes_exchange_rows_through_the_roots_block(tmp_path, resident):
+    V, K, n = 16384, 12, 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_exchange_worker.py"), str(r), str(n), str(tmp_path), str(V), str(K), str(resident)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(n)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d: %s\n%s" % (r, so[-1000:], se[-3000:])
+    got = np.load(os.path.join(str(tmp_path), "out0.npy"))
+    other = np.load(os.path.join(str(tmp_path), "out1.npy"))
+    assert not other.any(), "a rank other than the root returns silence"
+    # the same events on ONE device with mix_groups = 2
+    one = s2.Synth(V, max_frames=1024, mix_groups=n)
+    rng = np.random.RandomState(2024)
+    for k in range(K):
+        m = 3000 if k == 0 else int(rng.randint(0, 700))
+        ev = np.zeros(m, dtype=s2.NOTE_EVENT_DTYPE)
+        ev["kind"] = rng.randint(0, 2, m); ev["note"] = rng.randint(36, 97, m); ev["velocity"] = 1.0
+        if k % 3:
+            ev["frame"] = np.sort(rng.randint(0, 64, m)) * 16
+        one.note_events(ev)
+        assert_bits_equal(got[k], one.sample(np.empty(1024, dtype=np.float32), 48000), "two processes vs one device with mix_groups = 2, buffer %d" % k)
