@@ -309,7 +309,7 @@ def run_config_leg(name, voices, patch_text, steps, warmup, oversampled=False, b
         if oversampled:
             synth.sample_oversampled(FRAMES, SR)
         else:
-            synth.sample(out, SR)
+            synth.sample_begin(FRAMES, SR); synth.sample_end(out)      # (the launch the timed steps make, one fill at a time)
         kms.append(synth.last_render_ms())
     synth.set_timing(False)
     kernel_ms = float(np.median(kms))
@@ -583,7 +583,12 @@ def main():
         synth.set_timing(True)
         for k in range(k0, k0 + n):
             sh.note_events(events_of(k))
-            sh.fill(FRAMES, SR)
+            if world == 1:
+                # the launch the timed steps make — s2r_fill_begin's render kernel on its own stream, the mix and the chain heads
+                # beside it — with HIP events around it on that stream (s2r_set_timing); one fill at a time here
+                synth.sample_begin(FRAMES, SR); synth.sample_end(out_host)
+            else:
+                sh.fill(FRAMES, SR)
             kms.append(synth.last_render_ms())
         synth.set_timing(False)
         fence()

@@ -457,9 +457,16 @@ int flush_events(s2r_synth *s, hipStream_t stream, EventSlot **timed_slot, const
                 s->dmix.active = false;
                 S2rMixParams m = s->dmix.m;
                 m.ov_heads_counter = hc;
-                S2R_HIP(s, s2r_launch_mix_and_heads(m, s->heads2[ov_parity], sl.tdev, s->tevcopy2[ov_parity], nt, s->stream_b));
+                // (a launch that fails counts nobody in: the target goes back, and the handle is done for — ADVICE r3)
+                if (s2r_launch_mix_and_heads(m, s->heads2[ov_parity], sl.tdev, s->tevcopy2[ov_parity], nt, s->stream_b) != hipSuccess) {
+                    s->ov_heads_target[ov_parity] -= (nt + 255u) / 256u; s->broken = true;
+                    return set_err(s, S2R_ERR_HIP, "the launch of the chain heads and the mix failed");
+                }
             } else {
-                S2R_HIP(s, s2r_launch_tev_heads(s->heads2[ov_parity], sl.tdev, s->tevcopy2[ov_parity], nt, s->stream_b, hc));
+                if (s2r_launch_tev_heads(s->heads2[ov_parity], sl.tdev, s->tevcopy2[ov_parity], nt, s->stream_b, hc) != hipSuccess) {
+                    s->ov_heads_target[ov_parity] -= (nt + 255u) / 256u; s->broken = true;
+                    return set_err(s, S2R_ERR_HIP, "the launch of the chain heads failed");
+                }
             }
             *timed_slot = &sl; *tev_dev = s->tevcopy2[ov_parity];
         } else if (s->dmix.active && stream == s->stream) {    // the previous fill's mix rides with this fill's chain heads
@@ -1101,7 +1108,7 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
         if (tev_dev) { p.ov_heads_counter = &s->ov_words->heads_done[ov_parity]; p.ov_heads_target = s->ov_heads_target[ov_parity]; }
         p.ov_render_counter = &s->ov_words->render_done[ov_parity];
         p.ov_fail = s->done_dev + 3;
-        s->ov_render_target[ov_parity] += s->n_blocks;
+        s->ov_render_target[ov_parity] += s->n_blocks;       // (taken back below if the render launch fails)
     }
     a.n_events = 0;
     if (arg_events) {
@@ -1124,7 +1131,10 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
         if (!s->pool_running) { int rc = pool_launch(s, sample_rate, seq); if (rc != S2R_OK) return rc; }
     } else {
     if (s->timing) S2R_HIP(s, hipEventRecord(s->t0, stream));      // brackets the render kernel alone
-    S2R_HIP(s, s2r_launch_render(a, s->block_voices, stream));
+    if (s2r_launch_render(a, s->block_voices, stream) != hipSuccess) {
+        if (overlap) { s->ov_render_target[ov_parity] -= s->n_blocks; s->broken = true; }
+        return set_err(s, S2R_ERR_HIP, "the render kernel's launch failed: %s", hipGetErrorString(hipGetLastError()));
+    }
     if (s->timing) { S2R_HIP(s, hipEventRecord(s->t1, stream)); s->timed = true; }
     }
     if (timed_slot) {                     // the render kernel was the last reader of the slot's records

@@ -24,11 +24,27 @@ def _rank_ordered(pv, n, interleave, block):
     return acc
 
 
+@pytest.fixture(params=["", "S2R_FORCE_PEER", "S2R_FORCE_STAGE"])
+def multi_device_branch(request):
+    """the two multi-device branches of s2r_create / enqueue_multi, reachable on a box with ONE device (read
+    at s2r_create): S2R_FORCE_PEER — a shard on the parent's own device goes through the peer set-up (hipDeviceCanAccessPeer,
+    hipDeviceEnablePeerAccess) and writes its row into the parent's rows with system-scope stores, counting in on the
+    parent's word; S2R_FORCE_STAGE — every shard renders into a row of its own that hipMemcpyPeerAsync moves, events order
+    the parent's stream, s2r_sum_rows_kernel adds the rows"""
+    import os
+    knob = request.param
+    if knob:
+        os.environ[knob] = "1"
+    yield knob
+    if knob:
+        del os.environ[knob]
+
+
 @pytest.mark.parametrize("n,interleave", [(2, 0), (2, 64), (4, 64), (3, 0)])
-def test_device_list_matches_the_oracle_and_mix_groups(n, interleave):
+def test_device_list_matches_the_oracle_and_mix_groups(n, interleave, multi_device_branch):
     """contiguous shards: bit-equal to ONE device with mix_groups = N (and to the oracle's tree with that many groups);
     dealt-out shards: bit-equal to the rank-ordered sum of the oracle's per-shard trees.  Untimed and timed events,
-    restarts, a ragged fill, the voice index every note_on reports."""
+    restarts, a ragged fill, the voice index every note_on reports.  Under each of the multi-device branches."""
     V = 256 * n * 2
     pr = Pair(V, max_frames=1024, devices=[0] * n, shard_interleave=interleave)
     ref = s2.Synth(V, max_frames=1024, mix_groups=n) if not interleave else None
@@ -69,7 +85,7 @@ def test_device_list_matches_the_oracle_and_mix_groups(n, interleave):
             assert_bits_equal(g, ref.sample(np.empty(frames, dtype=np.float32), SR), "vs one device with mix_groups=%d, buffer %d" % (n, b))
 
 
-def test_device_list_every_entry_point():
+def test_device_list_every_entry_point(multi_device_branch):
     """render_voices in pool order, fill_begin / fill_end with two buffers in flight, the stereo copy, the 4x-oversampled
     fill, a patch bank with program changes, noise seeds, export -> import into a single-device handle and back"""
     V, n = 1024, 2

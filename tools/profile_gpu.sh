@@ -11,6 +11,8 @@ export TMPDIR=/tmp
 cd /tmp
 ARGS="--steps 16 --warmup 4 --no-cpu-baseline --no-config-legs $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 /root/repo/bench.py $ARGS > $OUT/trace.log 2>&1 || echo "trace pass failed"
+# (the counter passes serialise kernels; the two-stream fills wait for each other across streams inside the kernels: one stream for these passes)
+export S2R_OVERLAP=0 S2R_FUSED=0
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/pmc1 -- python3 /root/repo/bench.py $ARGS > $OUT/pmc1.log 2>&1 || echo "pmc1 failed"
 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc2 -- python3 /root/repo/bench.py $ARGS > $OUT/pmc2.log 2>&1 || echo "pmc2 failed"
 rocprofv3 --pmc SQ_INSTS_VALU_FLOPS_FP32 SQ_INSTS_VALU_FLOPS_FP32_TRANS SQ_INSTS_VALU_FLOPS_FP64 SQ_INSTS_VALU_IOPS SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT32 --output-format csv -d $OUT/pmc3 -- python3 /root/repo/bench.py $ARGS > $OUT/pmc3.log 2>&1 || echo "pmc3 failed"

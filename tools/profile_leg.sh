@@ -11,7 +11,9 @@ rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 CMD="python3 /root/repo/tools/leg_prof.py $LEG 16 4"
+# (the counter passes serialise kernels: the two-stream fills wait for each other across streams in the kernels, so every pass but the trace runs on one stream)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1 || echo "trace pass failed"
+export S2R_OVERLAP=0 S2R_FUSED=0
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/pmc1 -- $CMD > $OUT/pmc1.log 2>&1 || echo "pmc1 failed"
 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc2 -- $CMD > $OUT/pmc2.log 2>&1 || echo "pmc2 failed"
 rocprofv3 --pmc SQ_INSTS_VALU_FLOPS_FP32 SQ_INSTS_VALU_FLOPS_FP32_TRANS SQ_INSTS_VALU_FLOPS_FP64 SQ_INSTS_VALU_IOPS SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT32 --output-format csv -d $OUT/pmc3 -- $CMD > $OUT/pmc3.log 2>&1 || echo "pmc3 failed"
