@@ -121,6 +121,12 @@ pub mod ffi {
                                hip_stream: *mut c_void) -> c_int;
         pub fn s2r_device_count(s: *const S2rSynth) -> u32;
         pub fn s2r_set_low_latency(s: *mut S2rSynth, enabled: c_int) -> c_int;
+        pub fn s2r_set_resident(s: *mut S2rSynth, enabled: c_int) -> c_int;
+        pub fn s2r_resident_active(s: *const S2rSynth) -> c_int;
+        pub fn s2r_quiesce(s: *mut S2rSynth) -> c_int;
+        pub fn s2r_exchange_create(s: *mut S2rSynth, n_ranks: u32, handle_out: *mut c_void, handle_bytes: usize) -> c_int;
+        pub fn s2r_exchange_attach(s: *mut S2rSynth, rank: u32, n_ranks: u32, handle: *const c_void, handle_bytes: usize) -> c_int;
+        pub fn s2r_build_id() -> *const c_char;
         pub fn s2r_last_error(s: *const S2rSynth) -> *const c_char;
         pub fn s2r_status_string(status: c_int) -> *const c_char;
     }
@@ -295,6 +301,37 @@ pub mod synth {
         /// launch.  Small pools only (one workgroup: at most 256 voices); same samples either way.
         pub fn set_low_latency(&mut self, enabled: bool) {
             self.check(unsafe { ffi::s2r_set_low_latency(self.handle, if enabled { 1 } else { 0 }) });
+        }
+
+        /// The throughput caller's form of the same idea (`s2r_set_resident`, include/s2r.h): the shard's whole render grid
+        /// stays on the device between fills — a fill is a posted command, not a launch — for `sample`, `sample_stereo` and
+        /// `sample_begin` / `sample_end`; every shard of a `with_devices` Synth gets one.  Same samples either way.
+        pub fn set_resident(&mut self, enabled: bool) {
+            self.check(unsafe { ffi::s2r_set_resident(self.handle, if enabled { 1 } else { 0 }) });
+        }
+
+        /// stops any resident kernel of this Synth and waits for it (before the caller synchronises the whole device)
+        pub fn quiesce(&mut self) {
+            self.check(unsafe { ffi::s2r_quiesce(self.handle) });
+        }
+
+        /// One process per GPU without a collective in the step: rank 0 creates the exchange (the ranks' partial rows meet in
+        /// a block of its device memory and its last workgroup adds them in rank order) and hands the 64 handle bytes to the
+        /// other ranks, which `exchange_attach`.  Every rank then drives its shard's Synth with the same events and the same
+        /// `sample` / `sample_begin` / `sample_end` calls; rank 0's buffers receive the mix.
+        pub fn exchange_create(&mut self, n_ranks: u32) -> [u8; 64] {
+            let mut h = [0u8; 64];
+            self.check(unsafe { ffi::s2r_exchange_create(self.handle, n_ranks, h.as_mut_ptr() as *mut _, h.len()) });
+            h
+        }
+
+        pub fn exchange_attach(&mut self, rank: u32, n_ranks: u32, handle: &[u8; 64]) {
+            self.check(unsafe { ffi::s2r_exchange_attach(self.handle, rank, n_ranks, handle.as_ptr() as *const _, handle.len()) });
+        }
+
+        /// which sources the loaded libs2r was built from (`s2r_build_id`)
+        pub fn build_id() -> String {
+            unsafe { CStr::from_ptr(ffi::s2r_build_id()) }.to_string_lossy().into_owned()
         }
 
         /// how many GPUs render this Synth
