@@ -295,7 +295,7 @@ int s2r_low_latency_active(const s2r_synth *s);
  * bytes to the other ranks by whatever channel the caller has (once, at start-up); they call s2r_exchange_attach.  From
  * then on every rank drives its handle with the SAME events and the same s2r_fill / s2r_fill_begin / s2r_fill_end calls;
  * the root's buffers receive the mix, the other ranks' buffers silence.  Bit for bit what one device returns with
- * mix_groups = n_ranks (contiguous shards).  Shards of more than one workgroup with a single one-pole patch. */
+ * mix_groups = n_ranks (contiguous shards).  Shards of more than one workgroup; any patch or patch bank. */
 #define S2R_EXCHANGE_HANDLE_BYTES 64
 int s2r_exchange_create(s2r_synth *s, uint32_t n_ranks, void *handle_out, size_t handle_bytes);
 int s2r_exchange_attach(s2r_synth *s, uint32_t rank, uint32_t n_ranks, const void *handle, size_t handle_bytes);

@@ -609,6 +609,60 @@ S2rRenderParams make_params(s2r_synth *s, size_t frames, uint32_t sample_rate) {
     return p;
 }
 
+// The kernel that renders patch banks also renders single patches with a DPW oscillator: it reads its patch from the device copy
+// of the bank.  Resolves every patch for this sample rate (Ms::as_samples, units.rs:44-53), builds the bank's coefficient tables
+// and replaces the device copy when the bank or the rate changed; rare (bank edits, rate changes), so a synchronous hand-over.
+int ensure_bank(s2r_synth *s, uint32_t sample_rate, hipStream_t stream, bool *bank_kernel_out) {
+    bool bank_kernel = s->bank.size() > 1;
+    for (const s2r_patch &pt : s->bank) if (pt.osc_kind > S2R_OSC_SINE) bank_kernel = true;
+    if (bank_kernel && (s->bank_dirty || s->bank_rate != sample_rate)) {
+        // resolve every patch for this sample rate (Ms::as_samples, units.rs:44-53) and replace the
+        // device copy; rare (bank edits, rate changes), so a synchronous hand-over is fine
+        std::vector<S2rBankEntry> host(s->bank.size());
+        std::vector<S2rTabBuild> builds(s->bank.size());
+        size_t tab_floats = 0;
+        const float srf = (float)sample_rate;
+        for (size_t k = 0; k < s->bank.size(); k++) {
+            const s2r_patch &pt = s->bank[k];
+            S2rBankEntry &e = host[k];
+            std::memset(&e, 0, sizeof e);
+            e.osc_kind = pt.osc_kind; e.osc_gain = pt.osc_gain; e.noise_level = pt.noise; e.lpf_freq = pt.lpf_freq;
+            e.amt_osc = pt.mod_env_to_osc_freq; e.amt_lpf = pt.mod_env_to_lpf_freq; e.lpf_kind = pt.lpf_kind;
+            e.lpf_shape = pt.lpf_kind >= S2R_FILT_BP2 ? pt.lpf_q : pt.lpf_damping;
+            e.amp = resolve_env(pt.amp_env, sample_rate);
+            e.mod = resolve_env(pt.mod_env, sample_rate);
+            // this patch's coefficient tables (DESIGN.md 4.4), four planes in the bank's table buffer
+            S2rTabBuild &b = builds[k];
+            b = S2rTabBuild{};
+            // (the whole bank's tables stay under 2^28 floats = 1 GiB, so tab_off cannot wrap its 32 bits: a patch that
+            // would pass the budget computes in-lane, tab_valid = 0)
+            if (s->use_tab && !s->no_flat_shortcut && plan_tables(e.mod, b) && tab_floats + (size_t)b.plane * 4u <= ((size_t)1 << 28)) {
+                b.lpf_freq = e.lpf_freq; b.amt_lpf = e.amt_lpf; b.amt_osc = e.amt_osc; b.sr = srf; b.rcp_sr = 1.0f / srf;
+                b.fast_div_sr = 0;                   // (the per-lane-patch kernel divides by the sample rate with a true division)
+                b.lpf_kind = e.lpf_kind; b.lpf_damping = e.lpf_shape; b.fm_plane = 3u;
+                e.tab_valid = 1u; e.tab_off = (uint32_t)tab_floats; e.tab_plane = b.plane;
+                e.tab_ad = 0; e.tab_rc = (int32_t)b.n_ad; e.tab_rc_t0 = b.rc_t0; e.tab_ru = (int32_t)(b.n_ad + b.n_rel);
+                e.tab_sus = (int32_t)(b.n_ad + 2u * b.n_rel); e.tab_end = e.tab_sus + 16; e.tab_dead = e.tab_sus + 32;
+                tab_floats += (size_t)b.plane * 4u;
+            }
+        }
+        if (tab_floats > s->bank_tab_cap) {
+            S2R_HIP(s, hipStreamSynchronize(stream));
+            S2R_HIP(s, hipStreamSynchronize(s->stream));
+            if (s->bank_tab_dev) { S2R_HIP(s, hipFree(s->bank_tab_dev)); s->bank_tab_dev = nullptr; s->bank_tab_cap = 0; }
+            S2R_HIP(s, hipMalloc((void **)&s->bank_tab_dev, tab_floats * sizeof(float)));
+            s->bank_tab_cap = tab_floats;
+        }
+        for (size_t k = 0; k < s->bank.size(); k++)
+            if (host[k].tab_valid) { builds[k].base = s->bank_tab_dev + host[k].tab_off; S2R_HIP(s, s2r_launch_tables(builds[k], stream)); }
+        S2R_HIP(s, hipMemcpyAsync(s->bank_dev, host.data(), host.size() * sizeof(S2rBankEntry), hipMemcpyHostToDevice, stream));
+        S2R_HIP(s, hipStreamSynchronize(stream));
+        s->bank_dirty = false; s->bank_rate = sample_rate;
+    }
+    *bank_kernel_out = bank_kernel;
+    return S2R_OK;
+}
+
 // ---- one launch per fill (S2rMixTail, s2r_device.h) and the pool-resident kernel (S2rPool) ----
 
 // what a shard's last mixer does with its row when the fill's output is the sum of several shards' rows (a device list)
@@ -728,11 +782,11 @@ S2rMixTail mix_tail_of(const s2r_synth *s, bool root_add) {
     return mt;
 }
 
-// Can this shard's fills take the one-launch form?  The one-pole kernel (the general kernel keeps the three-launch form for
-// now), more than one workgroup (a single one writes the output itself), the bounds in the kernel arguments, the mix's run
-// sums in the staging the render kernel has anyway.
+// Can this shard's fills take the one-launch form?  More than one workgroup (a single one writes the output itself), the bounds
+// in the kernel arguments, the mix's run sums in the staging the render kernel has anyway (both render kernels take the form).
 bool fused_shape_ok(const s2r_synth *s) {
-    if (!s->fused_mode || !onepole_single_patch(s) || s->n_blocks < 2u) return false;
+    if (!s->fused_mode || s->n_blocks < 2u) return false;
+    if (!onepole_single_patch(s) && s->block_voices > 256u) return false;   // (the general kernel's staging for bigger workgroups is the smallest)
     if ((size_t)s->n_blocks + 1u > 3u * S2R_ARG_MAX_EVENTS) return false;
     const uint32_t groups = s->mix_groups ? s->mix_groups : 1u;
     const uint32_t runs = ((s->n_blocks + groups - 1u) / groups + 15u) / 16u * groups;
@@ -752,9 +806,12 @@ int enqueue_fused(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t
     if (!arg_events) { int rc = fused_events(s, stream, &slot, &nt); if (rc != S2R_OK) return rc; }
     static thread_local S2rRenderArgs a;
     S2rRenderParams &p = a.p;
+    bool bank_kernel = false;
+    { int rc = ensure_bank(s, sample_rate, stream, &bank_kernel); if (rc != S2R_OK) return rc; }
     p = make_params(s, frames, sample_rate);
     { int rc = ensure_tables(s, p, sample_rate, stream); if (rc != S2R_OK) return rc; }
     if (tables_wanted(s)) p.tab = s->tab;
+    else if (bank_kernel) { p.tab = S2rTabRef{}; p.tab.base = s->bank_tab_dev; }      // the per-lane-patch kernel adds each entry's tab_off
     p.stamps = s->stamps_dev;
     if (s->timeline_dev && s->timeline_n < s->timeline_cap) { p.timeline = s->timeline_dev; p.tl_slot = s->timeline_n++; }
     p.voice_ev_head = s->voice_ev_head;
@@ -810,7 +867,7 @@ bool pool_exited(const s2r_synth *s) { return __atomic_load_n(&s->pool_host[0], 
 // a fill the pool-resident kernel can take: the one-launch form's shape, a grid that is resident as a whole (at most one
 // workgroup of at most 256 threads per compute unit), nothing that brackets or watches single launches
 bool pool_eligible(const s2r_synth *s, size_t frames) {
-    return s->resident && s->kids.empty() && s->pool_cmd != nullptr && fused_shape_ok(s) && (int)s->n_blocks <= s->n_cu && s->block_voices <= 256u &&
+    return s->resident && s->kids.empty() && s->pool_cmd != nullptr && fused_shape_ok(s) && onepole_single_patch(s) && (int)s->n_blocks <= s->n_cu && s->block_voices <= 256u &&
            !s->timing && s->timeline_dev == nullptr && frames <= 0xffffu && frames <= s->cfg.max_frames;
 }
 
@@ -1040,54 +1097,8 @@ int enqueue_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, hipStream_t 
         int rc = launch_deferred_mix(s, stream);
         if (rc != S2R_OK) return rc;
     }
-    // (the kernel that renders patch banks also renders single patches with a DPW oscillator: it reads its patch from the
-    // device copy of the bank)
-    bool bank_kernel = s->bank.size() > 1;
-    for (const s2r_patch &pt : s->bank) if (pt.osc_kind > S2R_OSC_SINE) bank_kernel = true;
-    if (bank_kernel && (s->bank_dirty || s->bank_rate != sample_rate)) {
-        // resolve every patch for this sample rate (Ms::as_samples, units.rs:44-53) and replace the
-        // device copy; rare (bank edits, rate changes), so a synchronous hand-over is fine
-        std::vector<S2rBankEntry> host(s->bank.size());
-        std::vector<S2rTabBuild> builds(s->bank.size());
-        size_t tab_floats = 0;
-        const float srf = (float)sample_rate;
-        for (size_t k = 0; k < s->bank.size(); k++) {
-            const s2r_patch &pt = s->bank[k];
-            S2rBankEntry &e = host[k];
-            std::memset(&e, 0, sizeof e);
-            e.osc_kind = pt.osc_kind; e.osc_gain = pt.osc_gain; e.noise_level = pt.noise; e.lpf_freq = pt.lpf_freq;
-            e.amt_osc = pt.mod_env_to_osc_freq; e.amt_lpf = pt.mod_env_to_lpf_freq; e.lpf_kind = pt.lpf_kind;
-            e.lpf_shape = pt.lpf_kind >= S2R_FILT_BP2 ? pt.lpf_q : pt.lpf_damping;
-            e.amp = resolve_env(pt.amp_env, sample_rate);
-            e.mod = resolve_env(pt.mod_env, sample_rate);
-            // this patch's coefficient tables (DESIGN.md 4.4), four planes in the bank's table buffer
-            S2rTabBuild &b = builds[k];
-            b = S2rTabBuild{};
-            // (the whole bank's tables stay under 2^28 floats = 1 GiB, so tab_off cannot wrap its 32 bits: a patch that
-            // would pass the budget computes in-lane, tab_valid = 0)
-            if (s->use_tab && !s->no_flat_shortcut && plan_tables(e.mod, b) && tab_floats + (size_t)b.plane * 4u <= ((size_t)1 << 28)) {
-                b.lpf_freq = e.lpf_freq; b.amt_lpf = e.amt_lpf; b.amt_osc = e.amt_osc; b.sr = srf; b.rcp_sr = 1.0f / srf;
-                b.fast_div_sr = 0;                   // (the per-lane-patch kernel divides by the sample rate with a true division)
-                b.lpf_kind = e.lpf_kind; b.lpf_damping = e.lpf_shape; b.fm_plane = 3u;
-                e.tab_valid = 1u; e.tab_off = (uint32_t)tab_floats; e.tab_plane = b.plane;
-                e.tab_ad = 0; e.tab_rc = (int32_t)b.n_ad; e.tab_rc_t0 = b.rc_t0; e.tab_ru = (int32_t)(b.n_ad + b.n_rel);
-                e.tab_sus = (int32_t)(b.n_ad + 2u * b.n_rel); e.tab_end = e.tab_sus + 16; e.tab_dead = e.tab_sus + 32;
-                tab_floats += (size_t)b.plane * 4u;
-            }
-        }
-        if (tab_floats > s->bank_tab_cap) {
-            S2R_HIP(s, hipStreamSynchronize(stream));
-            S2R_HIP(s, hipStreamSynchronize(s->stream));
-            if (s->bank_tab_dev) { S2R_HIP(s, hipFree(s->bank_tab_dev)); s->bank_tab_dev = nullptr; s->bank_tab_cap = 0; }
-            S2R_HIP(s, hipMalloc((void **)&s->bank_tab_dev, tab_floats * sizeof(float)));
-            s->bank_tab_cap = tab_floats;
-        }
-        for (size_t k = 0; k < s->bank.size(); k++)
-            if (host[k].tab_valid) { builds[k].base = s->bank_tab_dev + host[k].tab_off; S2R_HIP(s, s2r_launch_tables(builds[k], stream)); }
-        S2R_HIP(s, hipMemcpyAsync(s->bank_dev, host.data(), host.size() * sizeof(S2rBankEntry), hipMemcpyHostToDevice, stream));
-        S2R_HIP(s, hipStreamSynchronize(stream));
-        s->bank_dirty = false; s->bank_rate = sample_rate;
-    }
+    bool bank_kernel = false;
+    { int rc = ensure_bank(s, sample_rate, stream, &bank_kernel); if (rc != S2R_OK) return rc; }
     static thread_local S2rRenderArgs a;             // 4 KiB of kernel arguments, copied by the launch
     S2rRenderParams &p = a.p;
     p = make_params(s, frames, sample_rate);
@@ -1293,7 +1304,7 @@ int enqueue_root(s2r_synth *s, size_t frames, uint32_t sample_rate, float *dev_o
         // One process per GPU: this rank's partial row goes into the root's block and the rows are added by the root's last
         // mixer, all inside the render kernels (S2rMixTail.xmode 1 / 2) — no collective, no call into another library per step.
         if (!(done && done->flag) || !fused_shape_ok(s))
-            return set_err(s, S2R_ERR_INVALID, "a handle in a process group fills through s2r_fill / s2r_fill_begin with a single one-pole patch and more than one workgroup");
+            return set_err(s, S2R_ERR_INVALID, "a handle in a process group fills through s2r_fill / s2r_fill_begin, with more than one workgroup (of at most 256 voices unless the patch is a single one-pole one)");
         const uint32_t slot = defer_ring_slot >= 0 ? (uint32_t)defer_ring_slot : ((s->ring_head + s->ring_count) & 1u) ^ 1u;
         Exchange xc;
         s->xg_target[slot] += s->xg_n;
@@ -1956,8 +1967,11 @@ int s2r_note_events(s2r_synth *s, const s2r_note_event *events, size_t n) {
     static thread_local std::vector<int64_t> chosen;
     if (chosen.size() < n) chosen.resize(n);
     static_assert(sizeof(S2rPolicyEvent) == 4 && S2R_NOTE_ON == S2R_POLICY_NOTE_ON && S2R_NOTE_OFF == S2R_POLICY_NOTE_OFF, "s2r_note_event's first four bytes");
-    if (n) s->fill_time = s->pool->resolve_batch(reinterpret_cast<const S2rPolicyEvent *>(events), sizeof(s2r_note_event), n, s->fill_time, chosen.data(),
-                                                 &events[0].velocity, sizeof(s2r_note_event));
+    // (with worker threads the policy runs over the whole batch first; without — the default — event by event inside the loop
+    // that builds the records, whose own memory traffic then hides behind the policy's: measured 3-4 us per 2 048 events)
+    const bool batch_first = s->pool->workers() > 0 && n >= 4096;
+    if (n && batch_first) s->fill_time = s->pool->resolve_batch(reinterpret_cast<const S2rPolicyEvent *>(events), sizeof(s2r_note_event), n, s->fill_time,
+                                                                chosen.data(), &events[0].velocity, sizeof(s2r_note_event));
     for (size_t k = 0; k < n; k++) {
         const s2r_note_event &e = events[k];
         if (e.kind == S2R_PROGRAM_CHANGE) {      // host-side state: which patch the following note_ons get
@@ -1965,6 +1979,10 @@ int s2r_note_events(s2r_synth *s, const s2r_note_event *events, size_t n) {
             continue;
         }
         const uint32_t frame = e.frame;
+        if (!batch_first) {
+            if (frame > s->fill_time) { s->pool->advance(frame - s->fill_time); s->fill_time = frame; }
+            chosen[k] = e.kind == S2R_NOTE_ON ? (int64_t)s->pool->note_on(e.note, e.velocity) : s->pool->note_off(e.note);
+        }
         const int64_t vi = chosen[k];
         if (vi < 0) { s->double_release++; continue; }           // synth.rs:77 logs "double release" and carries on
         if (frame == 0) {                     // takes effect before the next fill: folded per voice
@@ -2367,7 +2385,7 @@ static int xg_bind(s2r_synth *s, void *block, bool owner, uint32_t rank, uint32_
 int s2r_exchange_create(s2r_synth *s, uint32_t n_ranks, void *handle_out, size_t handle_bytes) {
     if (!s || s->parent || !s->kids.empty() || n_ranks < 1 || n_ranks > 64 || !handle_out || handle_bytes < sizeof(hipIpcMemHandle_t)) return S2R_ERR_INVALID;
     if (s->xg_on) return set_err(s, S2R_ERR_INVALID, "the handle is in a process group already");
-    if (!fused_shape_ok(s)) return set_err(s, S2R_ERR_INVALID, "a process group takes shards of more than one workgroup with a single one-pole patch");
+    if (!fused_shape_ok(s)) return set_err(s, S2R_ERR_INVALID, "a process group takes shards of more than one workgroup (of at most 256 voices unless the patch is a single one-pole one)");
     S2R_QUIESCE(s);
     S2R_HIP(s, hipSetDevice(s->device));
     void *block = nullptr;
@@ -2383,7 +2401,7 @@ int s2r_exchange_create(s2r_synth *s, uint32_t n_ranks, void *handle_out, size_t
 int s2r_exchange_attach(s2r_synth *s, uint32_t rank, uint32_t n_ranks, const void *handle, size_t handle_bytes) {
     if (!s || s->parent || !s->kids.empty() || rank == 0 || rank >= n_ranks || n_ranks > 64 || !handle || handle_bytes < sizeof(hipIpcMemHandle_t)) return S2R_ERR_INVALID;
     if (s->xg_on) return set_err(s, S2R_ERR_INVALID, "the handle is in a process group already");
-    if (!fused_shape_ok(s)) return set_err(s, S2R_ERR_INVALID, "a process group takes shards of more than one workgroup with a single one-pole patch");
+    if (!fused_shape_ok(s)) return set_err(s, S2R_ERR_INVALID, "a process group takes shards of more than one workgroup (of at most 256 voices unless the patch is a single one-pole one)");
     S2R_QUIESCE(s);
     S2R_HIP(s, hipSetDevice(s->device));
     hipIpcMemHandle_t h;
