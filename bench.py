@@ -441,23 +441,55 @@ def main():
         if world != 1:
             sys.exit("--device-list is the one-process form: do not launch it under torch.distributed.run")
         total = vpg * len(dev_list)
-    sh = ShardedSynth(vpg, max_frames=FRAMES, rank=rank, world=world, device=dev, block_voices=args.block_voices,
-                      overlap=not args.no_overlap, reduce_to_root=args.reduce, devices=dev_list)
+    def make_sharded():
+        sh_ = ShardedSynth(vpg, max_frames=FRAMES, rank=rank, world=world, device=dev, block_voices=args.block_voices,
+                           overlap=not args.no_overlap, reduce_to_root=args.reduce, devices=dev_list)
+        sh_.load_patch("synth mySynth {\n\n}\n")       # example.synth2: empty body == default patch
+        return sh_
+    sh = make_sharded()
     synth = sh.renderer
     block_voices = synth.block_voices
-    sh.load_patch("synth mySynth {\n\n}\n")       # example.synth2: empty body == default patch
-    # N = 1: the pool-resident render kernel (s2r_set_resident: a fill is a posted command, the grid stays on the device and its
-    # workgroups run ahead of each other across the two fills in flight).  S2R_BENCH_RESIDENT=0: a launch per fill (A/B).
     # N > 1 (one process per GPU): the partial rows are exchanged INSIDE the render kernels through a block of rank 0's device
     # memory (s2r_exchange_create / _attach: no collective, no torch call per step); S2R_BENCH_EXCHANGE=torch keeps the
-    # all-gather of round 3.  The handle travels once, at start-up, over torch.distributed.
+    # all-gather of round 3.  The handle travels once, at start-up, over torch.distributed.  This form has never run on two
+    # or more DEVICES (its authors had one): it is tried first — set-up, then one silent fill on every rank — and if any rank
+    # reports a failure every rank goes back to the torch exchange with a fresh handle, and the line says so.
     use_xg = world > 1 and not dev_list and os.environ.get("S2R_BENCH_EXCHANGE", "ipc") == "ipc"
+    xg_note = None
     if use_xg:
-        objs = [synth.exchange_create(world) if rank == 0 else None]
+        ok, why = 1, ""
+        handle = None
+        if rank == 0:
+            try:
+                handle = synth.exchange_create(world)
+            except Exception as e:                      # noqa: BLE001
+                ok, why = 0, "s2r_exchange_create: %s" % e
+        objs = [handle]
         dist.broadcast_object_list(objs, src=0)
         if rank != 0:
-            synth.exchange_attach(rank, world, objs[0])
+            if objs[0] is None:
+                ok = 0
+            else:
+                try:
+                    synth.exchange_attach(rank, world, objs[0])
+                except Exception as e:                  # noqa: BLE001
+                    ok, why = 0, "s2r_exchange_attach: %s" % e
         dist.barrier()
+        if ok:
+            try:                                        # one silent fill through the exchange on every rank
+                synth.sample(np.empty(FRAMES, dtype=np.float32), SR)
+            except Exception as e:                      # noqa: BLE001
+                ok, why = 0, "first fill through the exchange: %s" % e
+        t_ok = torch.tensor([ok], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+        if int(t_ok.item()) == 0:
+            whys = [None] * world
+            dist.all_gather_object(whys, why)
+            xg_note = "the in-kernel exchange failed on this node (%s): fell back to all-gather over RCCL" % "; ".join(w for w in whys if w)
+            use_xg = False
+            del synth, sh
+            sh = make_sharded()
+            synth = sh.renderer
     host_api = world == 1 or use_xg               # the step is s2r_note_events + s2r_fill_begin / s2r_fill_end
     # The pool-resident render kernel (s2r_set_resident: a fill is a posted command, no launch).  On by default where the host's
     # share of a step decides (N > 1: every rank resolves the whole pool's events); at N = 1 the launches' two-stream form is
@@ -740,7 +772,9 @@ def main():
             out["small_fill"] = small_fill
         if world > 1:
             out["multi_gpu_note"] = ("this path has not been run on two or more GPUs by its authors (no such box was available to them): "
-                                     "tests cover it with N ranks under gloo and with one rank through RCCL")
+                                     "tests cover it with two processes sharing one card (the in-kernel exchange), N ranks under gloo and one rank through RCCL")
+            if xg_note:
+                out["exchange_fallback"] = xg_note
         if cpu_legs is not None:
             legs = cpu_legs
             out["cpu_baseline"] = dict(legs[-1])                  # all cores at C3's pool size
