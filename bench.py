@@ -304,13 +304,18 @@ def run_config_leg(name, voices, patch_text, steps, warmup, oversampled=False, b
     dt = time.perf_counter() - t0
     synth.set_timing(True)
     kms = []
+    if not oversampled:                                           # (two fills in flight, as in the timed steps: bench main's kernel_ms_loop)
+        synth.note_events(cyc[state["k"] % period]); state["k"] += 1
+        synth.sample_begin(FRAMES, SR)
     for _ in range(min(max(steps, 4), 16)):
         synth.note_events(cyc[state["k"] % period]); state["k"] += 1
         if oversampled:
             synth.sample_oversampled(FRAMES, SR)
         else:
-            synth.sample_begin(FRAMES, SR); synth.sample_end(out)      # (the launch the timed steps make, one fill at a time)
+            synth.sample_begin(FRAMES, SR); synth.sample_end(out)
         kms.append(synth.last_render_ms())
+    if not oversampled:
+        synth.sample_end(out)
     synth.set_timing(False)
     kernel_ms = float(np.median(kms))
     hbm = bytes_per_voice * voices / (kernel_ms * 1e-3) / 1e9
@@ -613,15 +618,23 @@ def main():
         nonlocal k0
         kms = []
         synth.set_timing(True)
-        for k in range(k0, k0 + n):
-            sh.note_events(events_of(k))
-            if world == 1:
-                # the launch the timed steps make — s2r_fill_begin's render kernel on its own stream, the mix and the chain heads
-                # beside it — with HIP events around it on that stream (s2r_set_timing); one fill at a time here
-                synth.sample_begin(FRAMES, SR); synth.sample_end(out_host)
-            else:
+        if world == 1:
+            # The launch the timed steps make — s2r_fill_begin's render kernel on its own stream, the mix and the chain heads beside
+            # it — with HIP events around it on that stream (s2r_set_timing), and in the timed steps' own rhythm: two fills in
+            # flight, so that a fill's chain heads are built while the fill before it renders (one fill at a time, the render
+            # kernel spends its first ~3 us waiting for them inside the bracket).
+            sh.note_events(events_of(k0)); synth.sample_begin(FRAMES, SR)
+            for k in range(k0 + 1, k0 + n + 1):
+                sh.note_events(events_of(k)); synth.sample_begin(FRAMES, SR)
+                synth.sample_end(out_host)
+                kms.append(synth.last_render_ms())            # (the launch just begun; waits for it)
+            synth.sample_end(out_host)
+            k0 += 1
+        else:
+            for k in range(k0, k0 + n):
+                sh.note_events(events_of(k))
                 sh.fill(FRAMES, SR)
-            kms.append(synth.last_render_ms())
+                kms.append(synth.last_render_ms())
         synth.set_timing(False)
         fence()
         k0 += n

@@ -59,8 +59,9 @@ def main():
                 return sum(seg) / len(seg) if seg else None
             out["dispatch"]["phases_avg_ns"] = {"setup_and_warmup": avg(0, w), "timed_steps": avg(w, w + k),
                                                 "host_api_sync_steps": avg(w + k, w + k + sy),
-                                                "kernel_ms_launches": avg(w + k + sy, w + k + sy + m),
-                                                "kernel_ms_all_in_lane_launches": avg(w + k + sy + m, w + k + sy + 2 * m)}
+                                                # (each of the two HIP-event loops primes one launch: two fills in flight)
+                                                "kernel_ms_launches": avg(w + k + sy + 1, w + k + sy + m + 1),
+                                                "kernel_ms_all_in_lane_launches": avg(w + k + sy + m + 2, w + k + sy + 2 * m + 2)}
             out["dispatch"]["avg_ns"] = avg(w, w + k)            # the timed steps
     # PMC passes: one row per dispatch and counter; the same launch order as the trace, so the same
     # slices.  `pmc_avg_per_dispatch` is the TIMED-STEPS phase (steady state); the warm-up launches,
