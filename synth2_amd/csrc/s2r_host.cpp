@@ -130,6 +130,13 @@ constexpr unsigned kHostPolled = hipHostMallocMapped | hipHostMallocCoherent | h
 
 }  // namespace
 
+// Kernels that wait for each other's workgroups inside the kernels — the two streams of s2r_fill_begin — need those workgroups
+// resident TOGETHER; a second handle doing the same on the same device (or several sharing a hardware queue) could hold a
+// producer out until the bounded wait gives up.  So one handle per device and process gets the two streams (the first to ask);
+// the others take the one-launch form, in which no kernel waits for another.  (Other processes on the device are the
+// caller's to know about: s2r.h.)
+static std::atomic<int> g_two_stream_handles[64];
+
 // a workgroup's partial row starts on a 16-byte boundary (combine_groups stores four frames at a time)
 static inline uint32_t partials_stride(uint32_t max_frames) { return (max_frames + 3u) & ~3u; }
 
@@ -193,6 +200,7 @@ struct s2r_synth {
     // stream_b beside the render kernels on `stream`; [1] of each pair is the second buffer (by the fill's parity)
     hipStream_t stream_b = nullptr;
     bool ov_enabled = false;                     // stream_b and the second buffers exist (S2R_OVERLAP=0 leaves them out)
+    bool ov_registered = false;                  // ... and this handle holds its device's two-stream slot (g_two_stream_handles)
     bool ov_busy = false;                        // kernels of an overlapped fill may still be running on stream_b
     float *partials2[2] = {nullptr, nullptr};
     int32_t *heads2[2] = {nullptr, nullptr};
@@ -1530,6 +1538,7 @@ void release_all(s2r_synth *s) {
     if (s->heads2[1]) (void)hipFree(s->heads2[1]);
     if (s->tevcopy2[1]) (void)hipFree(s->tevcopy2[1]);
     if (s->ov_words) (void)hipFree(s->ov_words);
+    if (s->ov_registered && s->device < 64) g_two_stream_handles[s->device].store(0);
     if (s->stream_b) (void)hipStreamDestroy(s->stream_b);
     if (s->tab_dev) (void)hipFree(s->tab_dev);
     if (s->stamps_dev) (void)hipFree(s->stamps_dev);
@@ -1704,7 +1713,13 @@ static int create_single(const s2r_config *cfg, std::shared_ptr<S2rVoicePool> po
         // (a shard of a device list never begins a fill of its own: no second stream, no second buffers for it)
         const char *e = std::getenv("S2R_OVERLAP");
         const int n_cu = s->n_cu;
-        if (!parent && s->n_blocks > 1 && (int)s->n_blocks <= n_cu && s->block_voices <= 256u && !(e && e[0] == '0')) {
+        bool mine = false;
+        if (!parent && s->n_blocks > 1 && (int)s->n_blocks <= n_cu && s->block_voices <= 256u && !(e && e[0] == '0') && dev < 64) {
+            int expected = 0;
+            mine = g_two_stream_handles[dev].compare_exchange_strong(expected, 1);
+            s->ov_registered = mine;
+        }
+        if (mine) {
             CREATE_HIP(hipStreamCreateWithFlags(&s->stream_b, hipStreamNonBlocking));
             CREATE_HIP(hipMalloc((void **)&s->partials2[1], (size_t)s->n_blocks * partials_stride(cfg->max_frames) * sizeof(float)));
             CREATE_HIP(hipMalloc((void **)&s->heads2[1], pv * sizeof(int32_t)));

@@ -33,7 +33,7 @@ def random_patch(rng):
 
 
 # S2R_FUZZ_SEEDS=N widens the sweep, S2R_FUZZ_BASE moves it.  History: seed 293 found idle voices' rows coming
-# out as -0.0 after a general-path chunk (fixed); some 60 000 cases over two dozen bases have run; later finds (stale oscillator constants after a timed restart on the streamed path, an -O3 miscompile) were fixed before they were committed; with voices aged across 2^24 frames (below): 7500 more at bases 500000, 600000 and 700000; round 3 (the resident kernel, two streams, the combine, the run selection): some 16 000 cases of the four tests below at bases 930000 ... 1040000
+# out as -0.0 after a general-path chunk (fixed); some 60 000 cases over two dozen bases have run; later finds (stale oscillator constants after a timed restart on the streamed path, an -O3 miscompile) were fixed before they were committed; with voices aged across 2^24 frames (below): 7500 more at bases 500000, 600000 and 700000; round 3 (the resident kernel, two streams, the combine, the run selection): some 16 000 cases of the four tests below at bases 930000 ... 1040000; round 4 (s2r_set_resident among the draws: the pool-resident kernel in both forms, the one-launch fill for every patch): 600 cases at base 1100000
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("S2R_FUZZ_SEEDS", "40")))))
 def test_fuzz(seed):
     rng = np.random.RandomState(int(os.environ.get("S2R_FUZZ_BASE", "1000")) + seed)
@@ -57,9 +57,11 @@ def test_fuzz(seed):
     rng_age = np.random.RandomState(int(os.environ.get("S2R_FUZZ_BASE", "1000")) * 31 + 7 + seed)   # its own stream: the cases above stay what they were
     # (round 3) half of the cases ask for the resident kernel (s2r_set_low_latency; its own stream again): it takes the fills of the
     # pools of one workgroup with a single one-pole patch and stands aside for everything else
+    # (round 4) ... through s2r_set_resident: the same kernel for pools of one workgroup, the POOL-resident kernel (every
+    # workgroup of the shard on the device, chain heads and mix inside it) for bigger pools of at most 256-voice workgroups
     if np.random.RandomState(int(os.environ.get("S2R_FUZZ_BASE", "1000")) * 17 + 3 + seed).rand() < 0.5:
-        pr.gpu.set_low_latency(True)
-        what += ", low latency"
+        pr.gpu.set_resident(True)
+        what += ", resident"
     for b in range(7):
         if b and rng.rand() < 0.15:                      # checkpoint round trip between two buffers
             pr.gpu.import_state(pr.gpu.export_state())
@@ -308,6 +310,11 @@ def test_fuzz_two_buffers_in_flight(seed):
     pr = Pair(voices, patch, max_frames=max_frames, block_voices=block, mix_groups=groups)
     sr = int(rng.choice([48000, 48000, 44100]))
     what = "seed %d: %d voices, block %d, groups %d, osc/filter %d/%d, sr %d" % (seed, voices, block, groups, patch.osc_kind, patch.lpf_kind, sr)
+    # (round 4; a stream of its own) a third of the cases keep the render grid resident (s2r_set_resident): the fills of
+    # s2r_fill_begin then reach the pool-resident kernel as commands (two-stream form), the synchronous ones in its one-launch form
+    if np.random.RandomState(int(os.environ.get("S2R_FUZZ_BASE", "1000")) * 23 + 5 + seed).rand() < 0.34:
+        pr.gpu.set_resident(True)
+        what += ", resident"
     held = []
     queue = []                                                   # (index, frames, the oracle's buffer) of the fills in flight
 

@@ -107,3 +107,14 @@ def test_render_kernels_keep_their_state_in_registers():
         assert v[".vgpr_spill_count"] == 0, (name, v)
         assert v[".vgpr_count"] <= 256, (name, v)
         assert v[".sgpr_spill_count"] <= 300, (name, v)
+    # round 4: the pool-resident kernel of the same patch (one workgroup per compute unit: the whole register file), and the
+    # general kernel of a single patch — its copy of the patch sat in 168 bytes of scratch per lane until its event lambda read
+    # the kernel-argument patch instead (12.9 MB of HBM traffic per launch at 65 536 voices, now 5.6: profiles/r04/c2_summary.json)
+    pool = {k: v for k, v in md.items() if "s2r_pool_kernelILi1ELb0E" in k}
+    assert len(pool) == 1, sorted(md)
+    for name, v in pool.items():
+        assert v[".private_segment_fixed_size"] == 0 and v[".vgpr_spill_count"] == 0 and v[".vgpr_count"] <= 512, (name, v)
+    general = {k: v for k, v in md.items() if "s2r_render_general_kernelILi" in k and "ELb0ELi256EEE" in k}
+    assert len(general) == 4, sorted(md)
+    for name, v in general.items():
+        assert v[".private_segment_fixed_size"] == 0 and v[".vgpr_spill_count"] == 0, (name, v)
