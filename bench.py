@@ -481,10 +481,16 @@ def main():
                     ok, why = 0, "s2r_exchange_attach: %s" % e
         dist.barrier()
         if ok:
-            try:                                        # one silent fill through the exchange on every rank
-                synth.sample(np.empty(FRAMES, dtype=np.float32), SR)
+            try:                                        # silent fills through the exchange on every rank: one synchronous, then
+                probe = np.empty(FRAMES, dtype=np.float32)          # two pairs in flight (both rows slots, both ring slots)
+                synth.sample(probe, SR)
+                for _ in range(2):
+                    synth.sample_begin(FRAMES, SR); synth.sample_begin(FRAMES, SR)
+                    synth.sample_end(probe); synth.sample_end(probe)
+                if not np.all(np.isfinite(probe)):
+                    raise RuntimeError("the probe fills came back non-finite")
             except Exception as e:                      # noqa: BLE001
-                ok, why = 0, "first fill through the exchange: %s" % e
+                ok, why = 0, "first fills through the exchange: %s" % e
         t_ok = torch.tensor([ok], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
         if int(t_ok.item()) == 0:

@@ -123,6 +123,8 @@ struct S2rMixTail {
     float *final_out;
     S2rDone final_done;
     int32_t final_stereo;
+    unsigned long long *granules; // != nullptr: the fill's output goes out as tagged 8-byte words instead (mono; no completion word)
+    uint32_t granule_tag;
 };
 
 struct S2rRenderParams {
@@ -258,7 +260,8 @@ struct S2rResident {
 // flight.  No launch, no kernel boundary, no launch latency per fill.
 //   command words: [0] seq  [1] frames | flags << 16  [2] records in this fill  [3] the completion word's value
 //                  [4] output: 0, 1 the ring slots, 2 the synchronous buffer; | 256: stereo  [5] event slot (tev_src index)
-//                  [6] parity  [7] arrive_target  [8] n_mixers  [9] rows_target  [10] rows slot  [15] seq
+//                  [6] parity  [7] arrive_target  [8] n_mixers  [9] rows_target  [10] rows slot  [11] heads target (two streams)
+//                  [12] 1: the output as granules (tag = [3])  [15] seq
 //   Whether command `s` runs is decided ONCE for the whole grid, by whoever gets there first: word `decided` in device
 //   memory holds 2 * seq + bail of the last command decided; a workgroup that sees command s = last + 1 complete moves it
 //   2 * last -> 2 * s (run) and one whose patience has run out moves it -> 2 * s + 1 (everybody leaves: the host finds
@@ -289,6 +292,7 @@ struct S2rPool {
     float *rows[2], *rows_mine[2];    // exchange: the root's rows by rows slot, and this shard's row among them; the ROOT's outputs:
     float *final_out[3];
     uint32_t *final_flag, *final_counter;
+    unsigned long long *granules;     // [S2R_RES_GRANULE_FRAMES] mapped host memory: synchronous fills of up to that many frames
 };
 
 // what s2r_table_kernel needs: the patch resolved for a sample rate and where the planes go
@@ -332,6 +336,8 @@ struct S2rMixParams {
     uint32_t *ov_fail;
     unsigned long long *timeline; // diagnostic builds only: as S2rRenderParams.timeline
     uint32_t tl_slot;
+    unsigned long long *granules; // short fills of the pool-resident kernel: the output as tagged 8-byte words (FillCtl.granules)
+    uint32_t granule_tag;
 };
 
 hipError_t s2r_launch_tables(const S2rTabBuild &b, hipStream_t stream);

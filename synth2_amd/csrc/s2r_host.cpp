@@ -235,6 +235,8 @@ struct s2r_synth {
     uint32_t *pool_slices = nullptr, *pool_slices_dev = nullptr;   // mapped host memory [S2R_POOL_CMD_SLOTS][n_blocks + 1]
     uint32_t *pool_host = nullptr, *pool_host_dev = nullptr;       // mapped host memory: [0] the kernel's "exited" word
     uint32_t *pool_decided = nullptr;                              // device memory
+    bool pool_gran_pending = false;                                // the fill just posted comes back as granules (fill_host reads them)
+    EventSlot *pool_gran_slot = nullptr;                           // ... and this event slot's records are free again once it has
     uint32_t pool_idle_ticks = 200000u;                            // 2 ms without a command
     int n_cu = 0;
     float *os_buf = nullptr, *os_taps = nullptr; // 4x oversampling: [62 history + max_frames] mix at 4x rate, 63 taps
@@ -899,6 +901,11 @@ int pool_setup(s2r_synth *s) {
         S2R_HIP(s, hipMemset(s->heads2[1], 0xff, pv * sizeof(int32_t)));
     }
     if (!s->tevcopy2[1]) S2R_HIP(s, hipMalloc((void **)&s->tevcopy2[1], (size_t)s->tev_capacity * sizeof(S2rTimedEvent)));
+    if (!s->res_gran) {                                          // short synchronous fills come back as tagged 8-byte words (FillCtl.granules)
+        S2R_HIP(s, hipHostMalloc((void **)&s->res_gran, S2R_RES_GRANULE_FRAMES * sizeof(unsigned long long), kHostPolled));
+        std::memset(s->res_gran, 0, S2R_RES_GRANULE_FRAMES * sizeof(unsigned long long));
+        S2R_HIP(s, hipHostGetDevicePointer((void **)&s->res_gran_dev, s->res_gran, 0));
+    }
     // The command where the CPU's write is one posted trip and the kernel's polls none: fine-grained device memory behind the
     // BAR (as the one-workgroup resident kernel's); else mapped host memory.  S2R_RES_CMD_HOST=1 keeps it in host memory.
     const size_t cmd_words = (size_t)S2R_POOL_CMD_SLOTS * S2R_POOL_CMD_WORDS;
@@ -979,6 +986,7 @@ int pool_launch(s2r_synth *s, uint32_t sample_rate, uint32_t first_seq) {
     pl.out[0] = s->ring_dev[0]; pl.out[1] = s->ring_dev[1]; pl.out[2] = s->out_host_dev;
     pl.done_flag = s->done_dev; pl.done_counter = s->done_counter;
     pl.decided = s->pool_decided; pl.exited = s->pool_host_dev; pl.fail = s->done_dev + 3;
+    pl.granules = s->res_gran_dev;
     pl.launch_id = ++s->pool_launch_id; pl.first_seq = first_seq;
     pl.idle_ticks = s->pool_idle_ticks; pl.max_polls = 1u << 24;
     s2r_synth *par = s->parent;
@@ -1038,14 +1046,21 @@ int pool_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, uint32_t sel, b
     w[1] = (uint32_t)frames; w[2] = nt; w[3] = done_value; w[4] = sel | (stereo ? 256u : 0u);
     w[5] = slot ? (uint32_t)(slot - s->slots) : 0u; w[6] = par; w[7] = s->fz_target[par]; w[8] = pick_mixers(s, frames);
     w[9] = xc ? xc->rows_target : 0u; w[10] = rows_slot;
+    // a short synchronous fill of a single device: every frame comes back as one tagged 8-byte word — no completion word, no wait
+    // for a store acknowledged across the link (as the one-workgroup resident kernel's)
+    s->pool_gran_pending = sel == 2u && !xc && frames <= S2R_RES_GRANULE_FRAMES && s->res_gran != nullptr;
+    w[12] = s->pool_gran_pending ? 1u : 0u;
     const uint32_t next_seq = s->pool_seq + 1u;
     std::memcpy(s->pool_slices + (size_t)(next_seq % S2R_POOL_CMD_SLOTS) * (s->n_blocks + 1u), s->tbounds.data(), ((size_t)s->n_blocks + 1u) * sizeof(uint32_t));
     std::atomic_thread_fence(std::memory_order_release);
     const uint32_t seq = pool_post(s, w);
     if (!s->pool_running) { int rc = pool_launch(s, sample_rate, seq); if (rc != S2R_OK) return rc; }
+    s->pool_gran_slot = nullptr;
     if (slot) {
         slot->state = 2; slot->seq = done_value;
         slot->word = (xc && xc->slot_word) ? xc->slot_word : s->done_host + sel;
+        // (a fill that comes back as granules writes no completion word: fill_host frees the slot when the frames are in)
+        if (s->pool_gran_pending) s->pool_gran_slot = slot;
     }
     if (!s->parent) {
         s->pool->advance(frames - s->fill_time);
@@ -1480,6 +1495,32 @@ int fill_host(s2r_synth *s, float *out, size_t frames, uint32_t sample_rate, boo
     rc = enqueue_root(s, frames, sample_rate, s->out_host_dev, stereo, -1, &done);
     if (rc != S2R_OK) return rc;
     const size_t n = frames * (stereo ? 2 : 1);
+    if (s->pool_gran_pending) {
+        // the frames of a short fill of the pool-resident kernel, each with the fill's tag above the sample
+        s->pool_gran_pending = false;
+        volatile unsigned long long *g = s->res_gran;
+        auto arrived = [&]() -> bool {
+            for (size_t i = frames; i-- > 0;) if ((uint32_t)(g[i] >> 32) != done.value) return false;
+            return true;
+        };
+        timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+        bool ok = false;
+        for (;;) {
+            for (int i = 0; i < 2000 && !ok; i++) { ok = arrived(); if (!ok) cpu_relax(); }
+            if (ok) break;
+            if (s->pool_running && pool_exited(s)) { int rc2 = pool_recover(s); if (rc2 != S2R_OK) return rc2; }
+            timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((double)(t1.tv_sec - t0.tv_sec) * 1e6 + (double)(t1.tv_nsec - t0.tv_nsec) * 1e-3 > 200000.0) break;
+        }
+        if (!ok) { (void)pool_stop(s); if (!arrived()) return set_err(s, S2R_ERR_HIP, "the pool-resident kernel did not report the fill"); }
+        if (s->pool_gran_slot) { s->pool_gran_slot->state = 0; s->pool_gran_slot = nullptr; }
+        { int rc2 = overlap_check(s); if (rc2 != S2R_OK) return rc2; }
+        for (size_t i = 0; i < frames; i++) {
+            const float v = s2r_u2f((uint32_t)g[i]);
+            if (stereo) { out[2 * i] = v; out[2 * i + 1] = v; } else out[i] = v;
+        }
+        return S2R_OK;
+    }
     rc = wait_done(s, 2, done.value);
     if (rc != S2R_OK) return rc;
     { int rc2 = overlap_check(s); if (rc2 != S2R_OK) return rc2; }

@@ -1018,7 +1018,9 @@ __device__ __forceinline__ void mix_block(const S2rMixParams &m, uint32_t block,
             for (uint32_t r = 1; r < n_runs; ++r) acc += s_run[(g * runs_per_group + r) * 16u + f_local];
             total = (m.root_add || g > 0) ? total + acc : acc;
         }
-        if (sys) {
+        if (m.granules != nullptr)                             // (mono: the host doubles the frame for a stereo caller)
+            __hip_atomic_store(m.granules + f, ((unsigned long long)m.granule_tag << 32) | (unsigned long long)s2r_f2u(total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else if (sys) {
             if (m.stereo) { __hip_atomic_store(m.out + 2 * f, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                             __hip_atomic_store(m.out + 2 * f + 1, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
             else __hip_atomic_store(m.out + f, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1095,8 +1097,10 @@ __device__ __forceinline__ void fused_tail(const S2rRenderParams &p, const FillC
     S2rMixParams m{};
     m.block_partials = ctl.partials; m.n_blocks = mt.n_blocks; m.blocks_per_group = mt.blocks_per_group; m.n_groups = mt.n_groups;
     m.frames = ctl.frames; m.frames_stride = p.frames_stride; m.root_add = mt.root_add; m.stereo = mt.stereo; m.out = mt.out;
+    m.granules = mt.granules; m.granule_tag = mt.granule_tag;
     const uint32_t n_fb = (ctl.frames + 15u) / 16u;
     for (uint32_t b = mixer; b < n_fb; b += mt.n_mixers) { mix_block(m, b, s_run, true, true); __syncthreads(); }
+    if (mt.granules != nullptr) return;                          // (every frame carries the fill's tag: nothing to wait for, nothing to signal)
     // this mixer's part of the output is on its way; the last mixer to get here ends the fill
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
