@@ -274,14 +274,14 @@ int s2r_set_low_latency(s2r_synth *s, int enabled);
 int s2r_low_latency_active(const s2r_synth *s);
 /* The same idea for the THROUGHPUT path: keep the shard's whole render grid on the device between fills.
  * Enabled, a handle (or every shard of a device-list handle) whose grid is at most one workgroup of at most 256 voices per
- * compute unit, with a single one-pole patch, renders the fills of s2r_fill / s2r_fill_stereo / s2r_fill_begin through a
+ * compute unit — any patch, any patch bank — renders the fills of s2r_fill / s2r_fill_stereo / s2r_fill_begin through a
  * POOL-RESIDENT kernel: a fill is a 64-byte command plus the fill's note events grouped by workgroup, written to memory the
  * kernel polls — no launch; every workgroup builds its own voices' event chains, renders, and the last ones to finish add
  * the rows up and end the fill (one workgroup per fill, for a device list, also adds the shards' rows).  With two fills in
  * flight a workgroup that is done early starts the next fill while the slowest still finish this one.  The kernel leaves by
  * itself after 2 ms without a fill (the next fill starts it again) and is stopped by every entry point that touches the
- * device, the patch or a knob, and by s2r_quiesce; fills it cannot take (other filters, patch banks, per-voice rows,
- * caller-owned streams, timing on) go the ordinary way.  Same bits either way.  While it runs it holds the handle's stream
+ * device, the patch or a knob, and by s2r_quiesce; fills it cannot take (per-voice rows, caller-owned streams, timing
+ * on, the 4x-oversampled fill) go the ordinary way.  Same bits either way.  While it runs it holds the handle's stream
  * and one workgroup slot per 256 voices: enable it for ONE handle per device, on a device the caller does not share.
  * A single-workgroup handle gets s2r_set_low_latency's kernel.  (The reference's Synth is a value on the audio thread's
  * stack, synth.rs:9-12: it is always "resident".)

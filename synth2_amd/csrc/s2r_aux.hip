@@ -202,6 +202,11 @@ hipError_t s2r_launch_onepole_osc0(const S2rRenderArgs &a, uint32_t block_voices
 hipError_t s2r_launch_onepole_osc1(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
 hipError_t s2r_launch_onepole_osc2(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
 hipError_t s2r_launch_onepole_osc3(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
+hipError_t s2r_launch_general_pool_osc0(const S2rRenderArgs &a, const S2rPool &pl, uint32_t block_voices, hipStream_t stream);
+hipError_t s2r_launch_general_pool_osc1(const S2rRenderArgs &a, const S2rPool &pl, uint32_t block_voices, hipStream_t stream);
+hipError_t s2r_launch_general_pool_osc2(const S2rRenderArgs &a, const S2rPool &pl, uint32_t block_voices, hipStream_t stream);
+hipError_t s2r_launch_general_pool_osc3(const S2rRenderArgs &a, const S2rPool &pl, uint32_t block_voices, hipStream_t stream);
+hipError_t s2r_launch_general_pool_osc15(const S2rRenderArgs &a, const S2rPool &pl, uint32_t block_voices, hipStream_t stream);
 hipError_t s2r_launch_general_osc0(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
 hipError_t s2r_launch_general_osc1(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
 hipError_t s2r_launch_general_osc2(const S2rRenderArgs &a, uint32_t block_voices, hipStream_t stream);
@@ -249,12 +254,15 @@ hipError_t s2r_launch_resident(const S2rRenderArgs &a, const S2rResident &rs, ui
 
 hipError_t s2r_launch_pool(const S2rRenderArgs &a, const S2rPool &pl, uint32_t block_voices, hipStream_t stream) {
     const S2rRenderParams &p = a.p;
-    if (p.n_voices == 0 || p.frames == 0 || p.bank_size > 1 || p.lpf_kind != S2R_FILT_ONEPOLE) return hipErrorInvalidValue;
+    if (p.n_voices == 0 || p.frames == 0) return hipErrorInvalidValue;
+    // patch banks, and the DPW oscillator shapes: the kernel with oscillator and filter kind per lane
+    if (p.bank_size > 1 || p.osc_kind > S2R_OSC_SINE) return s2r_launch_general_pool_osc15(a, pl, block_voices, stream);
+    const bool general = p.lpf_kind != S2R_FILT_ONEPOLE;
     switch (p.osc_kind) {
-    case S2R_OSC_SQUARE: return s2r_launch_onepole_pool_osc0(a, pl, block_voices, stream);
-    case S2R_OSC_SAW: return s2r_launch_onepole_pool_osc1(a, pl, block_voices, stream);
-    case S2R_OSC_TRIANGLE: return s2r_launch_onepole_pool_osc2(a, pl, block_voices, stream);
-    case S2R_OSC_SINE: return s2r_launch_onepole_pool_osc3(a, pl, block_voices, stream);
+    case S2R_OSC_SQUARE: return general ? s2r_launch_general_pool_osc0(a, pl, block_voices, stream) : s2r_launch_onepole_pool_osc0(a, pl, block_voices, stream);
+    case S2R_OSC_SAW: return general ? s2r_launch_general_pool_osc1(a, pl, block_voices, stream) : s2r_launch_onepole_pool_osc1(a, pl, block_voices, stream);
+    case S2R_OSC_TRIANGLE: return general ? s2r_launch_general_pool_osc2(a, pl, block_voices, stream) : s2r_launch_onepole_pool_osc2(a, pl, block_voices, stream);
+    case S2R_OSC_SINE: return general ? s2r_launch_general_pool_osc3(a, pl, block_voices, stream) : s2r_launch_onepole_pool_osc3(a, pl, block_voices, stream);
     default: return hipErrorInvalidValue;
     }
 }

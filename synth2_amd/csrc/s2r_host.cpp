@@ -877,7 +877,7 @@ bool pool_exited(const s2r_synth *s) { return __atomic_load_n(&s->pool_host[0], 
 // a fill the pool-resident kernel can take: the one-launch form's shape, a grid that is resident as a whole (at most one
 // workgroup of at most 256 threads per compute unit), nothing that brackets or watches single launches
 bool pool_eligible(const s2r_synth *s, size_t frames) {
-    return s->resident && s->kids.empty() && s->pool_cmd != nullptr && fused_shape_ok(s) && onepole_single_patch(s) && (int)s->n_blocks <= s->n_cu && s->block_voices <= 256u &&
+    return s->resident && s->kids.empty() && s->pool_cmd != nullptr && fused_shape_ok(s) && (int)s->n_blocks <= s->n_cu && s->block_voices <= 256u &&
            !s->timing && s->timeline_dev == nullptr && frames <= 0xffffu && frames <= s->cfg.max_frames;
 }
 
@@ -970,9 +970,12 @@ int pool_launch(s2r_synth *s, uint32_t sample_rate, uint32_t first_seq) {
     S2R_HIP(s, hipSetDevice(s->device));
     static thread_local S2rRenderArgs a;
     S2rRenderParams &p = a.p;
+    bool bank_kernel = false;
+    { int rc = ensure_bank(s, sample_rate, s->stream, &bank_kernel); if (rc != S2R_OK) return rc; }
     p = make_params(s, s->cfg.max_frames, sample_rate);          // (p.frames: the longest fill, sizes the staging)
     { int rc = ensure_tables(s, p, sample_rate, s->stream); if (rc != S2R_OK) return rc; }
     if (tables_wanted(s)) p.tab = s->tab;
+    else if (bank_kernel) { p.tab = S2rTabRef{}; p.tab.base = s->bank_tab_dev; }      // the per-lane-patch kernel adds each entry's tab_off
     p.voice_ev_head = s->voice_ev_head;
     p.stamps = s->stamps_dev;                                    // (diagnostic builds: tools/stamps_pool.py)
     p.tev = s->tev_copy;                                         // (MODE 2: a fill's events come as chains)

@@ -1156,6 +1156,128 @@ __device__ __forceinline__ void fused_tail(const S2rRenderParams &p, const FillC
     if (threadIdx.x == 0 && mt.final_done.flag != nullptr) __hip_atomic_store(mt.final_done.flag, mt.final_done.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// The pool-resident kernels' command loop (S2rPool, s2r_device.h): the shard's whole grid stays on the device; every workgroup
+// renders fill after fill — `fill(ctl)`: a render kernel's per-fill function in its one-launch form (a fill's note events, timed
+// or not, come as chains), or its two-stream form —
+// as the host posts them, running ahead of the slower workgroups by as much as the fills in flight allow.  What happens to
+// command last + 1 is decided once for the grid (word `decided`): run it, or — no command for idle_ticks — everybody leaves.
+template <class Fill>
+__device__ __forceinline__ void pool_loop(const S2rRenderArgs &a, const S2rPool &pl, Fill fill) {
+    __shared__ uint32_t s_cmd[S2R_POOL_CMD_WORDS + 2];           // the command, then this workgroup's slice bounds
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    uint32_t last = pl.first_seq - 1u;
+    for (;;) {
+        if (tid < 64u) {
+            const uint32_t want = last + 1u;
+            const uint32_t slot = want % S2R_POOL_CMD_SLOTS;
+            const uint32_t *c = pl.cmd + slot * S2R_POOL_CMD_WORDS;
+            const uint32_t run_word = want << 1, bail_word = (want << 1) | 1u;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            uint32_t polls = 0;
+            bool leave = false, decided_run = false;
+            for (;;) {
+                uint32_t w = 0u;
+                // (the command lives behind the BAR in device memory, or in host memory: workgroup 0 looks at it every time
+                // round, the others mostly at the decision word, which is local)
+                const bool look = blockIdx.x == 0u || decided_run || gridDim.x <= 8u || (polls & 7u) == 0u;
+                if (look && lane < S2R_POOL_CMD_WORDS) w = __hip_atomic_load(c + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const uint32_t s_first = (uint32_t)__builtin_amdgcn_readlane((int)w, 0), s_last = (uint32_t)__builtin_amdgcn_readlane((int)w, 15);
+                const bool complete = look && s_first == want && s_last == want;
+                uint32_t d = 0u;
+                if (lane == 0u) {
+                    d = __hip_atomic_load(pl.decided, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (d != run_word && d != bail_word && complete) {
+                        uint32_t expected = last << 1;
+                        d = __hip_atomic_compare_exchange_strong(pl.decided, &expected, run_word, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? run_word : expected;
+                    }
+                }
+                d = (uint32_t)__builtin_amdgcn_readlane((int)d, 0);
+                if (d == bail_word) { leave = true; break; }
+                decided_run = d == run_word;
+                if (decided_run && complete) {
+                    if (lane < S2R_POOL_CMD_WORDS) s_cmd[lane] = w;
+                    // (this workgroup's slice of the fill's records: a trip to host memory, spared when the fill brings none)
+                    const uint32_t n_rec = (uint32_t)__builtin_amdgcn_readlane((int)w, 2);
+                    if (lane >= 16u && lane < 18u)
+                        s_cmd[lane] = n_rec == 0u ? 0u : __hip_atomic_load(pl.slices + (size_t)slot * pl.slices_stride + blockIdx.x + (lane - 16u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+                ++polls;
+                const bool out_of_patience = __builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)pl.idle_ticks || polls >= pl.max_polls;
+                if (out_of_patience) {
+                    if (decided_run) { leave = true; break; }    // (a command decided but never seen whole: cannot happen with a live host; leave rather than spin)
+                    uint32_t won = 0u;
+                    if (lane == 0u) {
+                        uint32_t expected = last << 1;
+                        won = __hip_atomic_compare_exchange_strong(pl.decided, &expected, bail_word, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+                        if (!won && expected == bail_word) won = 1u;
+                    }
+                    if (__builtin_amdgcn_readlane((int)won, 0) != 0) { leave = true; break; }
+                    // (somebody has just decided to run it: look for the command a little longer)
+                    decided_run = true;
+                    polls = pl.max_polls > 4096u ? pl.max_polls - 4096u : 0u;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (leave && lane == 0u) s_cmd[1] = S2R_POOL_FLAG_EXIT << 16;
+        }
+        __syncthreads();
+        const uint32_t w1 = s_cmd[1];
+        if ((w1 >> 16) & S2R_POOL_FLAG_EXIT) break;              // (uniform: every thread reads the same LDS word)
+        last = s_cmd[0];
+        const uint32_t frames = w1 & 0xffffu, sel = s_cmd[4] & 0xffu, par = s_cmd[6] & 1u, es = s_cmd[5] & 3u;
+        const int32_t stereo = (int32_t)((s_cmd[4] >> 8) & 1u);
+        FillCtl ctl = FillCtl{};                                  // (nothing of a launch's own fill: the kernel arguments' event words stay untouched)
+        ctl.frames = frames; ctl.n_events = 0u;
+        ctl.partials = par ? pl.partials[1] : pl.partials[0];
+        ctl.heads = par ? pl.heads[1] : pl.heads[0];
+        ctl.tev_copy = par ? pl.tev_copy[1] : pl.tev_copy[0];
+        ctl.tev = ctl.tev_copy;
+        ctl.tev_src = es == 0u ? pl.tev_src[0] : es == 1u ? pl.tev_src[1] : es == 2u ? pl.tev_src[2] : pl.tev_src[3];
+        ctl.slice_lo = s_cmd[16]; ctl.slice_hi = s_cmd[17];
+        ctl.fail = pl.fail;
+        const bool two_streams = ((w1 >> 16) & S2R_POOL_FLAG_TWO_STREAMS) != 0u;
+        if (two_streams) {
+            // the two-stream form of a fill (S2rOverlapWords): the chain heads and the mix are a launch on the other stream, as for a
+            // launch per fill — nothing of them on this workgroup's path; only the render launch is gone
+            ctl.fused = false;
+            ctl.tev_src = nullptr; ctl.slice_lo = 0u; ctl.slice_hi = 0u;
+            ctl.arrive = nullptr; ctl.mt.n_mixers = 0u;
+            ctl.ov_heads_counter = s_cmd[2] ? pl.ov_heads + par : nullptr; ctl.ov_heads_target = s_cmd[11];
+            ctl.ov_render_counter = pl.ov_render + par;
+        } else {
+        ctl.fused = true;
+        ctl.ov_heads_counter = nullptr; ctl.ov_render_counter = nullptr;
+        ctl.arrive = pl.arrive + par; ctl.arrive_target = s_cmd[7];
+        ctl.mt = pl.mt;
+        ctl.mt.n_mixers = s_cmd[8];
+        float *const o = sel == 0u ? pl.out[0] : sel == 1u ? pl.out[1] : pl.out[2];
+        if (pl.mt.rows_done != nullptr) {                        // a shard of a device list / of a group of processes
+            const uint32_t rs = s_cmd[10] & 1u;
+            ctl.mt.out = rs ? pl.rows_mine[1] : pl.rows_mine[0];
+            ctl.mt.rows = rs ? pl.rows[1] : pl.rows[0];
+            ctl.mt.rows_done = pl.mt.rows_done + rs;
+            ctl.mt.rows_target = s_cmd[9];
+            ctl.mt.stereo = 0;
+            ctl.mt.done = S2rDone{pl.mt.xmode == 2 ? pl.done_flag + sel : nullptr, s_cmd[3], pl.done_counter + sel};
+            ctl.mt.final_out = sel == 0u ? pl.final_out[0] : sel == 1u ? pl.final_out[1] : pl.final_out[2];
+            ctl.mt.final_done = S2rDone{pl.final_flag + sel, s_cmd[3], nullptr};
+            ctl.mt.final_stereo = stereo;
+        } else {
+            ctl.mt.out = o;
+            ctl.mt.stereo = stereo;
+            ctl.mt.done = S2rDone{pl.done_flag + sel, s_cmd[3], pl.done_counter + sel};
+            if (s_cmd[12] != 0u && pl.granules != nullptr) { ctl.mt.granules = pl.granules; ctl.mt.granule_tag = s_cmd[3]; }
+        }
+        }
+        // (ONE call site: the fill function is the whole render kernel, and a second copy of it — or a call through the lambda's
+        // address — costs the kernel arguments a copy in scratch)
+        if (frames != 0u && frames <= a.p.frames) fill(ctl);
+        __syncthreads();                                         // (the command words and the staging are reused)
+    }
+    if (blockIdx.x == 0u && tid == 0u) __hip_atomic_store(pl.exited, pl.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---------------------------------------------------------------------------------------
 // The branch-free 16-frame chunk.  Measured (ablated builds): with the rare branches (envelope
 // stage change, fmodf slow path, coefficient-source selection) inside the per-quad loop the

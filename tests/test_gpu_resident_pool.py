@@ -106,6 +106,43 @@ def test_pool_resident_kernel_against_the_oracle(osc):
     assert not gpu.resident_active
 
 
+@pytest.mark.parametrize("case", ["svf", "lp2_fm", "bank"])
+def test_pool_resident_kernel_of_the_other_render_kernel(case):
+    """the pool-resident form of s2r_render_general_kernel: a patch with the SVF, one with a dsp_filters.rs filter and mod-to-pitch,
+    and a patch bank with program changes (per-lane patches, a DPW voice among them) — ring fills (two-stream form) and
+    synchronous ones (chain heads and mix inside the kernel) against the oracle"""
+    rng = np.random.RandomState({"svf": 3, "lp2_fm": 4, "bank": 5}[case])
+    voices = 2048
+    gpu = s2.Synth(voices, max_frames=1024)
+    ora = s2o.OracleSynth(voices)
+    if case == "bank":
+        bank = [make_patch(osc_kind=s2.OSC_SAW), make_patch(osc_kind=s2.OSC_SINE, lpf_kind=s2.FILT_LP2, lpf_freq=900.0, noise=0.2),
+                make_patch(osc_kind=s2.OSC_DPW_SAW, lpf_kind=s2.FILT_SVF_LP, lpf_q=1.3)]
+        gpu.set_patch_bank(bank)
+        ora.set_bank([oracle_cfg_from_patch(q) for q in bank])
+    else:
+        patch = (make_patch(lpf_kind=s2.FILT_SVF_LP, lpf_freq=900.0, lpf_q=1.4) if case == "svf" else
+                 make_patch(osc_kind=s2.OSC_TRIANGLE, lpf_kind=s2.FILT_LP2, lpf_freq=1500.0, lpf_damping=0.8, mod_env_to_osc_freq=0.5, noise=0.1))
+        gpu.set_patch(patch)
+        ora.config = oracle_cfg_from_patch(patch)
+    gpu.set_resident(True)
+
+    def batch(n, frames, timed=True):
+        ev = _random_batch(rng, n, frames, timed)
+        if case == "bank":                                       # program changes among the events (kind 2: note = the program)
+            pc = rng.rand(ev.size) < 0.1
+            ev["kind"][pc] = 2; ev["note"][pc] = rng.randint(0, 3, int(pc.sum()))
+        return ev
+
+    batches = [batch(2500, 1024, timed=False)] + [batch(int(rng.randint(0, 700)), 1024) for _ in range(7)]
+    _drive(gpu, ora, batches, lambda k: 1024, "pool-resident general kernel (%s), ring" % case)
+    assert gpu.resident_active
+    lens = [1024, 1000, 16, 512]
+    batches = [batch(int(rng.randint(0, 500)), lens[k]) for k in range(4)]
+    _drive(gpu, ora, batches, lambda k: lens[k], "pool-resident general kernel (%s), s2r_fill" % case, ring=False)
+    assert gpu.resident_active
+
+
 def test_pool_resident_kernel_leaves_when_idle_and_is_started_again():
     """the kernel's patience is 2 ms: pauses shorter and longer than that between fills, with one fill in flight across the
     pause or none — every buffer still the oracle's"""
