@@ -237,6 +237,8 @@ struct s2r_synth {
     uint32_t *pool_decided = nullptr;                              // device memory
     bool pool_gran_pending = false;                                // the fill just posted comes back as granules (fill_host reads them)
     EventSlot *pool_gran_slot = nullptr;                           // ... and this event slot's records are free again once it has
+    volatile uint32_t *pool_staged = nullptr; uint32_t pool_staged_seq = 0;   // a command whose payload is written and whose sequence words
+                                                                   // the caller (a device list's parent) writes with its other shards'
     uint32_t pool_idle_ticks = 200000u;                            // 2 ms without a command
     int n_cu = 0;
     float *os_buf = nullptr, *os_taps = nullptr; // 4x oversampling: [62 history + max_frames] mix at 4x rate, 63 taps
@@ -939,11 +941,19 @@ hipError_t malloc_exchange(void **p, size_t bytes) {
     return hipMalloc(p, bytes);
 }
 
-// payload first, then word 15, then word 0 (device memory behind the BAR is write-combining: the fences order the stages)
-uint32_t pool_post(s2r_synth *s, const uint32_t *w) {
+// payload first, then word 15, then word 0 (device memory behind the BAR is write-combining: the fences order the stages).
+// The three stages apart, so that the shards of a device list share the fences: every shard's payload, one fence, every
+// shard's word 15, one fence, every shard's word 0 (a fence flushes the CPU's write-combining buffers whatever they hold).
+volatile uint32_t *pool_post_payload(s2r_synth *s, const uint32_t *w, uint32_t *seq_out) {
     const uint32_t seq = ++s->pool_seq;
     volatile uint32_t *c = s->pool_cmd + (size_t)(seq % S2R_POOL_CMD_SLOTS) * S2R_POOL_CMD_WORDS;
     for (uint32_t i = 1; i < 15; i++) c[i] = w[i];
+    *seq_out = seq;
+    return c;
+}
+uint32_t pool_post(s2r_synth *s, const uint32_t *w) {
+    uint32_t seq = 0;
+    volatile uint32_t *c = pool_post_payload(s, w, &seq);
     if (s->pool_cmd_vram) store_fence();
     __atomic_store_n(&c[15], seq, __ATOMIC_RELEASE);
     if (s->pool_cmd_vram) store_fence();
@@ -1032,7 +1042,8 @@ int pool_recover(s2r_synth *s) {
 
 // One fill through the pool-resident kernel: the events grouped by workgroup, the bounds, the command.  `sel`: where the output
 // goes (0, 1 the ring slots, 2 the synchronous buffer); xc: the shard's part in a device list's exchange.
-int pool_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, uint32_t sel, bool stereo, uint32_t done_value, const Exchange *xc, uint32_t rows_slot) {
+int pool_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, uint32_t sel, bool stereo, uint32_t done_value, const Exchange *xc, uint32_t rows_slot,
+              bool stage_only = false) {
     { int rc = overlap_drain(s); if (rc != S2R_OK) return rc; }
     { int rc = launch_deferred_mix(s, s->stream); if (rc != S2R_OK) return rc; }
     if (s->pool_running && (s->pool_rate != sample_rate || pool_exited(s) || s->pending.size() + s->tpending.size() > s->tev_capacity)) {
@@ -1056,7 +1067,9 @@ int pool_fill(s2r_synth *s, size_t frames, uint32_t sample_rate, uint32_t sel, b
     const uint32_t next_seq = s->pool_seq + 1u;
     std::memcpy(s->pool_slices + (size_t)(next_seq % S2R_POOL_CMD_SLOTS) * (s->n_blocks + 1u), s->tbounds.data(), ((size_t)s->n_blocks + 1u) * sizeof(uint32_t));
     std::atomic_thread_fence(std::memory_order_release);
-    const uint32_t seq = pool_post(s, w);
+    uint32_t seq = 0;
+    if (stage_only && s->pool_running) { s->pool_staged = pool_post_payload(s, w, &seq); s->pool_staged_seq = seq; }
+    else seq = pool_post(s, w);
     if (!s->pool_running) { int rc = pool_launch(s, sample_rate, seq); if (rc != S2R_OK) return rc; }
     s->pool_gran_slot = nullptr;
     if (slot) {
@@ -1248,7 +1261,7 @@ int enqueue_multi(s2r_synth *s, size_t frames, uint32_t sample_rate, float *dev_
             xc.final_out = dev_out; xc.final_done = *done; xc.final_stereo = stereo;
             xc.slot_word = s->done_host + (done->flag - s->done_dev);
             if (pool_eligible(kid, frames))
-                return pool_fill(kid, frames, sample_rate, (uint32_t)(done->flag - s->done_dev), stereo, done->value, &xc, slot);
+                return pool_fill(kid, frames, sample_rate, (uint32_t)(done->flag - s->done_dev), stereo, done->value, &xc, slot, true);
             { int rc = pool_stop(kid); if (rc != S2R_OK) return rc; }
             const S2rDone kd{nullptr, 0u, kid->done_counter + slot};
             return enqueue_fill(kid, frames, sample_rate, kid->stream, row, false, false, nullptr, -1, &kd, &xc);
@@ -1271,6 +1284,18 @@ int enqueue_multi(s2r_synth *s, size_t frames, uint32_t sample_rate, float *dev_
     if (rc != S2R_OK) return rc;
     s->pool->advance(frames - s->fill_time);      // the shared clock, once
     s->fill_time = 0;
+    if (exchange) {
+        // the staged commands of the resident shards: their sequence words behind shared fences (pool_post_payload)
+        bool any = false, vram = false;
+        for (s2r_synth *kid : s->kids) if (kid->pool_staged) { any = true; vram = vram || kid->pool_cmd_vram; }
+        if (any) {
+            if (vram) store_fence();
+            for (s2r_synth *kid : s->kids) if (kid->pool_staged) __atomic_store_n(&kid->pool_staged[15], kid->pool_staged_seq, __ATOMIC_RELEASE);
+            if (vram) store_fence();
+            for (s2r_synth *kid : s->kids) if (kid->pool_staged) { __atomic_store_n(&kid->pool_staged[0], kid->pool_staged_seq, __ATOMIC_RELEASE); kid->pool_staged = nullptr; }
+            if (vram) store_fence();
+        }
+    }
     if (per_voice_host || exchange) return S2R_OK;
     S2R_HIP(s, hipSetDevice(s->device));
     for (uint32_t k = 0; k < n; k++) S2R_HIP(s, hipStreamWaitEvent(s->stream, s->kid_done[slot][k], 0));

@@ -1217,7 +1217,8 @@ __device__ __forceinline__ void pool_loop(const S2rRenderArgs &a, const S2rPool 
                     decided_run = true;
                     polls = pl.max_polls > 4096u ? pl.max_polls - 4096u : 0u;
                 }
-                __builtin_amdgcn_s_sleep(8);
+                // (a caller in a loop comes back within microseconds: the first polls are close together, the rest leave the fabric alone)
+                if (polls < 128u) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(8);
             }
             if (leave && lane == 0u) s_cmd[1] = S2R_POOL_FLAG_EXIT << 16;
         }

@@ -18,6 +18,13 @@ import bench      # noqa: E402
 SETUP = int(os.environ.get("S2R_PROF_SETUP", str(bench.C3_SETUP)))      # bench.py's untimed set-up buffers (workload c3)
 
 
+def newest(pattern):
+    """gpurun merges a run's files INTO the local directory: an earlier run of the same tag leaves its files beside the new
+    ones.  Only the newest file of a kind is the run being summarised."""
+    files = glob.glob(pattern, recursive=True)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
 def main():
     root = sys.argv[1]
     want = sys.argv[2] if len(sys.argv) > 2 else "s2r_render_kernel"
@@ -28,11 +35,11 @@ def main():
         out["kernel_source_hash"] = bench.kernel_source_hash()     # bench.py quotes these counters only for this build
     except Exception:
         pass
-    for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    for f in newest(os.path.join(root, "trace", "**", "*kernel_stats.csv")):
         rows = list(csv.DictReader(open(f)))
         out["kernel_stats"] = [{"name": r["Name"][:120], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
                                 "pct": float(r["Percentage"])} for r in rows[:8]]
-    for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    for f in newest(os.path.join(root, "trace", "**", "*kernel_trace.csv")):
         rows = [r for r in csv.DictReader(open(f)) if want in r["Kernel_Name"]]
         if rows:
             rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -69,7 +76,7 @@ def main():
     w = SETUP + int(os.environ.get("S2R_PROF_WARMUP", "4")); k = int(os.environ.get("S2R_PROF_STEPS", "16"))
     counters = defaultdict(list)
     for sub in ("pmc1", "pmc2", "pmc3", "pmc4", "pmc_fetch", "pmc_write"):
-        for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
+        for f in newest(os.path.join(root, sub, "**", "*counter_collection.csv")):
             rows = [r for r in csv.DictReader(open(f)) if want in r.get("Kernel_Name", "")]
             rows.sort(key=lambda r: int(r["Dispatch_Id"]))
             per = defaultdict(list)
