@@ -690,15 +690,18 @@ def main():
     # ---- the other single-GPU configurations of BASELINE.json, each timed like the headline, after it (N = 1) ----
     config_legs = None
     if world == 1 and rank == 0 and not args.no_config_legs:
-        synth = None; sh = None                    # (frees the headline's handle)
+        # the headline's handle is destroyed HERE, not when the collector gets to it (ShardedSynth holds a bound method of itself):
+        # one handle per device gets the two streams of s2r_fill_begin, and the legs are timed the way the headline is
+        synth.close()
+        synth = None; sh = None
         config_legs = []
         leg, _s = run_config_leg("config[2] as written: 65 536 voices, saw + ADSR + SVF (build-defined state-variable filter; the reference has none)",
                                  65536, "synth c2 { lpf.kind = svf_lp; lpf.q = 1.4 }", args.steps, args.warmup, bytes_per_voice=36 + 20)
-        config_legs.append(leg); del _s
+        config_legs.append(leg); _s.close(); del _s
         leg, _s = run_config_leg("config[4]'s per-GPU share: 32 768 voices, alias-suppressed saw (DPW) + SVF, 4x oversampled (192 kHz internal)",
                                  32768, "synth c4 { osc.kind = dpw_saw; lpf.kind = svf_lp; lpf.q = 1.4 }", max(4, args.steps // 4), max(1, args.warmup // 4),
                                  oversampled=True, bytes_per_voice=40 + 24)
-        config_legs.append(leg); del _s
+        config_legs.append(leg); _s.close(); del _s
 
     # ---- the reference's own call pattern (BASELINE configs[0]: 8 voices, Synth::sample per 16 frames, main.rs:138-147): wall time of
     #      one s2r_fill from a C++ caller over the C ABI, a launch per call and through the resident kernel (s2r_set_low_latency) ----

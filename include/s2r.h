@@ -205,7 +205,12 @@ int s2r_fill(s2r_synth *s, float *mono_out, size_t frames, uint32_t sample_rate_
  * comes back).  s2r_fill_begin applies the events handed over so far and queues the fill; s2r_fill_end waits for the
  * OLDEST fill begun and not yet ended and copies its `frames` samples to mono_out.  At most two fills may be in flight;
  * between a begin and its end the caller may hand over the next buffer's events and begin that fill.  s2r_fill is
- * begin + end. */
+ * begin + end.  (How a begun fill is launched is the library's business and bit-neutral: ONE handle per device and process —
+ * the first created whose grid is at most one workgroup per compute unit — runs its render kernels on a stream of their own
+ * beside a second stream's chain heads and mixes, which wait for each other's workgroups inside the kernels and therefore
+ * need the device's compute units to themselves; every other handle takes one launch per fill in which no kernel waits for
+ * another.  A fill that fails on the device comes back from s2r_fill_end as an error ONCE, its buffer zeroed, and the handle
+ * refuses events and fills from then on: DESIGN.md 4.2.) */
 int s2r_fill_begin(s2r_synth *s, size_t frames, uint32_t sample_rate_hz);
 /* `capacity` = floats `mono_out` can take: S2R_ERR_INVALID (and nothing is consumed) when it is smaller than the
  * `frames` the oldest fill was begun with — s2r_fill_pending_frames says how many that is (0: none in flight). */
