@@ -347,6 +347,44 @@ void push_event(s2r_synth *top, uint32_t pool_index, uint32_t flags, float pitch
     if (flags & S2R_EV_RELEASE) e.flags |= S2R_EV_RELEASE;
 }
 
+// An untimed event of a voice whose shard already holds frame-0 RECORDS for the next fill (a big batch's, s2r_note_events) joins
+// them, behind them: folded, it would be applied in front.  false: no records are waiting (the caller folds it).
+bool append_frame0_record(s2r_synth *top, uint32_t pool_index, uint32_t flags, float pitch, uint32_t seed, uint32_t program) {
+    uint32_t local = 0;
+    s2r_synth *sh = shard_of(top, pool_index, &local);
+    if (!sh || sh->tpending.empty()) return false;
+    const int32_t idx = (int32_t)sh->tpending.size();
+    S2rTimedEvent te{};
+    te.voice = local; te.frame = 0; te.flags = flags; te.pitch = pitch; te.seed = seed; te.next = -1; te.program = program;
+    if (sh->tlast[local] >= 0) sh->tpending[(size_t)sh->tlast[local]].next = idx;
+    else te.flags |= S2R_TEV_FIRST;
+    sh->tlast[local] = idx;
+    sh->tpending.push_back(te);
+    return true;
+}
+
+// The other way round, for the entry points that take no chains (per-voice rows, checkpoints, seeds): while no event has a frame
+// inside the fill (fill_time == 0: every record waiting is a frame-0 one) the records are folded back, in their order, behind
+// whatever was folded before them.
+void fold_frame0_records(s2r_synth *top) {
+    for (s2r_synth *kid : top->kids) fold_frame0_records(kid);
+    s2r_synth *root = top->parent ? top->parent : top;
+    if (top->tpending.empty() || root->fill_time != 0) return;
+    for (const S2rTimedEvent &te : top->tpending) {
+        int32_t slot = top->pending_slot[te.voice];
+        if (slot < 0) {
+            slot = (int32_t)top->pending.size();
+            top->pending_slot[te.voice] = slot;
+            top->pending.push_back(S2rVoiceEvent{te.voice, 0u, 0.0f, 0u});
+        }
+        S2rVoiceEvent &e = top->pending[(size_t)slot];
+        if (te.flags & S2R_EV_RESTART) { e.flags = S2R_EV_RESTART | (te.program << S2R_EV_PROGRAM_SHIFT); e.pitch = te.pitch; e.seed = te.seed; }
+        if (te.flags & S2R_EV_RELEASE) e.flags |= S2R_EV_RELEASE;
+    }
+    for (const S2rTimedEvent &te : top->tpending) top->tlast[te.voice] = -1;
+    top->tpending.clear();
+}
+
 // upload the folded events and apply them on `stream`; publish the timed ones.  Returns the slot
 // whose `done` event the caller must record AFTER the render kernel when timed events exist
 // (the kernel reads them from the slot's mapped memory), or nullptr.
@@ -2003,7 +2041,8 @@ int s2r_note_on_ex(s2r_synth *s, uint8_t note, float velocity, uint32_t *voice_i
     if (s->fill_time) return set_err(s, S2R_ERR_INVALID, "untimed note_on after timed events: fill first or give it a frame");
     const uint32_t i = s->pool->note_on(note, velocity);
     if (voice_index_out) *voice_index_out = i;
-    push_event(s, i, S2R_EV_RESTART, s->pitch_table[note], s->seed_override[i], s->program);
+    if (!append_frame0_record(s, i, S2R_EV_RESTART, s->pitch_table[note], s->seed_override[i], s->program))
+        push_event(s, i, S2R_EV_RESTART, s->pitch_table[note], s->seed_override[i], s->program);
     return S2R_OK;
 }
 
@@ -2013,7 +2052,7 @@ int s2r_note_off(s2r_synth *s, uint8_t note) {
     if (!s) return S2R_ERR_INVALID;
     if (s->fill_time) return set_err(s, S2R_ERR_INVALID, "untimed note_off after timed events: fill first or give it a frame");
     const int64_t i = s->pool->note_off(note);
-    if (i >= 0) push_event(s, (uint32_t)i, S2R_EV_RELEASE, 0.0f, 0u);
+    if (i >= 0) { if (!append_frame0_record(s, (uint32_t)i, S2R_EV_RELEASE, 0.0f, 0u, 0u)) push_event(s, (uint32_t)i, S2R_EV_RELEASE, 0.0f, 0u); }
     else s->double_release++;                 // synth.rs:77: `log::warn!("double release")`, nothing else happens
     return S2R_OK;
 }
@@ -2069,7 +2108,14 @@ int s2r_note_events(s2r_synth *s, const s2r_note_event *events, size_t n) {
         }
         const int64_t vi = chosen[k];
         if (vi < 0) { s->double_release++; continue; }           // synth.rs:77 logs "double release" and carries on
-        if (frame == 0) {                     // takes effect before the next fill: folded per voice
+        uint32_t local = 0;
+        s2r_synth *sh = shard_of(s, (uint32_t)vi, &local);
+        if (!sh) continue;
+        // An event at frame 0 takes effect before the next fill.  A small batch's are FOLDED per voice (push_event: one record per
+        // touched voice, which can ride in the render kernel's arguments); a big batch's — and whatever follows records already
+        // waiting on the shard — go straight into the voices' chains as frame-0 records, which is where the folded ones of a fill
+        // with chains end up anyway (merge_pending_into_chains), without the fold's lookup per event and the merge's pass per fill.
+        if (frame == 0 && n <= S2R_ARG_MAX_EVENTS && sh->tpending.empty()) {
             if (e.kind == S2R_NOTE_ON) push_event(s, (uint32_t)vi, S2R_EV_RESTART, s->pitch_table[e.note], s->seed_override[(size_t)vi], s->program);
             else push_event(s, (uint32_t)vi, S2R_EV_RELEASE, 0.0f, 0u);
             continue;
@@ -2077,9 +2123,6 @@ int s2r_note_events(s2r_synth *s, const s2r_note_event *events, size_t n) {
         uint32_t fl; float pitch = 0.0f; uint32_t seed = 0;
         if (e.kind == S2R_NOTE_ON) { fl = S2R_EV_RESTART; pitch = s->pitch_table[e.note]; seed = s->seed_override[(size_t)vi]; }
         else fl = S2R_EV_RELEASE;
-        uint32_t local = 0;
-        s2r_synth *sh = shard_of(s, (uint32_t)vi, &local);
-        if (!sh) continue;
         // (no capacity limit here: the device-side buffers grow in flush_events when a fill brings more timed
         // events than they hold)
         const int32_t idx = (int32_t)sh->tpending.size();
@@ -2224,6 +2267,7 @@ int s2r_render_voices(s2r_synth *s, float *per_voice_out, size_t frames, uint32_
     if (rc != S2R_OK) return rc;
     if (frames == 0) return S2R_OK;
     if (!per_voice_out) return set_err(s, S2R_ERR_INVALID, "null output buffer");
+    fold_frame0_records(s);
     if (!s->tpending.empty()) return set_err(s, S2R_ERR_INVALID, "s2r_render_voices does not take timed events; use s2r_fill");
     S2R_QUIESCE(s);
     if (!s->kids.empty()) {                       // every shard's rows, put back into pool order
@@ -2259,6 +2303,7 @@ int s2r_render_voices(s2r_synth *s, float *per_voice_out, size_t frames, uint32_
 int s2r_export_state(s2r_synth *s, s2r_voice_state *voices) {
     if (!s || !voices) return S2R_ERR_INVALID;
     S2R_QUIESCE(s);
+    if (!s->parent) fold_frame0_records(s);
     if (!s->kids.empty()) {                       // pool order: every shard's voices put back where the pool has them
         std::vector<s2r_voice_state> tmp;
         for (s2r_synth *kid : s->kids) {
@@ -2304,6 +2349,7 @@ int s2r_export_state(s2r_synth *s, s2r_voice_state *voices) {
 int s2r_import_state(s2r_synth *s, const s2r_voice_state *voices) {
     if (!s || !voices) return S2R_ERR_INVALID;
     S2R_QUIESCE(s);
+    if (!s->parent) fold_frame0_records(s);
     if (!s->kids.empty()) {
         std::vector<s2r_voice_state> tmp;
         for (s2r_synth *kid : s->kids) {
@@ -2347,6 +2393,7 @@ int s2r_set_noise_seed(s2r_synth *s, uint32_t voice_index, uint32_t seed) {
     if (!s || s->parent || voice_index >= s->pool->size()) return S2R_ERR_INVALID;
     s->seed_override[voice_index] = seed;
     S2R_QUIESCE(s);
+    fold_frame0_records(s);
     uint32_t local = 0;
     s2r_synth *sh = shard_of(s, voice_index, &local);
     if (sh) {
