@@ -2090,50 +2090,58 @@ int s2r_note_events(s2r_synth *s, const s2r_note_event *events, size_t n) {
     static thread_local std::vector<int64_t> chosen;
     if (chosen.size() < n) chosen.resize(n);
     static_assert(sizeof(S2rPolicyEvent) == 4 && S2R_NOTE_ON == S2R_POLICY_NOTE_ON && S2R_NOTE_OFF == S2R_POLICY_NOTE_OFF, "s2r_note_event's first four bytes");
-    // (with worker threads the policy runs over the whole batch first; without — the default — event by event inside the loop
-    // that builds the records, whose own memory traffic then hides behind the policy's: measured 3-4 us per 2 048 events)
-    const bool batch_first = s->pool->workers() > 0 && n >= 4096;
-    if (n && batch_first) s->fill_time = s->pool->resolve_batch(reinterpret_cast<const S2rPolicyEvent *>(events), sizeof(s2r_note_event), n, s->fill_time,
-                                                                chosen.data(), &events[0].velocity, sizeof(s2r_note_event));
+    // The policy runs over the whole batch first (its note_on runs and note_off runs are loops of their own), the records are
+    // built behind it.
+    if (n) s->fill_time = s->pool->resolve_batch(reinterpret_cast<const S2rPolicyEvent *>(events), sizeof(s2r_note_event), n, s->fill_time,
+                                                 chosen.data(), &events[0].velocity, sizeof(s2r_note_event));
+    // An event at frame 0 takes effect before the next fill.  A small batch's are FOLDED per voice (push_event: one record per
+    // touched voice, which can ride in the render kernel's arguments); a big batch's — and whatever follows records already
+    // waiting on the shard — go straight into the voices' chains as frame-0 records, which is where the folded ones of a fill
+    // with chains end up anyway (merge_pending_into_chains), without the fold's lookup per event and the merge's pass per fill.
+    const bool may_fold = n <= S2R_ARG_MAX_EVENTS;
+    const int64_t *vi_of = chosen.data();
+    const float *pitch_of = s->pitch_table;
+    const uint32_t *seed_of = s->seed_override.data();
+    s2r_synth *one = s->kids.empty() ? s : nullptr;             // (not a device list: every record is this handle's own)
+    if (one) one->tpending.reserve(one->tpending.size() + n);
+    uint32_t double_release = 0;
     for (size_t k = 0; k < n; k++) {
         const s2r_note_event &e = events[k];
         if (e.kind == S2R_PROGRAM_CHANGE) {      // host-side state: which patch the following note_ons get
             s->program = e.note;
             continue;
         }
-        const uint32_t frame = e.frame;
-        if (!batch_first) {
-            if (frame > s->fill_time) { s->pool->advance(frame - s->fill_time); s->fill_time = frame; }
-            chosen[k] = e.kind == S2R_NOTE_ON ? (int64_t)s->pool->note_on(e.note, e.velocity) : s->pool->note_off(e.note);
-        }
-        const int64_t vi = chosen[k];
-        if (vi < 0) { s->double_release++; continue; }           // synth.rs:77 logs "double release" and carries on
+        const int64_t vi = vi_of[k];
+        if (vi < 0) { double_release++; continue; }              // synth.rs:77 logs "double release" and carries on
         uint32_t local = 0;
-        s2r_synth *sh = shard_of(s, (uint32_t)vi, &local);
-        if (!sh) continue;
-        // An event at frame 0 takes effect before the next fill.  A small batch's are FOLDED per voice (push_event: one record per
-        // touched voice, which can ride in the render kernel's arguments); a big batch's — and whatever follows records already
-        // waiting on the shard — go straight into the voices' chains as frame-0 records, which is where the folded ones of a fill
-        // with chains end up anyway (merge_pending_into_chains), without the fold's lookup per event and the merge's pass per fill.
-        if (frame == 0 && n <= S2R_ARG_MAX_EVENTS && sh->tpending.empty()) {
-            if (e.kind == S2R_NOTE_ON) push_event(s, (uint32_t)vi, S2R_EV_RESTART, s->pitch_table[e.note], s->seed_override[(size_t)vi], s->program);
+        s2r_synth *sh;
+        if (one) {
+            const int64_t mine = to_local(one, (uint32_t)vi);
+            if (mine < 0) continue;                              // (another rank's voice)
+            local = (uint32_t)mine; sh = one;
+        } else {
+            sh = shard_of(s, (uint32_t)vi, &local);
+            if (!sh) continue;
+        }
+        const uint32_t frame = e.frame;
+        const bool on = e.kind == S2R_NOTE_ON;
+        if (frame == 0 && may_fold && sh->tpending.empty()) {
+            if (on) push_event(s, (uint32_t)vi, S2R_EV_RESTART, pitch_of[e.note], seed_of[(size_t)vi], s->program);
             else push_event(s, (uint32_t)vi, S2R_EV_RELEASE, 0.0f, 0u);
             continue;
         }
-        uint32_t fl; float pitch = 0.0f; uint32_t seed = 0;
-        if (e.kind == S2R_NOTE_ON) { fl = S2R_EV_RESTART; pitch = s->pitch_table[e.note]; seed = s->seed_override[(size_t)vi]; }
-        else fl = S2R_EV_RELEASE;
         // (no capacity limit here: the device-side buffers grow in flush_events when a fill brings more timed
         // events than they hold)
-        const int32_t idx = (int32_t)sh->tpending.size();
-        S2rTimedEvent te{};
-        te.voice = local; te.frame = frame; te.flags = fl; te.pitch = pitch; te.seed = seed; te.next = -1;
-        te.program = s->program;
-        if (sh->tlast[local] >= 0) sh->tpending[(size_t)sh->tlast[local]].next = idx;
-        else te.flags |= S2R_TEV_FIRST;
-        sh->tlast[local] = idx;
-        sh->tpending.push_back(te);
+        std::vector<S2rTimedEvent> &tp = sh->tpending;
+        const int32_t idx = (int32_t)tp.size();
+        int32_t *last = &sh->tlast[local];
+        uint32_t fl = on ? S2R_EV_RESTART : S2R_EV_RELEASE;
+        if (*last >= 0) tp[(size_t)*last].next = idx;
+        else fl |= S2R_TEV_FIRST;
+        *last = idx;
+        tp.push_back(S2rTimedEvent{local, frame, fl, on ? pitch_of[e.note] : 0.0f, on ? seed_of[(size_t)vi] : 0u, -1, s->program, 0u});
     }
+    s->double_release += double_release;
     return S2R_OK;
 }
 

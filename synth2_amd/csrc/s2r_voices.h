@@ -27,11 +27,13 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -62,47 +64,62 @@ struct S2rHostVoice {
     uint64_t release_clock = 0;    // pool clock at note_off
 };
 
-// A set of voice indices with "greatest member" in three word operations: a bitmap and two
-// levels of summary bits (one bit per 64-bit word below).
-class S2rIndexSet {
+// The sets of ACTIVE voices (started, not released), one per note, with "greatest member" in a few word operations: per note a
+// bitmap and two levels of summary bits (one bit per 64-bit word below), all 256 notes in ONE zero-initialised block — a set is
+// reached by address arithmetic, not through a container per note (three pointers to fetch per operation, and again after
+// every byte the policy stores: a uint8_t store may alias anything), and pages no note ever touches are never backed.
+// The summaries are kept LAZILY: set() raises them, clear() touches the bitmap alone, and a summary bit over a word that has
+// gone empty is taken down by the next search that runs into it — every stale bit is cleaned once per set() that raised it, so
+// the searches stay O(1) amortised, and a voice taken over by a note_on (the common event of a full pool) costs its old
+// note's set one word.
+class S2rNoteSets {
   public:
-    void init(uint32_t n) {
-        l0_.assign(((size_t)n + 63) / 64, 0);
-        l1_.assign((l0_.size() + 63) / 64, 0);
-        l2_.assign((l1_.size() + 63) / 64, 0);
+    S2rNoteSets() = default;
+    ~S2rNoteSets() { std::free(mem_); }
+    S2rNoteSets(const S2rNoteSets &) = delete;
+    S2rNoteSets &operator=(const S2rNoteSets &) = delete;
+    // empties every set (fresh zero pages rather than a memset over all of them)
+    void init(uint32_t n_voices) {
+        std::free(mem_);
+        w0_ = ((size_t)n_voices + 63) / 64; w1_ = (w0_ + 63) / 64; w2_ = (w1_ + 63) / 64;
+        stride_ = (w2_ + w1_ + w0_ + 7) & ~(size_t)7;
+        mem_ = static_cast<uint64_t *>(std::calloc(stride_ * 256, sizeof(uint64_t)));
+        if (!mem_) throw std::bad_alloc();
     }
-    bool ready() const { return !l0_.empty(); }
-    bool test(uint32_t i) const { return ready() && ((l0_[i >> 6] >> (i & 63)) & 1ull) != 0; }
-    void set(uint32_t i) {
-        uint64_t &w = l0_[i >> 6];
-        const bool was_empty = w == 0;
-        w |= 1ull << (i & 63);
-        if (!was_empty) return;                   // (the summaries already say so)
-        l1_[i >> 12] |= 1ull << ((i >> 6) & 63);
-        l2_[i >> 18] |= 1ull << ((i >> 12) & 63);
+    bool test(uint32_t note, uint32_t i) const { return ((l0(note)[i >> 6] >> (i & 63)) & 1ull) != 0; }
+    void set(uint32_t note, uint32_t i) {
+        uint64_t *m = mem_ + note * stride_;
+        m[i >> 18] |= 1ull << ((i >> 12) & 63);
+        m[w2_ + (i >> 12)] |= 1ull << ((i >> 6) & 63);
+        m[w2_ + w1_ + (i >> 6)] |= 1ull << (i & 63);
     }
     // removes i if it is a member (a voice taken over by a note_on may or may not still be held)
-    void clear(uint32_t i) {
-        if (!ready()) return;
-        uint64_t &w = l0_[i >> 6];
-        const uint64_t bit = 1ull << (i & 63);
-        if (!(w & bit)) return;
-        if ((w &= ~bit) != 0) return;
-        if ((l1_[i >> 12] &= ~(1ull << ((i >> 6) & 63))) != 0) return;
-        l2_[i >> 18] &= ~(1ull << ((i >> 12) & 63));
-    }
-    // greatest member or -1
-    int64_t last() const {
-        for (size_t w2 = l2_.size(); w2-- > 0;) {
-            if (!l2_[w2]) continue;
-            const size_t w1 = (w2 << 6) + (63 - (size_t)__builtin_clzll(l2_[w2]));
-            const size_t w0 = (w1 << 6) + (63 - (size_t)__builtin_clzll(l1_[w1]));
-            return (int64_t)((w0 << 6) + (63 - (size_t)__builtin_clzll(l0_[w0])));
+    void clear(uint32_t note, uint32_t i) { mem_[note * stride_ + w2_ + w1_ + (i >> 6)] &= ~(1ull << (i & 63)); }
+    // removes and returns the greatest member, or -1 (cleans the stale summary bits it meets)
+    int64_t take_last(uint32_t note) {
+        uint64_t *l2 = mem_ + note * stride_, *l1 = l2 + w2_, *l0 = l1 + w1_;
+        for (size_t w2 = w2_; w2-- > 0;) {
+            while (l2[w2]) {
+                const size_t b2 = 63 - (size_t)__builtin_clzll(l2[w2]), w1 = (w2 << 6) + b2;
+                if (!l1[w1]) { l2[w2] &= ~(1ull << b2); continue; }
+                const size_t b1 = 63 - (size_t)__builtin_clzll(l1[w1]), w0 = (w1 << 6) + b1;
+                if (!l0[w0]) { l1[w1] &= ~(1ull << b1); continue; }
+                const size_t b0 = 63 - (size_t)__builtin_clzll(l0[w0]);
+                // (its own word gone empty is cleaned here, branch-free: the next search of this note would meet it first)
+                const uint64_t left0 = l0[w0] & ~(1ull << b0);
+                l0[w0] = left0;
+                const uint64_t left1 = l1[w1] & ~((uint64_t)(left0 == 0) << b1);
+                l1[w1] = left1;
+                l2[w2] &= ~((uint64_t)(left1 == 0) << b2);
+                return (int64_t)((w0 << 6) + b0);
+            }
         }
         return -1;
     }
   private:
-    std::vector<uint64_t> l0_, l1_, l2_;
+    const uint64_t *l0(uint32_t note) const { return mem_ + note * stride_ + w2_ + w1_; }
+    uint64_t *mem_ = nullptr;
+    size_t w0_ = 0, w1_ = 0, w2_ = 0, stride_ = 0;
 };
 
 // one event of a batch as resolve_batch sees it (s2r_note_event's first four bytes)
@@ -120,7 +137,7 @@ class S2rVoicePool {
     uint64_t clock() const { return now_; }
     S2rHostVoice voice(uint32_t i) const {
         S2rHostVoice v;
-        v.note = note_[i]; v.started = started_[i] != 0; v.released = v.started && !active_[v.note].test(i);
+        v.note = note_[i]; v.started = started_[i] != 0; v.released = v.started && !active_.test(v.note, i);
         v.velocity = velocity_[i]; v.start_clock = start_[i]; v.release_clock = v.released ? release_[i] : 0;
         return v;
     }
@@ -135,18 +152,15 @@ class S2rVoicePool {
     uint32_t note_on(uint8_t note, float velocity) {
         uint8_t old_note; bool was_started;
         const uint32_t i = take_voice(note, velocity, &old_note, &was_started);
-        if (was_started) active_[old_note].clear(i);           // stolen, possibly while still held
-        mark_active(note, i);
+        if (was_started) active_.clear(old_note, i);            // stolen, possibly while still held
+        active_.set(note, i);
         return i;
     }
 
     // synth.rs:72-96; returns the released index or -1 when no active voice holds `note`
     int64_t note_off(uint8_t note) {
-        S2rIndexSet &a = active_[note];
-        if (!a.ready()) return -1;
-        const int64_t i = a.last();
+        const int64_t i = active_.take_last(note);
         if (i < 0) return -1;
-        a.clear((uint32_t)i);
         release_[(size_t)i] = now_;
         return i;
     }
@@ -160,16 +174,27 @@ class S2rVoicePool {
     // the last event's frame (>= t0).  Batches of at least `mt_threshold` events are resolved by the worker threads.
     uint32_t resolve_batch(const S2rPolicyEvent *ev, size_t stride_bytes, size_t n, uint32_t t0, int64_t *voice_out, const float *velocity = nullptr,
                            size_t velocity_stride = 0) {
-        if (n >= mt_threshold_ && workers_wanted_ > 0) return resolve_mt(ev, stride_bytes, n, t0, voice_out, velocity, velocity_stride);
+        if (n >= mt_threshold_ && workers_wanted_ > 0 && n_ <= (1u << kHandoverVoiceBits)) return resolve_mt(ev, stride_bytes, n, t0, voice_out, velocity, velocity_stride);
+        // One thread: the note_ons that follow one another at one clock are resolved as a RUN (note_on_run: the queue handed
+        // out by the bucket instead of popped and pushed per event — most of what an event cost), the rest one by one.
+        const char *base = reinterpret_cast<const char *>(ev);
+        const char *vbase = reinterpret_cast<const char *>(velocity);
         uint32_t t = t0;
-        for (size_t k = 0; k < n; k++) {
-            const S2rPolicyEvent &e = *reinterpret_cast<const S2rPolicyEvent *>(reinterpret_cast<const char *>(ev) + k * stride_bytes);
+        size_t k = 0;
+        while (k < n) {
+            const S2rPolicyEvent &e = *reinterpret_cast<const S2rPolicyEvent *>(base + k * stride_bytes);
             if (e.frame > t) { now_ += e.frame - t; t = e.frame; }
             if (e.kind == S2R_POLICY_NOTE_ON) {
-                const float vel = velocity ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(velocity) + k * velocity_stride) : 1.0f;
-                voice_out[k] = note_on(e.note, vel);
-            } else if (e.kind == S2R_POLICY_NOTE_OFF) voice_out[k] = note_off(e.note);
-            else voice_out[k] = -1;
+                size_t r = k + 1;
+                while (r < n) {
+                    const S2rPolicyEvent &f = *reinterpret_cast<const S2rPolicyEvent *>(base + r * stride_bytes);
+                    if (f.kind != S2R_POLICY_NOTE_ON || f.frame > t) break;
+                    r++;
+                }
+                note_on_run(base, stride_bytes, vbase, velocity_stride, k, r, voice_out);
+                k = r;
+            } else if (e.kind == S2R_POLICY_NOTE_OFF) k = note_off_run(base, stride_bytes, k, n, t, voice_out);
+            else voice_out[k++] = -1;
         }
         return t;
     }
@@ -177,6 +202,7 @@ class S2rVoicePool {
     void set_workers(uint32_t n_workers, size_t threshold = 4096) {
         if (n_workers != workers_wanted_) stop_workers();
         workers_wanted_ = n_workers > 16u ? 16u : n_workers; mt_threshold_ = threshold;
+        for (uint32_t n = 0; n < 256; n++) owner_[n] = (uint8_t)(n % (workers_wanted_ + 1u));     // (partition 0 is the caller's)
     }
     uint32_t workers() const { return workers_wanted_; }
 
@@ -205,7 +231,7 @@ class S2rVoicePool {
     void rebuild() {
         // (a voice set_voice did not touch keeps its state: released or not is read off the sets before they are rebuilt)
         std::vector<uint8_t> rel(n_, 0);
-        for (uint32_t i = 0; i < n_; i++) rel[i] = (started_[i] && !active_[note_[i]].test(i)) ? 1 : 0;
+        for (uint32_t i = 0; i < n_; i++) rel[i] = (started_[i] && !active_.test(note_[i], i)) ? 1 : 0;
         for (const auto &p : pending_) rel[p.i] = p.released ? 1 : 0;
         if (now_ < pending_min_clock_) {
             // shift the whole time base forward so no start_clock underflows; offsets are unchanged
@@ -223,11 +249,11 @@ class S2rVoicePool {
         idle_.clear(); idle_head_ = 0;
         buckets_.clear(); ring_.clear(); ring_head_ = 0;
         std::vector<std::pair<uint64_t, uint32_t>> all;
-        for (int n = 0; n < 256; n++) active_[n] = S2rIndexSet();
+        active_.init(n_);
         for (uint32_t i = 0; i < n_; i++) {
             if (!started_[i]) { idle_.push_back(i); continue; }
             all.push_back({start_[i], i});
-            if (!rel[i]) mark_active(note_[i], i);
+            if (!rel[i]) active_.set(note_[i], i);
         }
         std::sort(all.begin(), all.end());
         for (const auto &e : all) push(e.first, e.second);
@@ -282,86 +308,167 @@ class S2rVoicePool {
         return i;
     }
 
-    // active = started and not yet released; one index set per note, created on first use
-    void mark_active(uint8_t note, uint32_t i) {
-        S2rIndexSet &a = active_[note];
-        if (!a.ready()) a.init(n_);
-        a.set(i);
+    // Events [k, r) of a batch: note_ons at the present clock.  The same choices as r - k calls of note_on: idle voices in index
+    // order, then the queue's front — whole stretches of the front buckets, each sorted once — and every taken voice goes to the
+    // back of the queue at the present clock.  (Once the front bucket IS the present clock's — every voice of the pool taken at
+    // this very clock — the rest of the run goes through note_on, whose re-queueing rule is a case of its own.)
+    // SETS = false (phase A of the threaded form): the sets are left alone; h[k] = the voice | the note it held << 23 (256: none).
+    template <bool SETS = true>
+    void note_on_run(const char *ev, size_t stride, const char *vel, size_t vstride, size_t k, size_t r, int64_t *voice_out, uint32_t *h = nullptr) {
+        while (k < r) {
+            const bool stolen = idle_head_ >= idle_.size();
+            if (stolen && (buckets_.empty() || buckets_.front().clock == now_)) break;
+            // where the stretch goes: the back of the queue, at the present clock (push() for a stretch; before the stretch is
+            // looked at, because making room may move the ring)
+            if (buckets_.empty() || buckets_.back().clock != now_) {
+                if (ring_head_ > ring_.size() / 2 + 1024 && ring_.size() >= 4096) compact();
+                buckets_.push_back(Bucket{now_, ring_.size(), ring_.size(), true});
+            }
+            size_t c, from;
+            if (!stolen) { from = idle_head_; c = std::min(r - k, idle_.size() - idle_head_); }
+            else { front(); const Bucket &b = buckets_.front(); from = b.begin; c = std::min(r - k, b.end - b.begin); }   // (front() sorts the bucket if it has to)
+            const size_t at = ring_.size();
+            ring_.resize(at + c);
+            const uint32_t *src = stolen ? ring_.data() + from : idle_.data() + from;
+            // (locals: the bytes stored below may alias anything the compiler has to fetch through `this`)
+            uint8_t *note_of = note_.data(), *started = started_.data();
+            float *velocity = velocity_.data();
+            uint64_t *start = start_.data();
+            const uint64_t now = now_;
+            const char *e = ev + k * stride, *v = vel ? vel + k * vstride : nullptr;
+            int64_t *out = voice_out + k;
+            for (size_t q = 0; q < c; q++, e += stride) {
+                const uint32_t i = src[q];
+                const uint8_t note = reinterpret_cast<const S2rPolicyEvent *>(e)->note;
+                if (!SETS) h[k + q] = i | (stolen ? (uint32_t)note_of[i] : 256u) << kHandoverVoiceBits;
+                if (!stolen) started[i] = 1;
+                else if (SETS) active_.clear(note_of[i], i);               // taken over, possibly while still held
+                note_of[i] = note; start[i] = now;
+                if (v) { velocity[i] = *reinterpret_cast<const float *>(v); v += vstride; } else velocity[i] = 1.0f;
+                if (SETS) active_.set(note, i);
+                out[q] = i;
+            }
+            // a stretch is ascending (idle voices by index, a sorted bucket's part); the bucket it joins may end above its start
+            Bucket &back = buckets_.back();
+            if (back.end > back.begin && src[0] < ring_[back.end - 1]) back.sorted = false;
+            std::memcpy(ring_.data() + at, src, c * sizeof(uint32_t));
+            back.end = at + c;
+            if (!stolen) idle_head_ += c;
+            else {
+                Bucket &b = buckets_.front();
+                ring_head_ = (b.begin += c);
+                if (b.begin == b.end) buckets_.pop_front();
+            }
+            k += c;
+        }
+        for (; k < r; k++) {
+            const S2rPolicyEvent &e = *reinterpret_cast<const S2rPolicyEvent *>(ev + k * stride);
+            const float velocity = vel ? *reinterpret_cast<const float *>(vel + k * vstride) : 1.0f;
+            if (SETS) voice_out[k] = note_on(e.note, velocity);
+            else {
+                uint8_t old; bool was;
+                const uint32_t i = take_voice(e.note, velocity, &old, &was);
+                voice_out[k] = i; h[k] = i | (was ? (uint32_t)old : 256u) << kHandoverVoiceBits;
+            }
+        }
+    }
+    // Events [k, ...) of a batch while they are note_offs: returns the first that is not (or n).  `t`: the frames the clock has
+    // moved inside the fill.
+    size_t note_off_run(const char *ev, size_t stride, size_t k, size_t n, uint32_t &t, int64_t *voice_out) {
+        uint64_t now = now_;
+        uint32_t tt = t;
+        uint64_t *release = release_.data();
+        const char *e = ev + k * stride;
+        for (; k < n; k++, e += stride) {
+            const S2rPolicyEvent &x = *reinterpret_cast<const S2rPolicyEvent *>(e);
+            if (x.kind != S2R_POLICY_NOTE_OFF) break;
+            if (x.frame > tt) { now += x.frame - tt; tt = x.frame; }
+            const int64_t i = active_.take_last(x.note);
+            voice_out[k] = i;
+            if (i >= 0) release[(size_t)i] = now;
+        }
+        now_ = now; t = tt;
+        return k;
     }
 
     // ---- resolve_batch on several threads ----
-    // What phase A hands to the workers, one 8-byte word per event, written once by the caller's thread and only read by the
-    // others (no line is written from two cores): the voice a note_on took, the note it held (256: none).  The workers' own
-    // results — the voices their note_offs released — go to lists of their own and are put in place by the caller afterwards:
-    // results written straight into the caller's array, a worker's note_offs next to the caller's note_ons, made every event a
-    // cache line bouncing between cores (measured: the threaded form five times SLOWER than one thread).
-    struct Handover { uint32_t voice; uint16_t old_note; uint16_t pad; };
+    // FORK-JOIN, in two phases.  Phase A, the caller alone: the queue — every note_on's voice, the note that voice held (what
+    // note_on_run computes, without the sets) — for the whole batch.  Phase B, the caller and the workers side by side, each
+    // owning the notes n with owner_[n] == its number: the batch replayed against its own notes' sets (a note_on's voice into
+    // the new note's set and out of the old note's, a note_off's search).  Phase A's hand-over is one 32-bit word per event,
+    // complete before anybody reads it: the first threaded form streamed it to the workers WHILE phase A wrote it, and every
+    // line made the trip between cores while still being written (measured: 2-5x slower than one thread).  The workers'
+    // results — the voices their note_offs released — go to lists of their own and are put in place by the caller afterwards
+    // (written straight into the caller's array, a worker's note_offs next to another's, they were bouncing lines again).
+    static constexpr uint32_t kHandoverVoiceBits = 23;         // (larger pools: one thread)
     struct Job {
         const char *ev = nullptr; size_t stride = 0, n = 0;
         uint32_t t0 = 0; uint64_t now0 = 0;
-        std::vector<Handover> h;
+        std::vector<uint32_t> h;                               // voice | old note << 23 (old note 256: the voice was idle)
     };
     uint32_t resolve_mt(const S2rPolicyEvent *ev, size_t stride, size_t n, uint32_t t0, int64_t *voice_out, const float *velocity, size_t velocity_stride) {
         start_workers();
         Job &j = job_;
         j.ev = reinterpret_cast<const char *>(ev); j.stride = stride; j.n = n;
-        for (size_t k = 0; k < n; k++) {                          // (no set is created while the workers run)
-            const S2rPolicyEvent &e = *reinterpret_cast<const S2rPolicyEvent *>(j.ev + k * stride);
-            if (e.kind == S2R_POLICY_NOTE_ON && !active_[e.note].ready()) active_[e.note].init(n_);
-        }
         if (j.h.size() < n) j.h.resize(n);
         j.t0 = t0; j.now0 = now_;
-        a_done_.store(0, std::memory_order_relaxed);
-        generation_.fetch_add(1, std::memory_order_release);
-        wake_workers();
-        // phase A, this thread: the queue.  Published to the workers every 128 events.
+        // phase A
+        const char *vbase = reinterpret_cast<const char *>(velocity);
         uint32_t t = t0;
-        for (size_t k = 0; k < n; k++) {
+        size_t k = 0;
+        while (k < n) {
             const S2rPolicyEvent &e = *reinterpret_cast<const S2rPolicyEvent *>(j.ev + k * stride);
             if (e.frame > t) { now_ += e.frame - t; t = e.frame; }
             if (e.kind == S2R_POLICY_NOTE_ON) {
-                const float vel = velocity ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(velocity) + k * velocity_stride) : 1.0f;
-                uint8_t old; bool was;
-                const uint32_t i = take_voice(e.note, vel, &old, &was);
-                voice_out[k] = i;
-                j.h[k] = Handover{i, (uint16_t)(was ? old : 256u), 0};
-            } else voice_out[k] = -1;
-            if ((k & 255u) == 255u) a_done_.store(k + 1, std::memory_order_release);
+                size_t r = k + 1;
+                while (r < n) {
+                    const S2rPolicyEvent &f = *reinterpret_cast<const S2rPolicyEvent *>(j.ev + r * stride);
+                    if (f.kind != S2R_POLICY_NOTE_ON || f.frame > t) break;
+                    r++;
+                }
+                note_on_run<false>(j.ev, stride, vbase, velocity_stride, k, r, voice_out, j.h.data());
+                k = r;
+            } else voice_out[k++] = -1;
         }
-        a_done_.store(n, std::memory_order_release);
+        // phase B
+        generation_.fetch_add(1, std::memory_order_release);
+        wake_workers();
+        replay_sets(0);
         for (auto &w : workers_) while (w->done.load(std::memory_order_acquire) != generation_.load(std::memory_order_relaxed)) cpu_pause();
-        // the workers' note_offs, in event order per worker, back into the caller's array
-        const uint32_t P = (uint32_t)workers_.size();
-        size_t cur[16] = {0};
-        for (size_t k = 0; k < n; k++) {
-            const S2rPolicyEvent &e = *reinterpret_cast<const S2rPolicyEvent *>(j.ev + k * stride);
-            if (e.kind == S2R_POLICY_NOTE_OFF) { const uint32_t w = e.note % P; voice_out[k] = workers_[w]->released[cur[w]++]; }
+        // the note_offs' voices, in event order per owner, back into the caller's array
+        const int64_t *from[17];
+        from[0] = released0_.data();
+        for (size_t w = 0; w < workers_.size(); w++) from[w + 1] = workers_[w]->released.data();
+        const uint8_t *owner = owner_;
+        const char *e = j.ev;
+        for (size_t q = 0; q < n; q++, e += stride) {
+            const S2rPolicyEvent &x = *reinterpret_cast<const S2rPolicyEvent *>(e);
+            if (x.kind == S2R_POLICY_NOTE_OFF) voice_out[q] = *from[owner[x.note]]++;
         }
         return t;
     }
-    // phase B, worker `me` of `P`: the sets of the notes it owns, event by event behind phase A
-    void worker_batch(uint32_t me, uint32_t P) {
+    // phase B, partition `me` (0: the caller): the sets of the notes it owns, event by event
+    void replay_sets(uint32_t me) {
         const Job &j = job_;
-        std::vector<int64_t> &rel = workers_[me]->released;
+        std::vector<int64_t> &rel = me ? workers_[me - 1]->released : released0_;
         rel.clear();
-        size_t avail = 0;
+        const uint8_t *owner = owner_;
+        const uint32_t *h = j.h.data();
         uint32_t t = j.t0; uint64_t now = j.now0;
-        for (size_t k = 0; k < j.n; k++) {
-            while (k >= avail) { avail = a_done_.load(std::memory_order_acquire); if (k >= avail) cpu_pause(); }
-            const S2rPolicyEvent &e = *reinterpret_cast<const S2rPolicyEvent *>(j.ev + k * j.stride);
-            if (e.frame > t) { now += e.frame - t; t = e.frame; }            // (the clock, as phase A moves it)
-            if (e.kind == S2R_POLICY_NOTE_ON) {
-                const Handover h = j.h[k];
-                if (h.old_note < 256u && h.old_note % P == me) active_[h.old_note].clear(h.voice);
-                if (e.note % P == me) active_[e.note].set(h.voice);
-            } else if (e.kind == S2R_POLICY_NOTE_OFF && e.note % P == me) {
-                S2rIndexSet &a = active_[e.note];
-                const int64_t i = a.ready() ? a.last() : -1;
+        const char *e = j.ev;
+        for (size_t k = 0; k < j.n; k++, e += j.stride) {
+            const S2rPolicyEvent &x = *reinterpret_cast<const S2rPolicyEvent *>(e);
+            if (x.frame > t) { now += x.frame - t; t = x.frame; }            // (the clock, as phase A moved it)
+            if (x.kind == S2R_POLICY_NOTE_ON) {
+                const uint32_t voice = h[k] & ((1u << kHandoverVoiceBits) - 1u), old = h[k] >> kHandoverVoiceBits;
+                if (old < 256u && owner[old] == me) active_.clear(old, voice);
+                if (owner[x.note] == me) active_.set(x.note, voice);
+            } else if (x.kind == S2R_POLICY_NOTE_OFF && owner[x.note] == me) {
+                const int64_t i = active_.take_last(x.note);
                 rel.push_back(i);
                 if (i >= 0) {
-                    a.clear((uint32_t)i);
-                    // The clock of the voice's LATEST release.  A voice released under this worker's note, taken over by a
-                    // later note_on and released again under another worker's note is written by both, in either order:
+                    // The clock of the voice's LATEST release.  A voice released under this partition's note, taken over by a
+                    // later note_on and released again under another partition's note is written by both, in either order:
                     // clocks only grow with the events, so the greater value is the later release's.
                     uint64_t *r = &release_[(size_t)i];
                     uint64_t cur = __atomic_load_n(r, __ATOMIC_RELAXED);
@@ -386,7 +493,7 @@ class S2rVoicePool {
             workers_.emplace_back(new Worker());
             Worker *me = workers_.back().get();
             me->done.store(generation_.load());
-            me->th = std::thread([this, me, w, P] {
+            me->th = std::thread([this, me, w] {
                 uint64_t seen = me->done.load();
                 for (;;) {
                     // spin for a while (the next batch of a caller in a loop comes within tens of microseconds), then sleep
@@ -401,7 +508,7 @@ class S2rVoicePool {
                         }
                     }
                     if (quit_.load()) return;
-                    worker_batch(w, P);
+                    replay_sets(w + 1);
                     seen = g;
                     me->done.store(g, std::memory_order_release);
                 }
@@ -427,7 +534,7 @@ class S2rVoicePool {
     mutable std::vector<uint32_t> ring_;
     size_t ring_head_ = 0;
     mutable std::deque<Bucket> buckets_;
-    S2rIndexSet active_[256];
+    S2rNoteSets active_;
     std::vector<Pending> pending_;
     uint64_t pending_min_clock_ = 0;
     uint64_t now_ = 0;
@@ -436,10 +543,11 @@ class S2rVoicePool {
     size_t mt_threshold_ = 4096;
     std::vector<std::unique_ptr<Worker>> workers_;
     std::atomic<uint64_t> generation_{0};
-    std::atomic<size_t> a_done_{0};
     std::atomic<bool> quit_{false};
     std::atomic<int> sleepers_{0};
     std::mutex mu_;
     std::condition_variable cv_;
     Job job_;
+    uint8_t owner_[256] = {0};           // which partition of the threaded form keeps a note's set
+    std::vector<int64_t> released0_;     // partition 0's note_offs
 };

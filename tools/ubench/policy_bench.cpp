@@ -67,10 +67,15 @@ int main(int argc, char **argv) {
             for (uint32_t k = 0; k < 2 * period; k++) runb(k);
             nb = 0;
             auto tb0 = std::chrono::steady_clock::now();
-            for (uint32_t k = 0; k < 4 * period; k++) runb(k);
+            double best = 1e9;                                  // (the quietest period too: a shared host's noise is one-sided)
+            for (uint32_t rep = 0; rep < 8; rep++) {
+                auto tp0 = std::chrono::steady_clock::now();
+                for (uint32_t k = 0; k < period; k++) runb(k);
+                best = std::min(best, std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count());
+            }
             const double dtb = std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count();
-            printf("%8u voices: batch, %u worker threads    %6.1f ns per event, %7.1f us per buffer  [%llu]\n", V, workers, dtb * 1e9 / nb, dtb * 1e6 / (4 * period),
-                   (unsigned long long)sink2);
+            printf("%8u voices: batch, %u worker threads    %6.1f ns per event, %7.1f us per buffer (quietest period of 8: %5.1f ns, %6.1f us)  [%llu]\n", V, workers,
+                   dtb * 1e9 / nb, dtb * 1e6 / (8 * period), best * 1e9 / (nb / 8), best * 1e6 / period, (unsigned long long)sink2);
         }
     }
     return 0;
