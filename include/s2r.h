@@ -244,11 +244,41 @@ int s2r_sum_partials_device(const float *dev_rows, uint32_t n_rows, size_t frame
  * per voice (process.rs:14-49). */
 int s2r_render_voices(s2r_synth *s, float *per_voice_out, size_t frames, uint32_t sample_rate_hz);
 
+/* The reference's lower-level public entry for callers that keep their own st::Layer:
+ *   process::process_layer_buf_simd(&sc::Layer, &mut st::Layer, Hz, SampleRateKhz, offset: u32, release_offset: Option<u32>, &mut [f32])
+ * (process.rs:14-49, pub through try3/mod.rs) — whole 16-frame chunks through process_layer_x16, the remainder through the
+ * scalar path, the state advanced in place, the offset passed by value — for n_layers independent layers side by side.
+ * static_config = the handle's patch (s2r_set_patch / s2r_load_patch; `program` picks a bank entry); bufs is [n_layers][frames].
+ * The handle is the workspace: its first n_layers voices are replaced by the layers (at offset + frames afterwards), the
+ * rest go idle — give the calls a handle of their own, sized to the batch (one device, n_layers <= total_voices).
+ * S2R_ERR_OFFSET_OVERFLOW where the reference panics (process.rs:36). */
+typedef struct {
+    float pitch_hz;                /* Hz */
+    uint32_t offset;               /* frames since the layer's note_on; by value: the caller adds `frames` (synth.rs:197) */
+    uint32_t release_offset;       /* valid when has_release */
+    uint8_t has_release;           /* Option<u32>::is_some() */
+    uint8_t program;               /* patch bank index (0 without a bank) */
+    uint8_t _pad[2];
+    /* st::Layer (state.rs:10-21), updated in place */
+    float phase_accum;             /* OscillatorState */
+    float lpf_last;                /* LowPassFilterState.last */
+    uint32_t noise_seed;           /* NoiseState.seed */
+    float filt_x1, filt_x2, filt_y1, filt_y2;   /* dsp_filters.rs kinds / SVF */
+    float osc_z;                   /* DPW oscillators (NaN: none yet) */
+} s2r_layer_call;
+int s2r_process_layers(s2r_synth *s, s2r_layer_call *layers, uint32_t n_layers, float *bufs, size_t frames, uint32_t sample_rate_hz);
+
 /* Checkpoint / resume and test access; `voices` has shard_voices entries. */
 int s2r_export_state(s2r_synth *s, s2r_voice_state *voices);
 int s2r_import_state(s2r_synth *s, const s2r_voice_state *voices);
 /* NoiseState.seed of one pool voice ("todo don't default this", state.rs:19). */
 int s2r_set_noise_seed(s2r_synth *s, uint32_t voice_index, uint32_t seed);
+
+/* Synth::next_voice's `log::debug!("using new voice index {} for note {}", …)` (synth.rs:118) as a callback: called once
+ * per note_on (s2r_note_on, s2r_note_on_ex, every note_on of s2r_note_events, in event order) with the voice the allocation
+ * policy chose.  NULL switches it off (the default).  Not on the shards of a device list (their parent's pool decides). */
+typedef void (*s2r_voice_log_fn)(void *user, uint32_t voice_index, uint8_t note);
+int s2r_set_voice_log(s2r_synth *s, s2r_voice_log_fn fn, void *user);
 
 /* Introspection */
 uint32_t s2r_abi_version(void);

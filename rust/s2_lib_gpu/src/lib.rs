@@ -87,6 +87,26 @@ pub mod ffi {
         _private: [u8; 0],
     }
 
+    /// include/s2r.h `s2r_layer_call`: one call of process::process_layer_buf_simd (process.rs:14-22), st::Layer in place
+    #[repr(C)]
+    #[derive(Copy, Clone)]
+    pub struct S2rLayerCall {
+        pub pitch_hz: f32,
+        pub offset: u32,
+        pub release_offset: u32,
+        pub has_release: u8,
+        pub program: u8,
+        pub _pad: [u8; 2],
+        pub phase_accum: f32,
+        pub lpf_last: f32,
+        pub noise_seed: u32,
+        pub filt_x1: f32,
+        pub filt_x2: f32,
+        pub filt_y1: f32,
+        pub filt_y2: f32,
+        pub osc_z: f32,
+    }
+
     /// include/s2r.h `s2r_note_event`: `frame` = 0 or the 16-frame boundary inside the next fill
     #[repr(C)]
     #[derive(Copy, Clone)]
@@ -126,6 +146,8 @@ pub mod ffi {
         pub fn s2r_quiesce(s: *mut S2rSynth) -> c_int;
         pub fn s2r_exchange_create(s: *mut S2rSynth, n_ranks: u32, handle_out: *mut c_void, handle_bytes: usize) -> c_int;
         pub fn s2r_exchange_attach(s: *mut S2rSynth, rank: u32, n_ranks: u32, handle: *const c_void, handle_bytes: usize) -> c_int;
+        pub fn s2r_process_layers(s: *mut S2rSynth, layers: *mut S2rLayerCall, n_layers: u32, bufs: *mut f32, frames: usize, sample_rate_hz: u32) -> c_int;
+        pub fn s2r_set_voice_log(s: *mut S2rSynth, f: Option<extern "C" fn(*mut c_void, u32, u8)>, user: *mut c_void) -> c_int;
         pub fn s2r_build_id() -> *const c_char;
         pub fn s2r_last_error(s: *const S2rSynth) -> *const c_char;
         pub fn s2r_status_string(status: c_int) -> *const c_char;
@@ -337,6 +359,20 @@ pub mod synth {
         /// how many GPUs render this Synth
         pub fn device_count(&self) -> u32 {
             unsafe { ffi::s2r_device_count(self.handle) }
+        }
+
+        /// `log::debug!("using new voice index {} for note {}", …)` of `next_voice` (synth.rs:118) through the `log` facade's
+        /// place: `f(voice_index, note)` per note_on.  `None` switches it off.
+        pub fn set_voice_log(&mut self, f: Option<extern "C" fn(*mut std::os::raw::c_void, u32, u8)>) {
+            self.check(unsafe { ffi::s2r_set_voice_log(self.handle, f, std::ptr::null_mut()) });
+        }
+
+        /// process::process_layer_buf_simd (process.rs:14-49) for layers the caller keeps itself, `layers.len()` of them side
+        /// by side: this Synth is the workspace (its patch is the `sc::Layer`, its voices are replaced), `bufs` is
+        /// `[layers.len()][frames]`, every `S2rLayerCall`'s state fields are advanced in place.
+        pub fn process_layers(&mut self, layers: &mut [ffi::S2rLayerCall], bufs: &mut [f32], frames: usize, sample_rate: SampleRateKhz) {
+            assert!(bufs.len() >= layers.len() * frames);
+            self.check(unsafe { ffi::s2r_process_layers(self.handle, layers.as_mut_ptr(), layers.len() as u32, bufs.as_mut_ptr(), frames, sample_rate.0) });
         }
     }
 

@@ -268,6 +268,8 @@ struct s2r_synth {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool timing = false, timed = false, no_flat_shortcut = false;
     uint64_t double_release = 0;
+    s2r_voice_log_fn voice_log = nullptr;    // synth.rs:118's log::debug!, as a callback
+    void *voice_log_user = nullptr;
     // A kernel that gave up a bounded wait for another kernel's (or workgroup's) work left the fill unrendered — it touches
     // neither the voices' state nor the chain heads then — while the host's pool clock and event bookkeeping had moved on:
     // the handle says so from then on instead of rendering something else than what its caller believes (import a checkpoint
@@ -2041,6 +2043,7 @@ int s2r_note_on_ex(s2r_synth *s, uint8_t note, float velocity, uint32_t *voice_i
     if (s->fill_time) return set_err(s, S2R_ERR_INVALID, "untimed note_on after timed events: fill first or give it a frame");
     const uint32_t i = s->pool->note_on(note, velocity);
     if (voice_index_out) *voice_index_out = i;
+    if (s->voice_log) s->voice_log(s->voice_log_user, i, note);
     if (!append_frame0_record(s, i, S2R_EV_RESTART, s->pitch_table[note], s->seed_override[i], s->program))
         push_event(s, i, S2R_EV_RESTART, s->pitch_table[note], s->seed_override[i], s->program);
     return S2R_OK;
@@ -2098,6 +2101,8 @@ int s2r_note_events(s2r_synth *s, const s2r_note_event *events, size_t n) {
     // touched voice, which can ride in the render kernel's arguments); a big batch's — and whatever follows records already
     // waiting on the shard — go straight into the voices' chains as frame-0 records, which is where the folded ones of a fill
     // with chains end up anyway (merge_pending_into_chains), without the fold's lookup per event and the merge's pass per fill.
+    if (s->voice_log)
+        for (size_t k = 0; k < n; k++) if (events[k].kind == S2R_NOTE_ON) s->voice_log(s->voice_log_user, (uint32_t)chosen[k], events[k].note);
     const bool may_fold = n <= S2R_ARG_MAX_EVENTS;
     const int64_t *vi_of = chosen.data();
     const float *pitch_of = s->pitch_table;
@@ -2394,6 +2399,51 @@ int s2r_import_state(s2r_synth *s, const s2r_voice_state *voices) {
     s->pool->rebuild();
     S2R_HIP(s, hipMemcpyAsync(s->voice_mem, h.data(), pv * kVoiceWords * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
     S2R_HIP(s, hipStreamSynchronize(s->stream));
+    return S2R_OK;
+}
+
+int s2r_set_voice_log(s2r_synth *s, s2r_voice_log_fn fn, void *user) {
+    if (!s || s->parent) return S2R_ERR_INVALID;
+    s->voice_log = fn; s->voice_log_user = user;
+    return S2R_OK;
+}
+
+// process::process_layer_buf_simd (process.rs:14-49) for layers the caller keeps itself: the handle's first n voices become the
+// layers (checkpoint in), one fill of per-voice rows, the layers' states come back (checkpoint out).
+int s2r_process_layers(s2r_synth *s, s2r_layer_call *layers, uint32_t n_layers, float *bufs, size_t frames, uint32_t sample_rate_hz) {
+    if (!s || s->parent || (!layers && n_layers)) return S2R_ERR_INVALID;
+    const uint32_t total = s->pool->size();
+    if (!s->kids.empty() || s->shard_voices != total) return set_err(s, S2R_ERR_INVALID, "s2r_process_layers takes a handle that holds its whole pool on one device");
+    if (n_layers > total) return set_err(s, S2R_ERR_INVALID, "%u layers, the handle has %u voices", n_layers, total);
+    if (n_layers && frames && !bufs) return set_err(s, S2R_ERR_INVALID, "null output buffer");
+    for (uint32_t i = 0; i < n_layers; i++)                     // process.rs:36: `offset.checked_add(16).expect("overflow")`
+        if ((uint64_t)layers[i].offset + frames > 0xffffffffull) return set_err(s, S2R_ERR_OFFSET_OVERFLOW, "layer %u: offset %u + %zu frames overflows u32 (process.rs:36)", i, layers[i].offset, frames);
+    std::vector<s2r_voice_state> st(total);
+    std::memset(st.data(), 0, st.size() * sizeof(s2r_voice_state));
+    for (uint32_t i = 0; i < n_layers; i++) {
+        const s2r_layer_call &c = layers[i];
+        s2r_voice_state &v = st[i];
+        v.started = 1; v.released = c.has_release ? 1 : 0; v.program = c.program;
+        v.current_frame_offset = c.offset; v.release_frame_offset = c.has_release ? c.release_offset : 0u;
+        v.pitch_hz = c.pitch_hz; v.phase_accum = c.phase_accum; v.lpf_last = c.lpf_last; v.noise_seed = c.noise_seed; v.velocity = 1.0f;
+        v.filt_x1 = c.filt_x1; v.filt_x2 = c.filt_x2; v.filt_y1 = c.filt_y1; v.filt_y2 = c.filt_y2; v.osc_z = c.osc_z;
+    }
+    int rc = s2r_import_state(s, st.data());
+    if (rc != S2R_OK) return rc;
+    if (frames && n_layers) {
+        std::vector<float> rows((size_t)total * frames);
+        rc = s2r_render_voices(s, rows.data(), frames, sample_rate_hz);
+        if (rc != S2R_OK) return rc;
+        std::memcpy(bufs, rows.data(), (size_t)n_layers * frames * sizeof(float));
+    }
+    rc = s2r_export_state(s, st.data());
+    if (rc != S2R_OK) return rc;
+    for (uint32_t i = 0; i < n_layers; i++) {
+        s2r_layer_call &c = layers[i];
+        const s2r_voice_state &v = st[i];
+        c.phase_accum = v.phase_accum; c.lpf_last = v.lpf_last; c.noise_seed = v.noise_seed;
+        c.filt_x1 = v.filt_x1; c.filt_x2 = v.filt_x2; c.filt_y1 = v.filt_y1; c.filt_y2 = v.filt_y2; c.osc_z = v.osc_z;
+    }
     return S2R_OK;
 }
 

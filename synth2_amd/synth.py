@@ -83,6 +83,13 @@ VOICE_STATE_DTYPE = np.dtype([("note", np.uint8), ("started", np.uint8), ("relea
                               ("filt_x1", np.float32), ("filt_x2", np.float32), ("filt_y1", np.float32), ("filt_y2", np.float32),
                               ("osc_z", np.float32)])
 assert VOICE_STATE_DTYPE.itemsize == C.sizeof(VoiceState)
+LAYER_CALL_DTYPE = np.dtype([("pitch_hz", np.float32), ("offset", np.uint32), ("release_offset", np.uint32),
+                             ("has_release", np.uint8), ("program", np.uint8), ("_pad", np.uint8, (2,)),
+                             ("phase_accum", np.float32), ("lpf_last", np.float32), ("noise_seed", np.uint32),
+                             ("filt_x1", np.float32), ("filt_x2", np.float32), ("filt_y1", np.float32), ("filt_y2", np.float32),
+                             ("osc_z", np.float32)])
+assert LAYER_CALL_DTYPE.itemsize == 48
+VOICE_LOG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint8)
 NOTE_EVENT_DTYPE = np.dtype([("kind", np.uint8), ("note", np.uint8), ("frame", np.uint16), ("velocity", np.float32)])
 assert NOTE_EVENT_DTYPE.itemsize == 8
 
@@ -161,6 +168,8 @@ def load_library():
         "s2r_fill_device_root": (C.c_int, [H, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
         "s2r_sum_partials_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_size_t, C.c_void_p, C.c_void_p]),
         "s2r_render_voices": (C.c_int, [H, _f32p, C.c_size_t, C.c_uint32]),
+        "s2r_process_layers": (C.c_int, [H, C.c_void_p, C.c_uint32, _f32p, C.c_size_t, C.c_uint32]),
+        "s2r_set_voice_log": (C.c_int, [H, VOICE_LOG_FN, C.c_void_p]),
         "s2r_export_state": (C.c_int, [H, C.c_void_p]),
         "s2r_import_state": (C.c_int, [H, C.c_void_p]),
         "s2r_set_noise_seed": (C.c_int, [H, C.c_uint32, C.c_uint32]),
@@ -421,6 +430,19 @@ class Synth:
         """Final (root-added) mix of a single-shard synth into device memory (async)."""
         self._check(self.L.s2r_fill_device_root(self.h, C.c_void_p(dev_ptr), frames, int(sample_rate),
                                                 C.c_void_p(stream) if stream else None))
+
+    def process_layers(self, layers, frames, sample_rate=SampleRateKhz(48000)):
+        """process::process_layer_buf_simd (process.rs:14-49) for layers the caller keeps: `layers` (LAYER_CALL_DTYPE) is
+        updated in place (the st::Layer fields); returns (n_layers, frames) float32.  The handle is the workspace."""
+        assert layers.dtype == LAYER_CALL_DTYPE and layers.flags["C_CONTIGUOUS"]
+        out = np.empty((layers.size, frames), dtype=np.float32)
+        self._check(self.L.s2r_process_layers(self.h, layers.ctypes.data, layers.size, out.ctypes.data_as(_f32p), frames, int(sample_rate)))
+        return out
+
+    def set_voice_log(self, fn):
+        """synth.rs:118's log::debug! as a callback fn(voice_index, note) per note_on; None switches it off"""
+        self._voice_log = VOICE_LOG_FN((lambda user, i, note: fn(int(i), int(note)))) if fn else VOICE_LOG_FN()
+        self._check(self.L.s2r_set_voice_log(self.h, self._voice_log, None))
 
     # --- state ---
     def export_state(self):

@@ -4,6 +4,9 @@ kernel's, the GPU waits for the host."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+if os.environ.get("WITH_TORCH") == "1":          # (does the bench's own environment — torch loaded, its CUDA context up — cost the calls anything?)
+    import torch
+    torch.cuda.init(); torch.zeros(1, device="cuda")
 import synth2_amd as s2
 from bench import make_c3_events, FRAMES, SR, PERIOD
 
