@@ -124,6 +124,40 @@ def _compile_one(args):
     return obj
 
 
+def check_m0_contract(lib=None, texts=None):
+    """The kernels' tile stores are inline assembly that writes M0 once per chunk (tile_set_base) and reads it in sixteen
+    ds_write_addtid_b32 — with no "m0" in the clobber lists (s2r_kern_common.h says why).  That is only sound while nothing the
+    compiler emits touches M0 in those kernels, which is a property of THIS compiler on THIS code: so it is checked on the
+    disassembly of every library the build links (a compiler that starts using M0 fails the build, here and on any box that
+    builds the library, instead of corrupting the mix where the CPU tests are not run first).  Returns (M0 writes, tile
+    stores), or None when there is no llvm-objdump to ask.  `texts`: disassembly to check instead of the library's (the test of the
+    check itself)."""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("s2r_code_objects", os.path.join(ROOT, "tools", "code_objects.py"))
+    co = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(co)
+    if texts is None:
+        if not os.path.exists(co.OBJDUMP):
+            return None
+        texts = co.disassemble(lib or LIB)
+    n_set = n_store = 0
+    for text in texts:
+        lines = [l.split("//")[0].strip() for l in text.splitlines()]
+        for i, l in enumerate(lines):
+            if "ds_write_addtid_b32" in l:
+                n_store += 1
+            elif re.search(r"\bm0\b", l):
+                if not re.match(r"s_mov_b32 m0, s\d+$", l):
+                    raise RuntimeError("libs2r: the compiler uses M0 (%r): the tile stores' inline assembly is no longer safe" % l)
+                if not lines[i + 1].startswith("s_nop"):
+                    raise RuntimeError("libs2r: M0 written without the wait state in front of the LDS store (%r)" % lines[i + 1])
+                n_set += 1
+    if not n_set or n_store != 16 * n_set:
+        raise RuntimeError("libs2r: %d M0 writes for %d tile stores (sixteen per write expected)" % (n_set, n_store))
+    return n_set, n_store
+
+
 def build(force=False, verbose=False, jobs=None):
     if not force and not needs_build():
         return LIB
@@ -161,6 +195,11 @@ def build(force=False, verbose=False, jobs=None):
     subprocess.check_call(link)
     if embedded_build_id() != bid:
         raise RuntimeError("the linked library does not carry the build id %s" % bid)
+    try:
+        check_m0_contract()
+    except RuntimeError:
+        os.replace(LIB, LIB + ".rejected")                      # (never loadable under its own name)
+        raise
     return LIB
 
 

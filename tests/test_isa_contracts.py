@@ -32,18 +32,19 @@ def test_m0_is_ours_between_the_tile_stores(disassembly):
     """chunk_fast puts the wave's tile address into M0 once per chunk (tile_set_base) and then issues sixteen
     ds_write_addtid_b32 (address = M0 + offset + 4 * lane) from separate asm statements: nothing the compiler emits may
     write M0 — every M0 write in the library must be our `s_mov_b32 m0, sN` + `s_nop 0`, and nothing else may read it."""
-    n_set = n_store = 0
-    for text in disassembly:
-        lines = [l.split("//")[0].strip() for l in text.splitlines()]
-        for i, l in enumerate(lines):
-            if "ds_write_addtid_b32" in l:
-                n_store += 1
-                continue
-            if re.search(r"\bm0\b", l):
-                assert re.match(r"s_mov_b32 m0, s\d+$", l), "unexpected use of M0: %r" % l
-                assert lines[i + 1].startswith("s_nop"), "M0 write without the wait state in front of the LDS store: %r" % lines[i + 1]
-                n_set += 1
+    from synth2_amd import build as _b
+    n_set, n_store = _b.check_m0_contract()          # (what every build of the library runs on itself: synth2_amd/build.py)
     assert n_set > 0 and n_store == 16 * n_set, (n_set, n_store)
+    # ... and the check does see a violation: code that touches M0 anywhere else, or sets it without the wait state, is refused
+    k = next(i for i, t in enumerate(disassembly) if re.search(r"s_mov_b32 m0, s\d+", t))
+    lines = disassembly[k].splitlines()
+    at = next(i for i, l in enumerate(lines) if re.search(r"s_mov_b32 m0, s\d+", l))
+    assert "s_nop" in lines[at + 1]
+    elsewhere = lines[:at] + ["\ts_mov_b32 m0, exec_lo"] + lines[at:]
+    no_wait = lines[:at + 1] + ["\tv_mov_b32_e32 v0, v0"] + lines[at + 2:]
+    for bad in (elsewhere, no_wait):
+        with pytest.raises(RuntimeError):
+            _b.check_m0_contract(texts=disassembly[:k] + ["\n".join(bad)] + disassembly[k + 1:])
 
 
 def test_hot_chunk_has_no_compare_or_select(disassembly):
