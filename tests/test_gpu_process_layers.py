@@ -76,6 +76,45 @@ def test_process_layers_equals_process_layer_buf_simd(frames, patch_text):
     ws.close()
 
 
+def test_process_layers_with_a_patch_bank_and_dpw_oscillators():
+    """`program` picks the layer's sc::Layer from the handle's bank; a DPW oscillator's differentiator memory (osc_z: NaN = none yet)
+    travels with the layer like the rest of its state"""
+    rng = np.random.RandomState(77)
+    bank = [s2.parse_patch("synth a { osc.kind = dpw_saw  lpf.kind = lp2  lpf.damping = 0.9 }"),
+            s2.parse_patch("synth b { osc.kind = square  noise = 0.1 }"),
+            s2.parse_patch("synth c { osc.kind = dpw_triangle  lpf.kind = svf_bp  lpf.q = 1.5  mod_env_to_lpf_freq = 4 }")]
+    ws = s2.Synth(256, max_frames=256)
+    ws.set_patch_bank(bank)
+    n, frames = 200, 112
+    layers = _random_layers(rng, n)
+    layers["program"] = rng.randint(0, 3, n)
+    layers["phase_accum"] = 0.0                            # (a DPW voice without history starts at phase 0 like a fresh note_on)
+    L = s2o.lib()
+    for call in range(3):
+        want = np.zeros((n, frames), dtype=np.float32)
+        after = layers.copy()
+        for i in range(n):
+            c = layers[i]
+            cfg = oracle_cfg_from_patch(bank[int(c["program"])])
+            st = s2o.LayerState()
+            st.has_phase = 1; st.phase_accum = float(c["phase_accum"]); st.seed = int(c["noise_seed"]); st.lpf_last = float(c["lpf_last"])
+            st.x1, st.x2, st.y1, st.y2 = (float(c[k]) for k in ("filt_x1", "filt_x2", "filt_y1", "filt_y2"))
+            z = float(c["osc_z"])
+            st.has_z = 0 if np.isnan(z) else 1
+            st.dpw_z = 0.0 if np.isnan(z) else z
+            assert L.s2o_process_layer_buf_simd(C.byref(cfg), C.byref(st), float(c["pitch_hz"]), SR, int(c["offset"]), int(c["has_release"]),
+                                                int(c["release_offset"]), s2o._fp(want[i]), frames) == 0
+            after[i]["phase_accum"] = st.phase_accum; after[i]["lpf_last"] = st.lpf_last
+            after[i]["filt_x1"], after[i]["filt_x2"], after[i]["filt_y1"], after[i]["filt_y2"] = st.x1, st.x2, st.y1, st.y2
+            after[i]["osc_z"] = st.dpw_z if st.has_z else np.float32(np.nan)
+        got = ws.process_layers(layers, frames, SR)
+        assert_bits_equal(got, want, "call %d" % call)
+        for k in ("phase_accum", "lpf_last", "filt_x1", "filt_x2", "filt_y1", "filt_y2", "osc_z"):
+            assert_bits_equal(layers[k], after[k], "call %d: %s" % (call, k))
+        layers["offset"] += frames
+    ws.close()
+
+
 def test_process_layers_errors():
     ws = s2.Synth(256, max_frames=64)
     a = np.zeros(257, dtype=s2.LAYER_CALL_DTYPE)
