@@ -396,7 +396,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the SVF and 4x-oversampled configurations timed after the headline")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="seconds per CPU-baseline leg (three legs)")
+    ap.add_argument("--watchdog", type=float, default=float(os.environ.get("S2R_BENCH_WATCHDOG", "600")),
+                    help="seconds after which a run that has not finished dumps every thread's stack and exits (0: never): a rank stuck in a "
+                         "collective or a device call must end the job, not hold the box")
     args = ap.parse_args()
+    if args.watchdog > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)
 
     import torch
     import torch.distributed as dist
@@ -505,6 +511,12 @@ def main():
     # The pool-resident render kernel (s2r_set_resident: a fill is a posted command, no launch).  On by default where the host's
     # share of a step decides (N > 1: every rank resolves the whole pool's events); at N = 1 the launches' two-stream form is
     # as fast on the GPU side and is what is timed (S2R_BENCH_RESIDENT=1 / 0 force either: tools/ab_modes.sh).
+    # (The rehearsal in which the ranks SHARE one card is only sound while all their grids fit the card together: a fill's kernels
+    # wait for one another inside the launch — bounded, 50 ms — on the understanding that the handle's grid is alone on its device,
+    # which one process per GPU guarantees and two processes on one card do not; with grids that do not fit, the waits run out.)
+    if os.environ.get("S2R_BENCH_SHARE_GPU") == "1" and world * (vpg // max(1, block_voices)) > torch.cuda.get_device_properties(dev).multi_processor_count:
+        sys.exit("S2R_BENCH_SHARE_GPU=1: %d ranks x %d workgroups do not fit this card's %d compute units together; rehearse with a smaller "
+                 "--voices-per-gpu (tests/test_bench_rehearsal.py uses 8192)" % (world, vpg // max(1, block_voices), torch.cuda.get_device_properties(dev).multi_processor_count))
     resident = host_api and os.environ.get("S2R_BENCH_RESIDENT", "1" if world > 1 else "0") != "0"
     if resident:
         synth.set_resident(True)

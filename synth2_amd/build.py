@@ -31,10 +31,21 @@ HEADERS = ["s2r_device.h", "s2r_math.h", "s2r_patch.h", "s2r_voices.h", "s2r_ker
 # a wrong result of one variant of the general render kernel at -O3; it belonged to an uncommitted intermediate and has
 # not been reproduced since — the committed sources of every round pass the whole GPU suite and the fuzzer at -O3 too
 # (S2R_OPT=O3 below builds them that way), so nothing here claims a compiler fault.
+# -ftrivial-auto-var-init=zero: every local the source leaves without a value starts as zero bits.  Round 4 met a result that
+# depended on code nowhere near it: the patch bank's pool-resident kernel rendered one restarted LP2 voice 7e-4 off after an
+# unrelated block was added to fused_tail — identically at -O0, -O1 and -O2, right again after any edit to general_fill (a counter,
+# a printf) and under this flag with either fill pattern; the launch-per-fill kernel of the same source was right throughout.
+# The read of an indeterminate local that this points at has not been found (CHANGELOG, round 4); until it is, the kernels are
+# built so that there is no indeterminate local to read: what the tests then hold against the oracle is the only behaviour
+# the source has.  (No measurable cost: the optimiser drops the stores it can prove dead.)
 FLAGS = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-         "-mllvm", "-amdgpu-sched-strategy=max-ilp",
+         "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-ftrivial-auto-var-init=zero",
          "-fPIC", "-Wall", "-Wno-unused-function"]
 
+
+PER_FILE_FLAGS = {}
+if os.environ.get("S2R_EXPERIMENT_BANK_FLAGS"):                 # (development: extra flags for the patch-bank translation unit)
+    PER_FILE_FLAGS["s2r_render_general_bank.hip"] = os.environ["S2R_EXPERIMENT_BANK_FLAGS"].split()
 
 # S2R_OPT=O3 in the environment builds the same sources at -O3 into libs2r_o3.so (tools and tests that compare the two
 # optimisation levels; the product is -O2).
@@ -115,7 +126,11 @@ def needs_build(csrc=None):
 
 def _compile_one(args):
     cc, src, obj, verbose, extra, stamp = args
-    cmd = [cc] + FLAGS + extra + ["-x", "hip", "-c", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", obj, src]
+    flags = list(FLAGS)
+    for drop in [x[len("drop:"):] for x in extra if x.startswith("drop:")]:     # (development: "drop:<flag>" among a file's extra flags removes it)
+        flags = [f for f in flags if f != drop]
+    extra = [x for x in extra if not x.startswith("drop:")]
+    cmd = [cc] + flags + extra + ["-x", "hip", "-c", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", obj, src]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
@@ -176,7 +191,7 @@ def build(force=False, verbose=False, jobs=None):
         src, obj = os.path.join(CSRC, f), os.path.join(OBJ_DIR, os.path.splitext(f)[0] + ".o")
         objs.append(obj)
         # (s2r_host.cpp carries the build id: S2R_BUILD_ID, the marker embedded_build_id() looks for)
-        extra = ['-DS2R_BUILD_ID="%s"' % bid] if f == "s2r_host.cpp" else []
+        extra = ['-DS2R_BUILD_ID="%s"' % bid] if f == "s2r_host.cpp" else list(PER_FILE_FLAGS.get(f, []))
         h = hh.copy(); h.update(open(src, "rb").read()); h.update(repr(extra).encode())
         stamp = h.hexdigest()
         try:
@@ -196,7 +211,8 @@ def build(force=False, verbose=False, jobs=None):
     if embedded_build_id() != bid:
         raise RuntimeError("the linked library does not carry the build id %s" % bid)
     try:
-        check_m0_contract()
+        if os.environ.get("S2R_DEBUG_NO_M0_CHECK") != "1":       # (debugging builds with printf in a kernel: the host call uses M0)
+            check_m0_contract()
     except RuntimeError:
         os.replace(LIB, LIB + ".rejected")                      # (never loadable under its own name)
         raise

@@ -224,7 +224,7 @@ struct s2r_synth {
     bool xg_on = false;
     uint32_t xg_rank = 0, xg_n = 0, xg_target[2] = {0, 0};
     float *xg_rows = nullptr;                    // [2][xg_n][max_frames]
-    uint32_t *xg_done = nullptr;                 // [2], behind the rows
+    uint32_t *xg_done = nullptr;                 // [2] counters behind the rows, then [2] words `consumed` (the root's: fused_tail)
     void *xg_block = nullptr; bool xg_owner = false;
     bool force_stage = false, force_peer = false;   // S2R_FORCE_STAGE / S2R_FORCE_PEER: the multi-device branches on one device (tests)
     // The pool-resident render kernel (S2rPool, s2r_device.h; s2r_set_resident): running on `stream` between fills while
@@ -1071,13 +1071,18 @@ int pool_launch(s2r_synth *s, uint32_t sample_rate, uint32_t first_seq) {
 int pool_recover(s2r_synth *s) {
     if (!s->pool_running || !pool_exited(s)) return S2R_OK;
     s->pool_running = false;
+    const bool dbg = std::getenv("S2R_DEBUG_STUCK") != nullptr;
+    if (dbg) std::fprintf(stderr, "[s2r rank %u] pool_recover: kernel %u has left; pool_seq %u\n", s->xg_rank, s->pool_launch_id, s->pool_seq);
     S2R_HIP(s, hipSetDevice(s->device));
     S2R_HIP(s, hipStreamSynchronize(s->stream));
     uint32_t d = 0;
     S2R_HIP(s, hipMemcpy(&d, s->pool_decided, sizeof d, hipMemcpyDeviceToHost));
     const uint32_t first = (d & 1u) ? (d >> 1) : (d >> 1) + 1u;  // (left at command d >> 1, or — no bail recorded — after it)
+    if (dbg) std::fprintf(stderr, "[s2r rank %u] pool_recover: decided %u -> first pending %u\n", s->xg_rank, d, first);
     if ((int32_t)(s->pool_seq - first) < 0) return S2R_OK;        // nothing was pending
-    return pool_launch(s, s->pool_rate, first);
+    const int rc = pool_launch(s, s->pool_rate, first);
+    if (dbg) std::fprintf(stderr, "[s2r rank %u] pool_recover: launched again (%d)\n", s->xg_rank, rc);
+    return rc;
 }
 
 // One fill through the pool-resident kernel: the events grouped by workgroup, the bounds, the command.  `sel`: where the output
@@ -1361,10 +1366,18 @@ int wait_done(s2r_synth *s, uint32_t idx, uint32_t seq) {
         timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
         const double us = (double)(t1.tv_sec - t0.tv_sec) * 1e6 + (double)(t1.tv_nsec - t0.tv_nsec) * 1e-3;
         const bool pool = s->pool_running || (!s->kids.empty() && s->kids[0]->pool_running);
-        if (us > (pool ? 200000.0 : 300.0)) break;               // (a resident kernel never ends a stream wait: only the word tells)
+        if (us > (pool ? 200000.0 : 300.0)) {                    // (a resident kernel never ends a stream wait: only the word tells)
+            if (std::getenv("S2R_DEBUG_STUCK"))
+                std::fprintf(stderr, "[s2r rank %u] wait_done(idx %u, seq %u): word %u after %.0f us; pool_running %d exited %d launch_id %u pool_host[0] %u pool_seq %u "
+                             "done_host %u %u %u %u ring_count %u\n", s->xg_rank, idx, seq, *f, us, (int)s->pool_running, (int)(s->pool_running && pool_exited(s)),
+                             s->pool_launch_id, s->pool_host ? s->pool_host[0] : 0u, s->pool_seq, s->done_host[0], s->done_host[1], s->done_host[2], s->done_host[3], s->ring_count);
+            break;
+        }
     }
     if (s->pool_running || (!s->kids.empty() && s->kids[0]->pool_running)) {
+        if (std::getenv("S2R_DEBUG_STUCK")) std::fprintf(stderr, "[s2r rank %u] wait_done: stopping the pool-resident kernel\n", s->xg_rank);
         (void)pool_stop(s);
+        if (std::getenv("S2R_DEBUG_STUCK")) std::fprintf(stderr, "[s2r rank %u] wait_done: stopped; word %u\n", s->xg_rank, *f);
         if ((int32_t)(*f - seq) < 0) return set_err(s, S2R_ERR_HIP, "the pool-resident kernel did not report the fill");
         return S2R_OK;
     }
@@ -2193,6 +2206,7 @@ int s2r_fill_end(s2r_synth *s, float *mono_out, size_t capacity) {
     // A fill that failed on the device is reported ONCE, with its buffer zeroed, and leaves the ring like any other: the next
     // s2r_fill_end is the next fill's (which, the handle being broken by then, reports that).
     int rc_fill = S2R_OK;
+    if (std::getenv("S2R_DEBUG_STUCK") && s->xg_on) { static thread_local unsigned n_calls = 0; if ((++n_calls & 15u) == 0u) std::fprintf(stderr, "[s2r rank %u] fill_end %u: waits for word %u (now %u)\n", s->xg_rank, n_calls, s->ring_seq[slot], s->done_host[slot]); }
     if (s->ring_seq[slot]) rc_fill = wait_done(s, slot, s->ring_seq[slot]);
     else if (hipEventSynchronize(s->ring_done[slot]) != hipSuccess) rc_fill = set_err(s, S2R_ERR_HIP, "hipEventSynchronize failed");
     if (rc_fill == S2R_OK) rc_fill = overlap_check(s);

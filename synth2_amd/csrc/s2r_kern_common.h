@@ -1092,6 +1092,19 @@ __device__ __forceinline__ void fused_tail(const S2rRenderParams &p, const FillC
     if (pos + mt.n_mixers < mt.n_blocks) return;                 // (uniform over the workgroup) not one of the last
     const uint32_t mixer = pos - (mt.n_blocks - mt.n_mixers);
     if (threadIdx.x == 0 && !ov_wait(ctl.arrive, ctl.arrive_target)) ov_raise(ctl.fail, 2u);
+    // A rank of a group of processes writes its row into the ROOT's memory, where each rows slot serves every other fill: the
+    // root must have added up the slot's previous fill before this one's row goes over it.  Nothing else holds a rank back — its
+    // own fills end when its rows are written — so a rank two fills ahead of the root waits here (word `consumed`, behind the
+    // slot's counter: the target of the last fill the root has added up from it); bounded like every wait.
+    if (threadIdx.x == 0 && mt.xmode == 2) {
+        const uint32_t *consumed = mt.rows_done + 2;
+        const uint32_t need = mt.rows_target - mt.n_rows;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while ((int32_t)(__hip_atomic_load(consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - need) < 0) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 5000000ull) { ov_raise(ctl.fail, 3u); break; }
+            __builtin_amdgcn_s_sleep(20);
+        }
+    }
     __syncthreads();
     S2R_TAIL_STAMP(5);
     S2rMixParams m{};
@@ -1153,7 +1166,11 @@ __device__ __forceinline__ void fused_tail(const S2rRenderParams &p, const FillC
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0 && mt.final_done.flag != nullptr) __hip_atomic_store(mt.final_done.flag, mt.final_done.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) {
+        // (the rows have been read: the slot is the ranks' again)
+        if (mt.xmode == 1) __hip_atomic_store(mt.rows_done + 2, mt.rows_target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (mt.final_done.flag != nullptr) __hip_atomic_store(mt.final_done.flag, mt.final_done.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // The pool-resident kernels' command loop (S2rPool, s2r_device.h): the shard's whole grid stays on the device; every workgroup
@@ -1186,14 +1203,18 @@ __device__ __forceinline__ void pool_loop(const S2rRenderArgs &a, const S2rPool 
                 uint32_t d = 0u;
                 if (lane == 0u) {
                     d = __hip_atomic_load(pl.decided, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (d != run_word && d != bail_word && complete) {
+                    if (d == (last << 1) && complete) {          // undecided, and the command is here: run it
                         uint32_t expected = last << 1;
                         d = __hip_atomic_compare_exchange_strong(pl.decided, &expected, run_word, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? run_word : expected;
                     }
                 }
                 d = (uint32_t)__builtin_amdgcn_readlane((int)d, 0);
                 if (d == bail_word) { leave = true; break; }
-                decided_run = d == run_word;
+                // Decisions only move forward, and a workgroup may be MORE than one behind the grid's: the one that adds up a fill's
+                // rows for a group of processes waits for the other ranks' (tens of milliseconds at worst) while its neighbours run
+                // the next command and — nothing further posted, patience 2 ms — decide to leave at the one after.  A decision about
+                // a LATER command says this one was run.
+                decided_run = d == run_word || (int32_t)((d >> 1) - want) > 0;
                 if (decided_run && complete) {
                     if (lane < S2R_POOL_CMD_WORDS) s_cmd[lane] = w;
                     // (this workgroup's slice of the fill's records: a trip to host memory, spared when the fill brings none)

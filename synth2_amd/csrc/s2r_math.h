@@ -313,7 +313,7 @@ S2R_HD double s2r_reduce_fast(double x, int *np) {
 // exponent, in integer arithmetic; returns the remainder in [-pi/4, pi/4] and the quadrant
 S2R_HD double s2r_reduce_large(uint32_t xi, int *np) {
     // __inv_pio4: 4/pi = 0x1.45F306DC9C882A53F84EAFA3EA69BB81B6C52B3278872...p0 in 32-bit windows, 8 bits apart
-    const uint32_t inv_pio4[24] = {
+    static const uint32_t inv_pio4[24] = {                       // (static: a table in constant memory, not an array built on every call's stack)
         0xa2u, 0xa2f9u, 0xa2f983u, 0xa2f9836eu, 0xf9836e4eu, 0x836e4e44u, 0x6e4e4415u, 0x4e441529u,
         0x441529fcu, 0x1529fc27u, 0x29fc2757u, 0xfc2757d1u, 0x2757d1f5u, 0x57d1f534u, 0xd1f534ddu, 0xf534ddc0u,
         0x34ddc0dbu, 0xddc0db62u, 0xc0db6295u, 0xdb629599u, 0x6295993cu, 0x95993c43u, 0x993c4390u, 0x3c439041u};

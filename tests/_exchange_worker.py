@@ -1,6 +1,8 @@
 """one rank of a group of processes sharing the card (tests/test_gpu_exchange.py): its shard of the pool, the exchange through the
 root's block (s2r_exchange_create / _attach), the same events on every rank; rank 0 saves the buffers it gets
-usage: _exchange_worker.py RANK N DIR VOICES_TOTAL BUFFERS RESIDENT"""
+usage: _exchange_worker.py RANK N DIR VOICES_TOTAL BUFFERS RESIDENT [free]
+free: no barrier between the ranks' steps — the root dawdles (pauses of up to 4 ms: past a resident kernel's patience), the others run
+as fast as their own fills allow, and what keeps a rank from writing fill k + 2's row over fill k's unread one is the library's."""
 import os
 import sys
 import time
@@ -11,6 +13,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import synth2_amd as s2  # noqa: E402
 
 rank, n, d, V, K, resident = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+free = len(sys.argv) > 7 and sys.argv[7] == "free"
+pause_rng = np.random.RandomState(7)
 
 
 def wait_for(name, timeout=120.0):
@@ -58,6 +62,12 @@ for k in range(K):
         in_flight.append(k)
         if len(in_flight) == 2:
             s.sample_end(out[in_flight.pop(0)])
+    if free:
+        if rank == 0 and pause_rng.rand() < 0.5:
+            t_end = time.perf_counter() + float(pause_rng.choice([2e-4, 1e-3, 4e-3]))
+            while time.perf_counter() < t_end:
+                pass
+        continue
     # (the ranks stay within a few fills of each other: the root's last workgroup waits 50 ms at most for a rank's row)
     touch("step%d_%d" % (rank, k))
     for r in range(n):

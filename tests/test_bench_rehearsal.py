@@ -54,3 +54,24 @@ def test_two_rank_bench_flow_on_one_gpu():
     # only the order of magnitude of the checksum is comparable here; the bit-level equivalence of the
     # sharded sum is tests/test_gpu_parity.py::test_mix_groups_reproduce_multi_gpu_order
     assert 0.1 < d["mix_checksum"] / float(np.abs(buf).sum()) < 10.0
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_flow_with_resident_kernels_and_the_in_kernel_exchange():
+    """what `bench.py --gpus N` runs by default — the C3 workload, pool-resident kernels, the rows exchanged inside the kernels — as
+    two ranks on one card (16 384 voices each: both grids fit it together).  Round 4: this hung every time.  A resident kernel's
+    workgroups leave after 2 ms without a command; the root's last mixer may wait tens of milliseconds for another rank's row, and
+    when it came back its neighbours had run the next command and decided to leave at the one after — a decision two ahead of
+    its own, which the command loop did not read as "run yours" (s2r_kern_common.h, pool_loop).  Twice, back to back."""
+    for attempt in range(2):
+        env = dict(os.environ, S2R_BENCH_BACKEND="gloo", S2R_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+               "--gpus", "2", "--steps", "20", "--warmup", "5", "--voices-per-gpu", "16384", "--watchdog", "60"]
+        out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["config"]["voices_total"] == 2 * 16384 and d["value"] > 0
+        assert "resident" in d["config"]["timed_call"] and "exchange" in d["config"]["parallelism"], d["config"]

@@ -15,11 +15,14 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("resident", [0, 1])
-def test_two_processes_exchange_rows_through_the_roots_block(tmp_path, resident):
-    V, K, n = 16384, 12, 2
+@pytest.mark.parametrize("resident,pace,K", [(0, "lockstep", 12), (1, "lockstep", 12), (0, "free", 60), (1, "free", 60)])
+def test_two_processes_exchange_rows_through_the_roots_block(tmp_path, resident, pace, K):
+    """pace "free": nothing outside the library keeps the ranks together — the root pauses at random (up to 4 ms, past a resident
+    kernel's patience), the other rank runs ahead as far as its own two fills in flight allow and must wait, inside its kernels,
+    for the root to have added up a rows slot's previous fill before it writes the next one's row there"""
+    V, n = 16384, 2
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_exchange_worker.py"), str(r), str(n), str(tmp_path), str(V), str(K), str(resident)],
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_exchange_worker.py"), str(r), str(n), str(tmp_path), str(V), str(K), str(resident)] + (["free"] if pace == "free" else []),
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(n)]
     outs = [p.communicate(timeout=300) for p in procs]
     for r, (p, (so, se)) in enumerate(zip(procs, outs)):

@@ -215,3 +215,42 @@ def test_device_list_exchange_in_the_kernels(n, interleave, resident):
         got = multi.sample(np.empty(1000, dtype=np.float32), SR).copy()
         assert_bits_equal(got, want_of(ora.render_events(ev, 1000, SR, threads=_threads())), "device list of %d, s2r_fill %d" % (n, k))
     assert multi.resident_active == resident
+
+
+def test_a_voice_restarted_among_other_programs_in_the_pool_resident_bank_kernel():
+    """Round 4's stray result, kept as found (delta-debugged from the test above): one note held, then 26 note-ons inside the next
+    buffer — programs 0, 2 (DPW + SVF: the wave leaves the branch-free chunk) and, last, 1 (sine + LP2 + noise, started at frame
+    976).  A build with an unrelated block added to fused_tail rendered that last voice 7e-4 off in the pool-resident kernel only
+    (synth2_amd/build.py, -ftrivial-auto-var-init); its 48 frames go through the frame loop with fresh LP2 coefficients per frame."""
+    voices = 2048
+    bank = [make_patch(osc_kind=s2.OSC_SAW), make_patch(osc_kind=s2.OSC_SINE, lpf_kind=s2.FILT_LP2, lpf_freq=900.0, noise=0.2),
+            make_patch(osc_kind=s2.OSC_DPW_SAW, lpf_kind=s2.FILT_SVF_LP, lpf_q=1.3)]
+
+    def evs(lst):
+        ev = np.zeros(len(lst), dtype=s2.NOTE_EVENT_DTYPE)
+        for j, (kind, note, frame) in enumerate(lst):
+            ev["kind"][j] = kind; ev["note"][j] = note; ev["frame"][j] = frame; ev["velocity"][j] = 1.0
+        return ev
+
+    b0 = evs([(1, 89, 0)])
+    b1 = evs([(1, 36, 816), (1, 45, 816), (1, 87, 816), (1, 81, 832), (1, 60, 832), (1, 47, 832), (1, 50, 848), (1, 76, 848), (1, 78, 848),
+              (1, 88, 848), (1, 74, 848), (1, 56, 864), (1, 95, 864), (1, 84, 864), (1, 70, 880), (1, 44, 880), (1, 64, 880), (1, 53, 880),
+              (2, 2, 912), (1, 52, 912), (1, 42, 944), (1, 96, 944), (1, 71, 960), (1, 51, 960), (1, 70, 960), (1, 87, 960), (2, 1, 960), (1, 46, 976)])
+    for resident in (False, True):
+        gpu = s2.Synth(voices, max_frames=1024)
+        ora = s2o.OracleSynth(voices)
+        gpu.set_patch_bank(bank)
+        ora.set_bank([oracle_cfg_from_patch(q) for q in bank])
+        gpu.set_resident(resident)
+        for k, ev in enumerate((b0, b1)):
+            gpu.note_events(ev)
+            got = gpu.sample(1024, SR).copy()
+            pv = ora.render_events(ev, 1024, SR, threads=_threads())
+            assert_bits_equal(got, s2o.mix_tree(pv, gpu.block_voices, 1), "resident %d, buffer %d" % (resident, k))
+        st = gpu.export_state()
+        for i in range(27):
+            v = ora.voice(i)
+            for name, a, b in (("phase", st["phase_accum"][i], v.state.phase_accum), ("x1", st["filt_x1"][i], v.state.x1), ("x2", st["filt_x2"][i], v.state.x2),
+                               ("y1", st["filt_y1"][i], v.state.y1), ("y2", st["filt_y2"][i], v.state.y2), ("lpf_last", st["lpf_last"][i], v.state.lpf_last)):
+                assert np.float32(a).view(np.uint32) == np.float32(b).view(np.uint32), "resident %d, voice %d: %s" % (resident, i, name)
+        gpu.close()
