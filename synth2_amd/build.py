@@ -31,21 +31,25 @@ HEADERS = ["s2r_device.h", "s2r_math.h", "s2r_patch.h", "s2r_voices.h", "s2r_ker
 # a wrong result of one variant of the general render kernel at -O3; it belonged to an uncommitted intermediate and has
 # not been reproduced since — the committed sources of every round pass the whole GPU suite and the fuzzer at -O3 too
 # (S2R_OPT=O3 below builds them that way), so nothing here claims a compiler fault.
-# -ftrivial-auto-var-init=zero: every local the source leaves without a value starts as zero bits.  Round 4 met a result that
-# depended on code nowhere near it: the patch bank's pool-resident kernel rendered one restarted LP2 voice 7e-4 off after an
-# unrelated block was added to fused_tail — identically at -O0, -O1 and -O2, right again after any edit to general_fill (a counter,
-# a printf) and under this flag with either fill pattern; the launch-per-fill kernel of the same source was right throughout.
-# The read of an indeterminate local that this points at has not been found (CHANGELOG, round 4); until it is, the kernels are
-# built so that there is no indeterminate local to read: what the tests then hold against the oracle is the only behaviour
-# the source has.  (No measurable cost: the optimiser drops the stores it can prove dead.)
 FLAGS = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-         "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-ftrivial-auto-var-init=zero",
+         "-mllvm", "-amdgpu-sched-strategy=max-ilp",
          "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
 PER_FILE_FLAGS = {}
+# -ftrivial-auto-var-init=zero for the translation units of s2r_render_general.inc: every local that source leaves without a value
+# starts as zero bits.  Round 4 met a result that depended on code nowhere near it: the patch bank's pool-resident kernel
+# rendered one restarted LP2 voice 7e-4 off after an unrelated block was added to fused_tail — identically at -O0, -O1 and -O2,
+# right again after any edit to general_fill (a counter, a printf) and under this flag with either fill pattern; the
+# launch-per-fill kernel of the same source was right throughout.  The read of an indeterminate local that this points at has
+# not been found (CHANGELOG, round 4); until it is, these kernels are built so that there is no indeterminate local to read: what
+# the tests then hold against the oracle is the only behaviour the source has.  Not for the one-pole kernels (their own source,
+# never seen to move): the flag costs the timed kernel 3 % (A/B on one box: 0.0430 -> 0.0446 ms).
+for _f in ("s2r_render_general_square.hip", "s2r_render_general_saw.hip", "s2r_render_general_triangle.hip", "s2r_render_general_sine.hip",
+           "s2r_render_general_bank.hip"):
+    PER_FILE_FLAGS[_f] = ["-ftrivial-auto-var-init=zero"]
 if os.environ.get("S2R_EXPERIMENT_BANK_FLAGS"):                 # (development: extra flags for the patch-bank translation unit)
-    PER_FILE_FLAGS["s2r_render_general_bank.hip"] = os.environ["S2R_EXPERIMENT_BANK_FLAGS"].split()
+    PER_FILE_FLAGS["s2r_render_general_bank.hip"] = PER_FILE_FLAGS["s2r_render_general_bank.hip"] + os.environ["S2R_EXPERIMENT_BANK_FLAGS"].split()
 
 # S2R_OPT=O3 in the environment builds the same sources at -O3 into libs2r_o3.so (tools and tests that compare the two
 # optimisation levels; the product is -O2).
@@ -96,6 +100,7 @@ def build_id(csrc=None):
     h = hashlib.sha256()
     h.update(open(os.path.join(ROOT, "include", "s2r.h"), "rb").read())
     h.update(repr(FLAGS).encode())
+    h.update(repr(sorted(PER_FILE_FLAGS.items())).encode())
     return source_hash(csrc) + "-" + h.hexdigest()[:8]
 
 

@@ -8,6 +8,7 @@ TAG=${1:-run}; shift || true
 OUT=/root/repo/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
+export S2R_BENCH_SETTLE=0      # (bench.py: no extra warm-up blocks — tools/summarize_prof.py counts launches)
 cd /tmp
 ARGS="--steps 16 --warmup 4 --no-cpu-baseline --no-config-legs $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 /root/repo/bench.py $ARGS > $OUT/trace.log 2>&1 || echo "trace pass failed"

@@ -9,6 +9,7 @@ TAG=${1:-leg}; LEG=${2:-c2}
 OUT=/root/repo/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
+export S2R_BENCH_SETTLE=0      # (bench.py: no extra warm-up blocks — tools/summarize_prof.py counts launches)
 cd /tmp
 CMD="python3 /root/repo/tools/leg_prof.py $LEG 16 4"
 # (the counter passes serialise kernels: the two-stream fills wait for each other across streams in the kernels, so every pass but the trace runs on one stream)
