@@ -1045,14 +1045,22 @@ __device__ __forceinline__ void fused_heads(const FillCtl &ctl) {
     const uint32_t n_halves = (ctl.slice_hi - ctl.slice_lo) * 2u;
     for (uint32_t h0 = 0; h0 < n_halves; h0 += 4u * blockDim.x) {
         f4 v[4];
+        const float *src[4];
 #pragma unroll
         for (uint32_t k = 0; k < 4u; ++k) {
             const uint32_t h = h0 + k * blockDim.x + threadIdx.x;
             const uint32_t hc = h < n_halves ? h : 0u;
-            const float *src = reinterpret_cast<const float *>(ctl.tev_src + ctl.slice_lo + (hc >> 1)) + 4u * (hc & 1u);
-            asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[k]) : "v"(src) : "memory");
+            src[k] = reinterpret_cast<const float *>(ctl.tev_src + ctl.slice_lo + (hc >> 1)) + 4u * (hc & 1u);
         }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : : "memory");
+        // ONE statement for the four loads and their wait: an output of an asm statement is, to the compiler, a value that exists
+        // when the statement ends — with the wait in a statement of its own, a copy or a spill of a load's destination placed
+        // between the two would move a register the data has not reached yet (at -O0 it does exactly that)
+        asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\t"
+                     "global_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+                     "global_load_dwordx4 %2, %6, off sc0 sc1\n\t"
+                     "global_load_dwordx4 %3, %7, off sc0 sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]) : "memory");
 #pragma unroll
         for (uint32_t k = 0; k < 4u; ++k) {
             const uint32_t h = h0 + k * blockDim.x + threadIdx.x;
