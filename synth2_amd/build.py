@@ -135,7 +135,8 @@ def _compile_one(args):
     flags = list(FLAGS)
     for drop in [x[len("drop:"):] for x in extra if x.startswith("drop:")]:     # (development: "drop:<flag>" among a file's extra flags removes it)
         flags = [f for f in flags if f != drop]
-    extra = [x for x in extra if not x.startswith("drop:")]
+    drops = [x[len("drop:"):] for x in extra if x.startswith("drop:")]
+    extra = [x for x in extra if not x.startswith("drop:") and x not in drops]
     cmd = [cc] + flags + extra + ["-x", "hip", "-c", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", obj, src]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -21,6 +21,7 @@ def test_two_processes_exchange_rows_through_the_roots_block(tmp_path, resident,
     kernel's patience), the other rank runs ahead as far as its own two fills in flight allow and must wait, inside its kernels,
     for the root to have added up a rows slot's previous fill before it writes the next one's row there"""
     V, n = 16384, 2
+    K = int(os.environ.get("S2R_EXCHANGE_K", K))                 # (a soak: S2R_EXCHANGE_K=2000)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_exchange_worker.py"), str(r), str(n), str(tmp_path), str(V), str(K), str(resident)] + (["free"] if pace == "free" else []),
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(n)]
