@@ -611,6 +611,8 @@ def main():
             if shares[-1] < 0.62 or time.perf_counter() - t_settle > float(os.environ.get("S2R_BENCH_SETTLE_S", "45")):
                 break
             time.sleep(0.25)
+        for k in range(k0, k0 + args.steps + 80):
+            events_of(k)                          # (workload churn builds its batches on demand: never inside the timed region)
         settle = {"extra_warmup_steps": 64 * len(shares), "seconds": time.perf_counter() - t_settle, "host_share_first": shares[0], "host_share_last": shares[-1],
                   "note": "untimed: warm-up went on until the host's share of a step fell below 0.62 (the step GPU-bound, as the workload defines it) or 45 s had passed"}
     fence()
