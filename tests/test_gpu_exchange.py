@@ -15,12 +15,13 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("resident,pace,K", [(0, "lockstep", 12), (1, "lockstep", 12), (0, "free", 60), (1, "free", 60)])
-def test_two_processes_exchange_rows_through_the_roots_block(tmp_path, resident, pace, K):
+@pytest.mark.parametrize("resident,pace,K,n", [(0, "lockstep", 12, 2), (1, "lockstep", 12, 2), (0, "free", 60, 2), (1, "free", 60, 2),
+                                               (0, "free", 40, 4), (1, "free", 40, 4)])
+def test_two_processes_exchange_rows_through_the_roots_block(tmp_path, resident, pace, K, n):
     """pace "free": nothing outside the library keeps the ranks together — the root pauses at random (up to 4 ms, past a resident
     kernel's patience), the other rank runs ahead as far as its own two fills in flight allow and must wait, inside its kernels,
     for the root to have added up a rows slot's previous fill before it writes the next one's row there"""
-    V, n = 16384, 2
+    V = 16384                                                    # (n = 4: four processes on the card, 16 workgroups each)
     K = int(os.environ.get("S2R_EXCHANGE_K", K))                 # (a soak: S2R_EXCHANGE_K=2000)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_exchange_worker.py"), str(r), str(n), str(tmp_path), str(V), str(K), str(resident)] + (["free"] if pace == "free" else []),
@@ -31,6 +32,8 @@ def test_two_processes_exchange_rows_through_the_roots_block(tmp_path, resident,
     got = np.load(os.path.join(str(tmp_path), "out0.npy"))
     other = np.load(os.path.join(str(tmp_path), "out1.npy"))
     assert not other.any(), "a rank other than the root returns silence"
+    for r in range(2, n):
+        assert not np.load(os.path.join(str(tmp_path), "out%d.npy" % r)).any()
     # the same events on ONE device with mix_groups = 2
     one = s2.Synth(V, max_frames=1024, mix_groups=n)
     rng = np.random.RandomState(2024)
